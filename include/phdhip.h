@@ -1,0 +1,200 @@
+/*
+ * phdhip.h — C-ABI of libphdhip.so, the MI355X (gfx950) implementation of monorfs's
+ * Rao-Blackwellized PHD-SLAM inner loop.
+ *
+ * The library sits behind the reference's solver interface
+ *     abstract class Navigator<MeasurerT, PoseT, MeasurementT>
+ *     (mono-rfs-lib/SLAM/Navigators/Navigator.cs:47-396)
+ * and replaces the managed body of
+ *     PHDNavigator.SlamUpdate (mono-rfs-lib/SLAM/Navigators/PHDNavigator.cs:323-362)
+ * for the PRM3D model (Pose3D + PixelRangeMeasurement). The calling convention mirrors the
+ * reference's only native solver binding, ISAM2Lib (ISAM2Navigator.cs:600-622 <-> isam2/isam2.cpp:46-365):
+ *   - an opaque handle made by a `create` call and released by a `destroy` call;
+ *   - inputs are caller-owned flat `double*` / `int*`, read only for the duration of the call;
+ *   - outputs are library-owned host buffers returned as pointer + length, valid until the next
+ *     call on the same handle (the C# side copies them out, ISAM2Navigator.cs:507-593);
+ *   - booleans cross as one byte (UnmanagedType.U1, ISAM2Navigator.cs:609);
+ *   - every call returns an int status: 0 ok, >0 a specific condition, -1 generic failure
+ *     (isam2.cpp:317-335); no C++ exception ever crosses the boundary.
+ *
+ * Threading: one caller thread per handle, no re-entrancy (Simulation.Update drives the
+ * navigator from one thread, Simulation.cs:636-673). The library uses HIP streams internally.
+ *
+ * Matrix conventions: row-major; a 3-D Gaussian component is (weight, mean[3], cov[9]);
+ * a pose is (x, y, z, qw, qx, qy, qz) as in Pose3D (Pose3D.cs:142-162); a measurement is
+ * (px, py, range) as in PixelRangeMeasurement.ToLinear (PixelRangeMeasurement.cs:96-99).
+ */
+#ifndef PHDHIP_H
+#define PHDHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHD_API_VERSION 1
+
+/* status codes */
+#define PHD_OK                    0
+#define PHD_ERR_GENERIC          -1
+#define PHD_ERR_BAD_ARGUMENT      1   /* a size/pointer/flag is out of range                        */
+#define PHD_ERR_CAPACITY          2   /* a mixture outgrew its slab (raise max_components/emit_cap) */
+#define PHD_ERR_ASSOCIATION       3   /* data-association cluster beyond the on-device solver's cap;
+                                         surfaces as Data["module"]="association" (Simulation.cs:666) */
+#define PHD_ERR_DEVICE            4   /* HIP runtime error, see phd_last_error                       */
+#define PHD_ERR_NO_DEVICE         5   /* no gfx950 device / HIP runtime unavailable                  */
+
+/* dynamics model; only PRM3D runs on the device. LINEAR2D exists so that the unit KATs of
+ * PHDNavigatorTest.cs (Linear2D model) can be expressed with the same parameter block.     */
+#define PHD_MODEL_LINEAR2D 0
+#define PHD_MODEL_PRM3D    1
+
+/* radius-gate metric of Map.Near / Map.Evaluate(x, r) (Map.cs:170-184, 210-220): the reference
+ * delegates to Accord 3.0.2 KDTree.Nearest(point, radius), whose metric is not in the tree.   */
+#define PHD_GATE_SQUARED_EUCLIDEAN 1  /* |x-m|^2 <= radius   (Accord 3.0.x default distance) */
+#define PHD_GATE_EUCLIDEAN         0  /* |x-m|   <= radius                                   */
+#define PHD_GATE_DISABLED          2  /* every component is "near" (PHDNavigatorTest.Correct) */
+
+/*
+ * Every configuration value the path reads. Field <- reference origin:
+ */
+typedef struct phd_params {
+	int32_t model;                 /* Config.Model (Config.cs:47)                                      */
+	int32_t zdim;                  /* measurement dimension: 3 for PRM3D, 2 for Linear2D               */
+	double  measurer[7];           /* PRM3DMeasurer.ToLinear(): focal, rangemin, rangemax, filmX, filmY,
+	                                  filmW, filmH (PRM3DMeasurer.cs:92-96); rangemin/max are float32
+	                                  values widened to double (PRM3DMeasurer.cs:65,73).
+	                                  Linear2D: measurer[0] = Range (Linear2DMeasurer.cs:56-59)        */
+	double  R[9];                  /* MeasurementCovariance * MeasurementCovarianceMultiplier, zdim x zdim
+	                                  row-major in the leading entries (SimulatedVehicle.cs:159-168)  */
+	double  visibility_ramp[3];    /* Config.VisibilityRamp (Config.cs:257-259)                        */
+	double  pd;                    /* Config.NavigatorPD (Config.cs:90)                                */
+	double  clutter_density;       /* Config.NavigatorClutterDensity (Config.cs:91)                    */
+	double  birth_covariance[9];   /* Config.BirthCovariance (Config.cs:77-79)                         */
+	double  birth_weight;          /* Config.BirthWeight (Config.cs:80)                                */
+	double  min_weight;            /* Config.MinWeight (Config.cs:81)                                  */
+	double  min_effective_particle;/* Config.MinEffectiveParticle (Config.cs:82)                       */
+	int32_t max_quantity;          /* Config.MaxQuantity (Config.cs:83)                                */
+	int32_t gate_metric;           /* PHD_GATE_*                                                       */
+	double  merge_threshold;       /* Config.MergeThreshold (Config.cs:84)                             */
+	double  exploration_threshold; /* Config.ExplorationThreshold (Config.cs:85)                       */
+	double  density_distance_threshold; /* Config.DensityDistanceThreshold (Config.cs:74)              */
+	/* capacities of the device slabs (not reference values) */
+	int32_t max_particles;         /* particles this handle (this GPU's shard) can hold                */
+	int32_t max_components;        /* components per particle slab, >= max_quantity                    */
+	int32_t max_measurements;      /* measurements per frame                                           */
+	int32_t emit_capacity;         /* per-particle scratch for corrected-but-unpruned components;
+	                                  0 = library default                                              */
+} phd_params;
+
+typedef struct phd_navigator phd_navigator;
+
+/* Fill `p` with the PRM3D defaults of Config.SetPRM3DDefaults (Config.cs:238-263) and the PHD
+ * constants of Config.cs:74-91; capacities are set from the three arguments.                   */
+void phd_default_params(phd_params* p, int max_particles, int max_components, int max_measurements);
+
+/* ≙ `new PHDNavigator(vehicle, particlecount, onlymapping)` (PHDNavigator.cs:192-208) and
+ * ISAM2Lib.newnavigator (ISAM2Navigator.cs:603). `device` is the HIP ordinal. NULL on failure;
+ * phd_create_error() then holds the reason.                                                     */
+phd_navigator* phd_create(const phd_params* params, int device);
+const char*    phd_create_error(void);
+/* ≙ Navigator.Dispose (Navigator.cs:395) / ISAM2Lib.deletenavigator.                             */
+void           phd_destroy(phd_navigator* nav);
+const char*    phd_last_error(const phd_navigator* nav);
+int            phd_api_version(void);
+
+/* ≙ PHDNavigator.reset (PHDNavigator.cs:245-266): `nparticles` equal particles at `pose`, each
+ * with a deep copy of the `ncomp`-component map and weight 1/nparticles; BestParticle = 0.
+ * Also serves CollapseParticles (:233-236) and ResetMapModel (:271-276, ncomp = 0).              */
+int phd_reset(phd_navigator* nav, int nparticles, const double* pose7,
+              const double* w, const double* mean3, const double* cov9, int ncomp);
+
+/* The host keeps the motion model and its RNG (TrackVehicle.UpdateNoisy, TrackVehicle.cs:89-102):
+ * after Navigator.Update (PHDNavigator.cs:295-314) it hands the particle poses over.             */
+int phd_set_poses(phd_navigator* nav, const double* poses7, int nparticles);
+/* Test/bench access to the public arrays VehicleWeights / MapModels (PHDNavigator.cs:128,134).   */
+int phd_set_weights(phd_navigator* nav, const double* weights, int nparticles);
+int phd_set_map(phd_navigator* nav, int particle, const double* w, const double* mean3,
+                const double* cov9, int ncomp);
+
+/* ≙ PHDNavigator.SlamUpdate (PHDNavigator.cs:323-362): predict, correct, prune and (unless
+ * `onlymapping`) reweight every particle, then normalise, pick BestParticle and resample if
+ * depleted. `u_resample` replaces `(double) Util.Uniform.Next()` of ResampleParticles
+ * (PHDNavigator.cs:727): the RNG stays on the host. Blocking.                                    */
+int phd_slam_update(phd_navigator* nav, const double* z3, int nmeasurements,
+                    uint8_t onlymapping, double u_resample);
+
+/* The same step split so that measurements can be resident before a timed region:
+ * upload, enqueue (asynchronous on the handle's stream), wait + collect status.                  */
+int phd_set_measurements(phd_navigator* nav, const double* z3, int nmeasurements);
+int phd_step_async(phd_navigator* nav, uint8_t onlymapping, double u_resample);
+int phd_sync(phd_navigator* nav);
+/* Benchmark aid: when frozen, a step reads the current state but does not replace it, so every
+ * step sees identical input sizes (SURVEY §8d "steady state").                                   */
+int phd_set_frozen(phd_navigator* nav, uint8_t frozen);
+
+/* Getters. Buffers are library-owned and valid until the next call on the handle.               */
+const double* phd_weights(phd_navigator* nav, int* length);               /* VehicleWeights       */
+int           phd_best_particle(phd_navigator* nav);                       /* BestParticle         */
+const double* phd_poses(phd_navigator* nav, int* length);                  /* 7 per particle       */
+int           phd_particle_count(phd_navigator* nav);
+/* ≙ MapModels[particle] (PHDNavigator.cs:134) / BestMapModel (:155-161): n components,
+ * w[n], mean[3n], cov[9n] row-major like isam2.cpp:95-119.                                       */
+int phd_map(phd_navigator* nav, int particle, int* ncomp,
+            const double** w, const double** mean3, const double** cov9);
+/* Source slot of every particle in the last step (identity when no resampling happened); the
+ * host applies it to its own per-particle objects (trajectories). `resampled` <- 0/1.           */
+const int32_t* phd_resample_sources(phd_navigator* nav, int* length, uint8_t* resampled);
+
+/* Stage-level entry points for the unit KATs (PHDNavigator public methods). Each acts on one
+ * particle of the handle's state; `phd_map`-style getters read the result back.
+ *   phd_predict       ≙ PredictConditional (PHDNavigator.cs:793-819): state map -> predicted
+ *   phd_correct       ≙ CorrectConditional (:829-906) fused with the MinWeight cut of PruneModel
+ *   phd_prune         ≙ PruneModel (:913-948)
+ *   phd_weight_alpha  ≙ WeightAlpha (:373-393)
+ * `phd_stage_run` runs predict→correct→prune(→alpha) on every particle without the weight
+ * normalisation / resampling, leaving per-stage results readable through phd_stage_map.          */
+#define PHD_STAGE_PREDICTED 0
+#define PHD_STAGE_CORRECTED 1   /* corrected components with weight >= MinWeight, unsorted */
+#define PHD_STAGE_PRUNED    2
+int phd_stage_run(phd_navigator* nav, const double* z3, int nmeasurements, uint8_t with_alpha);
+int phd_stage_map(phd_navigator* nav, int stage, int particle, int* ncomp,
+                  const double** w, const double** mean3, const double** cov9);
+const double* phd_stage_alpha(phd_navigator* nav, int* length);      /* WeightAlpha per particle  */
+const double* phd_stage_setloglik(phd_navigator* nav, int* length);  /* SetLogLikelihood          */
+
+/* ≙ ResampleParticles (:724-760), ParticleDepleted (:768-777) on caller-supplied weights.        */
+int phd_resample(phd_navigator* nav, const double* weights, int nparticles, double u_resample,
+                 int32_t* sources, int32_t* best_particle);
+int phd_particle_depleted(phd_navigator* nav, const double* weights, int nparticles, uint8_t* depleted);
+
+/* ---- multi-GPU (one handle per GPU, particles sharded contiguously) ---------------
+ * The step is split around the one exchange the path has (PHDNavigator.cs:343-358):
+ *   phd_step_local_async : predict/correct/prune/reweight of the local shard;
+ *   the host all-gathers the un-normalised local weights (RCCL over xGMI);
+ *   phd_step_global_async: normalise, BestParticle, depletion test and systematic resampling on
+ *                          the gathered vector (identical on every rank), local part of the copy;
+ * Device pointers are exposed so the collective runs on device memory without staging.          */
+int   phd_step_local_async(phd_navigator* nav, uint8_t onlymapping);
+void* phd_device_local_weights(phd_navigator* nav);                 /* double[local particles]     */
+void* phd_device_global_weights(phd_navigator* nav, int world_particles); /* double[world]         */
+int   phd_step_global_async(phd_navigator* nav, int rank, int world_size, double u_resample);
+/* Particle migration after a global resample: packs the particles other ranks need into a
+ * contiguous device buffer (send), and unpacks what arrived (recv). Counts are in particles.    */
+int   phd_migration_plan(phd_navigator* nav, int rank, int world_size,
+                         int32_t* send_counts, int32_t* recv_counts);
+void* phd_migration_send_buffer(phd_navigator* nav, int64_t* bytes_per_particle);
+void* phd_migration_recv_buffer(phd_navigator* nav);
+int   phd_migration_pack_async(phd_navigator* nav);
+int   phd_migration_unpack_async(phd_navigator* nav);
+void* phd_stream(phd_navigator* nav);                               /* hipStream_t of the handle   */
+
+/* per-kernel device time of the last completed step in milliseconds (HIP events on the handle's
+ * stream): names[i] -> ms[i]; returns the number of entries.                                     */
+int phd_last_timings(phd_navigator* nav, const char*** names, const double** ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHDHIP_H */

@@ -1,0 +1,214 @@
+"""Pins the CPU oracle to every known-answer vector the reference's own tests hold for the hot path
+(tests/golden/*.json, transcribed from mono-rfs-lib/Test/*.cs by tests/golden/make_kat_fixtures.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from monorfs_amd.abi import PHD_GATE_DISABLED, PHD_GATE_SQUARED_EUCLIDEAN, params_from_dict, prm3d_defaults
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    with open(os.path.join(GOLD, name + ".json")) as f:
+        return json.load(f)
+
+
+def mix_of(lst):
+    return (np.array([g["w"] for g in lst], float), np.array([g["mean"] for g in lst], float).reshape(-1, 3),
+            np.array([g["cov"] for g in lst], float).reshape(-1, 3, 3))
+
+
+def assert_same_set(got, expected, tol):
+    """PHDNavigatorTest's matcher: every expected component is found once (Gaussian.Equals, 1e-5)."""
+    gw, gm, gc = got
+    assert len(gw) == len(expected)
+    left = list(range(len(gw)))
+    for e in expected:
+        hit = None
+        for i in left:
+            if (abs(gw[i] - e["w"]) <= tol and np.all(np.abs(gm[i] - np.array(e["mean"])) <= tol)
+                    and np.all(np.abs(gc[i] - np.array(e["cov"])) <= tol)):
+                hit = i
+                break
+        assert hit is not None, "component not found: %r" % (e,)
+        left.remove(hit)
+
+
+# ---------------------------------------------------------------- PHDNavigatorTest (Linear2D)
+KAT = load("phdnavigator_kat")
+
+
+def test_predict_initial():
+    p = params_from_dict(KAT["params"])
+    k = KAT["predict_initial"]
+    got = orc.predict(p, KAT["pose"] + [0.0], k["measurements"], mix_of(k["model"]))
+    assert_same_set(got, k["expected"], KAT["tolerance"])
+
+
+def test_predict_known():
+    p = params_from_dict(KAT["params"])
+    k = KAT["predict_known"]
+    got = orc.predict(p, KAT["pose"] + [0.0], k["measurements"], mix_of(k["model"]))
+    assert_same_set(got, k["expected"], KAT["tolerance"])
+
+
+def test_correct_ungated():
+    # the reference test expects all four pairs although the components are 0-4 m from the
+    # measurements: it pins the ungated formula
+    d = dict(KAT["params"], gate_metric=PHD_GATE_DISABLED)
+    p = params_from_dict(d)
+    k = KAT["correct"]
+    got = orc.correct(p, KAT["pose"] + [0.0], k["measurements"], mix_of(k["model"]))
+    assert_same_set(got, k["expected"], KAT["tolerance"])
+
+
+def test_correct_gated_drops_far_pairs():
+    # our own gated KAT: with the squared-Euclidean radius 0.5 only (z1,c1) and (z2,c2)... are near:
+    # z1 -> (3,5,0) hits c1 (distance 0), z2 -> (6,5,0) is 1 m from c2 (sq. distance 1 > 0.5) and 3 m from c1
+    d = dict(KAT["params"], gate_metric=PHD_GATE_SQUARED_EUCLIDEAN)
+    p = params_from_dict(d)
+    k = KAT["correct"]
+    w, m, c = orc.correct(p, KAT["pose"] + [0.0], k["measurements"], mix_of(k["model"]))
+    assert len(w) == 3
+    # the lone pair's weight is PD w q / (kappa + PD w q)
+    assert abs(w[2] - 1.0) < 1e-4
+
+
+def test_prune():
+    p = params_from_dict(KAT["params"])
+    k = KAT["prune"]
+    got = orc.prune(p, mix_of(k["model"]))
+    assert_same_set(got, k["expected"], KAT["tolerance"])
+
+
+# ---------------------------------------------------------------- GraphCombinatoricsTest
+GC = load("graphcombinatorics_kat")
+
+
+def mat(m):
+    return np.array([[float(x) for x in row] for row in m], float)
+
+
+@pytest.mark.parametrize("case", GC["connected_components"], ids=lambda c: c["name"])
+def test_connected_components(case):
+    n, rl, cl = orc.connected_components(case["defined"], case["n"], case["n"])
+    assert n == case["count"]
+    # partition property (GraphCombinatoricsTest.cs:131-172): both ends of an entry share a label
+    for i, k in case["defined"]:
+        assert rl[i] == cl[k] >= 0
+
+
+@pytest.mark.parametrize("case", GC["assignment_value"])
+def test_assignment_value(case):
+    assert orc.assignment_value(mat(case["matrix"]), case["matches"]) == case["expected"]
+
+
+@pytest.mark.parametrize("case", GC["linear_assignment"], ids=lambda c: c["name"])
+def test_hungarian(case):
+    assert orc.hungarian(mat(case["matrix"])) == case["expected"]
+
+
+@pytest.mark.parametrize("case", GC["lexicographical"], ids=lambda c: "modelsize%d" % c["modelsize"])
+def test_lexicographical(case):
+    perms, _ = orc.lexicographic(mat(case["matrix"]), case["modelsize"])
+    assert perms == case["expected"]
+
+
+@pytest.mark.parametrize("case", GC["murty_children"], ids=["with_duplicates", "none"])
+def test_murty_children(case):
+    got = orc.murty_children(case["forced"], case["eliminated"], case["assignment"])
+    assert len(got) == len(case["expected"])
+    for e in case["expected"]:
+        assert e in got
+
+
+@pytest.mark.parametrize("case", GC["murty_pairing"], ids=["full_small", "unique"])
+def test_murty_pairing(case):
+    asg, val = orc.murty(mat(case["matrix"]))
+    assert asg == case["expected"]
+    assert np.all(np.diff(val) <= 0)
+
+
+# ---------------------------------------------------------------- SimulationTest.resample
+def test_resample_systematic():
+    k = load("resample_kat")
+    w = np.array(k["weights"])
+    missing = {s: 0 for s in k["sometimes_absent"]}
+    us = np.concatenate([np.linspace(1e-9, 1 - 1e-9, 20001), np.random.default_rng(7).random(2000)])
+    for u in us:
+        src, best = orc.resample(w, float(u))
+        assert src[best] == k["best_source"]
+        assert np.all(np.diff(src) >= 0)
+        for s in k["always_present"]:
+            assert s in src
+        for s in missing:
+            missing[s] += s not in src
+    for s, cnt in missing.items():
+        assert cnt > 0, "particle %d was never dropped" % s
+
+
+def test_resample_u_zero_is_clamped():
+    src, best = orc.resample(np.array([0.25, 0.25, 0.5]), 0.0)
+    assert src[0] == 0 and src.min() >= 0
+
+
+def test_particle_depleted():
+    p = prm3d_defaults()
+    assert not orc.particle_depleted(p, np.full(20, 0.05))
+    w = np.full(20, 1e-6)
+    w[3] = 1 - 19e-6
+    assert orc.particle_depleted(p, w)
+
+
+# ---------------------------------------------------------------- measurement model (QuaternionTest / Pose3DTest conventions)
+def test_prm3d_measure_roundtrip_and_jacobian():
+    p = prm3d_defaults()
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        q = rng.normal(size=4)
+        pose = np.concatenate([rng.normal(size=3) * 0.3, q])
+        z = np.array([rng.uniform(-300, 300), rng.uniform(-220, 220), rng.uniform(0.3, 1.8)])
+        x = orc.measure_to_map(p, pose, z)
+        z2 = orc.measure_perfect(p, pose, x)
+        assert np.allclose(z2, z, rtol=1e-9, atol=1e-9)
+        H = orc.jacobian_l(p, pose, x)
+        eps = 1e-6
+        Hn = np.zeros((3, 3))
+        for a in range(3):
+            dx = np.zeros(3)
+            dx[a] = eps
+            Hn[:, a] = (orc.measure_perfect(p, pose, x + dx) - orc.measure_perfect(p, pose, x - dx)) / (2 * eps)
+        assert np.allclose(H, Hn, rtol=1e-5, atol=1e-4)
+
+
+def test_quaternion_matrix_matches_sandwich():
+    # Quaternion.ToMatrix (Quaternion.cs:327-342) == v -> q v q*  (QuaternionTest conventions)
+    rng = np.random.default_rng(11)
+    import ctypes as C
+    for _ in range(20):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        v = rng.normal(size=3)
+        r = np.zeros(9)
+        o = np.zeros(3)
+        orc.lib.orc_quat_matrix(q.ctypes.data_as(orc.dp), r.ctypes.data_as(orc.dp))
+        orc.lib.orc_quat_rotate(q.ctypes.data_as(orc.dp), v.ctypes.data_as(orc.dp), o.ctypes.data_as(orc.dp))
+        assert np.allclose(r.reshape(3, 3) @ v, o, atol=1e-12)
+
+
+def test_fuzzy_visibility_ramp():
+    p = prm3d_defaults()
+    pose = np.array([0, 0, 0, 1, 0, 0, 0.0])
+    centre = orc.measure_to_map(p, pose, np.array([0.0, 0.0, 1.0]))
+    assert abs(orc.detection_probability(p, pose, centre) - 0.9) < 1e-15
+    outside = orc.measure_to_map(p, pose, np.array([330.0, 0.0, 1.0]))
+    assert orc.detection_probability(p, pose, outside) == 0.0
+    # float32 range clip: 0.1f is slightly above 0.1 (PRM3DMeasurer.cs:73)
+    edge = orc.measure_to_map(p, pose, np.array([0.0, 0.0, 0.1]))
+    assert orc.detection_probability(p, pose, edge) == 0.0
+    half = orc.measure_to_map(p, pose, np.array([-320 + 1.5 * np.sqrt(2.0), 0.0, 1.0]))
+    assert abs(orc.detection_probability(p, pose, half) - 0.45) < 1e-9
