@@ -1,0 +1,311 @@
+// phd_device.h — device-side parameter block and FP64 math of the PRM3D measurement model.
+// gfx950 only. Everything is IEEE double like the reference (all state is `double[]`/`double[][]`).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PHD_WAVE 64
+
+// Parameters as the kernels consume them (built once on the host from phd_params).
+struct DevParams {
+	// PRM3DMeasurer (PRM3DMeasurer.cs:55-73): focal, float32 range clip, integer film rectangle
+	double focal;
+	double rmin, rmax;
+	double left, right, top, bottom;
+	double ramp[3];
+	double R[9];            // measurement covariance
+	double Rinv[9];         // its inverse (Gaussian(mlinear, R, pd) in SetLogLikeMatrix, PHDNavigator.cs:429)
+	double logRmult;        // log of that Gaussian's multiplier
+	double pd, kappa, logkappa;
+	double birthP[6];       // BirthCovariance, upper triangle
+	double birthw;
+	double minw;
+	double expl_thr;
+	double r_correct;       // DensityDistanceThreshold         (PHDNavigator.cs:882)
+	double r_explore;       // 3 * DensityDistanceThreshold     (PHDNavigator.cs:958)
+	double merge_thr2;      // MergeThreshold^2                 (Gaussian.cs:245)
+	double min_eff;
+	double emit_log_floor;  // log(minw * kappa): no emitted weight can come from below it
+	int    gate_metric;
+	int    maxq;
+};
+
+#define PHD_INV_2PI 0.15915494309189535   // Math.Pow(2 * Math.PI, -3 / 2) with C# integer division (Gaussian.cs:155)
+
+struct PoseD {
+	double t[3];
+	double qw, qx, qy, qz;   // normalised (Pose3D.cs:157-161)
+};
+
+__device__ __forceinline__ PoseD load_pose(const double* __restrict__ s)
+{
+	PoseD p;
+	p.t[0] = s[0]; p.t[1] = s[1]; p.t[2] = s[2];
+	double w = s[3], x = s[4], y = s[5], z = s[6];
+	double a = 1.0 / sqrt(w * w + x * x + y * y + z * z);
+	p.qw = a * w; p.qx = a * x; p.qy = a * y; p.qz = a * z;
+	return p;
+}
+
+// Hamilton product (Quaternion.cs:295-301)
+__device__ __forceinline__ void qmul(double aw, double ax, double ay, double az,
+                                     double bw, double bx, double by, double bz,
+                                     double& w, double& x, double& y, double& z)
+{
+	w = aw * bw - (ax * bx + ay * by + az * bz);
+	x = aw * bx + ax * bw + ay * bz - az * by;
+	y = aw * by + ay * bw + az * bx - ax * bz;
+	z = aw * bz + az * bw + ax * by - ay * bx;
+}
+
+// local = q* (0, d) q : world -> sensor frame (PRM3DMeasurer.cs:141-142)
+__device__ __forceinline__ void to_local(const PoseD& p, const double d[3], double l[3])
+{
+	double w1, x1, y1, z1, w2;
+	qmul(p.qw, -p.qx, -p.qy, -p.qz, 0.0, d[0], d[1], d[2], w1, x1, y1, z1);
+	qmul(w1, x1, y1, z1, p.qw, p.qx, p.qy, p.qz, w2, l[0], l[1], l[2]);
+}
+
+// Quaternion.Conjugate().ToMatrix() (Quaternion.cs:327-342 on (w, -x, -y, -z))
+__device__ __forceinline__ void conj_matrix(const PoseD& p, double r[9])
+{
+	double X = -p.qx, Y = -p.qy, Z = -p.qz, W = p.qw;
+	double xx = X * X, yy = Y * Y, zz = Z * Z;
+	double xy = X * Y, xz = X * Z, xw = X * W;
+	double yz = Y * Z, yw = Y * W, zw = Z * W;
+	r[0] = 1 - 2 * (yy + zz); r[1] = 2 * (xy - zw);     r[2] = 2 * (xz + yw);
+	r[3] = 2 * (xy + zw);     r[4] = 1 - 2 * (xx + zz); r[5] = 2 * (yz - xw);
+	r[6] = 2 * (xz - yw);     r[7] = 2 * (yz + xw);     r[8] = 1 - 2 * (xx + yy);
+}
+
+// MeasureToMap (PRM3DMeasurer.cs:299-312)
+__device__ __forceinline__ void measure_to_map(const DevParams& prm, const PoseD& p, const double z[3], double x[3])
+{
+	double f = prm.focal;
+	double alpha = z[2] / sqrt(f * f + z[0] * z[0] + z[1] * z[1]);
+	double dx = alpha * z[0], dy = alpha * z[1], dz = alpha * f;
+	double w1, x1, y1, z1, w2, rx, ry, rz;
+	qmul(p.qw, p.qx, p.qy, p.qz, 0.0, dx, dy, dz, w1, x1, y1, z1);
+	qmul(w1, x1, y1, z1, p.qw, -p.qx, -p.qy, -p.qz, w2, rx, ry, rz);
+	x[0] = p.t[0] + rx; x[1] = p.t[1] + ry; x[2] = p.t[2] + rz;
+}
+
+// MeasurePerfect (PRM3DMeasurer.cs:138-149); also returns the local vector for the Jacobian
+__device__ __forceinline__ void measure_perfect(const DevParams& prm, const PoseD& p, const double m[3],
+                                                double zh[3], double l[3])
+{
+	double d[3] = {m[0] - p.t[0], m[1] - p.t[1], m[2] - p.t[2]};
+	to_local(p, d, l);
+	double euclid = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+	double sgn = (l[2] > 0) ? 1.0 : ((l[2] < 0) ? -1.0 : 0.0);   // Math.Sign
+	zh[2] = sgn * euclid;
+	zh[0] = prm.focal * l[0] / l[2];
+	zh[1] = prm.focal * l[1] / l[2];
+}
+
+// FuzzyVisibleM (PRM3DMeasurer.cs:277-291) * detectionProbability (SimulatedVehicle.cs:335-338)
+__device__ __forceinline__ double detection_probability_m(const DevParams& prm, const double z[3])
+{
+	double mind = (z[0] - prm.left) / prm.ramp[0];
+	mind = fmin(mind, (prm.right - z[0]) / prm.ramp[0]);
+	mind = fmin(mind, (z[1] - prm.top) / prm.ramp[1]);
+	mind = fmin(mind, (prm.bottom - z[1]) / prm.ramp[1]);
+	mind = fmin(mind, (z[2] - prm.rmin) / prm.ramp[2]);
+	mind = fmin(mind, (prm.rmax - z[2]) / prm.ramp[2]);
+	return fmax(0.0, fmin(1.0, mind)) * prm.pd;
+}
+
+// MeasurementJacobianL (PRM3DMeasurer.cs:157-177): H = Jproj(local) * R(q*)
+__device__ __forceinline__ void jacobian_l(const DevParams& prm, const double l[3], const double rq[9], double H[9])
+{
+	double f = prm.focal;
+	double mag = ((l[2] > 0) ? 1.0 : -1.0) * sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
+	double jp[9] = {f / l[2], 0.0, -f * l[0] / (l[2] * l[2]),
+	                0.0, f / l[2], -f * l[1] / (l[2] * l[2]),
+	                l[0] / mag, l[1] / mag, l[2] / mag};
+#pragma unroll
+	for (int i = 0; i < 3; i++) {
+#pragma unroll
+		for (int j = 0; j < 3; j++) {
+			double s = 0;
+#pragma unroll
+			for (int k = 0; k < 3; k++) {
+				s += jp[i * 3 + k] * rq[k * 3 + j];
+			}
+			H[i * 3 + j] = s;
+		}
+	}
+}
+
+// inverse (upper triangle) and determinant of a symmetric 3x3 given as xx,xy,xz,yy,yz,zz — the
+// cofactor formulas of the general inverse with the symmetric entries substituted.
+__device__ __forceinline__ void inv_sym3(const double P[6], double inv[6], double& det)
+{
+	double xx = P[0], xy = P[1], xz = P[2], yy = P[3], yz = P[4], zz = P[5];
+	double c00 = yy * zz - yz * yz;
+	double c01 = xy * zz - yz * xz;
+	double c02 = xy * yz - yy * xz;
+	det = xx * c00 - xy * c01 + xz * c02;
+	double id = 1.0 / det;
+	inv[0] = c00 * id;
+	inv[1] = (xz * yz - xy * zz) * id;
+	inv[2] = (xy * yz - xz * yy) * id;
+	inv[3] = (xx * zz - xz * xz) * id;
+	inv[4] = (xz * xy - xx * yz) * id;
+	inv[5] = (xx * yy - xy * xy) * id;
+}
+
+// inverse and determinant of a general 3x3, row-major
+__device__ __forceinline__ void inv_gen3(const double a[9], double inv[9], double& det)
+{
+	double c00 = a[4] * a[8] - a[5] * a[7];
+	double c01 = a[3] * a[8] - a[5] * a[6];
+	double c02 = a[3] * a[7] - a[4] * a[6];
+	det = a[0] * c00 - a[1] * c01 + a[2] * c02;
+	double id = 1.0 / det;
+	inv[0] = c00 * id;
+	inv[1] = (a[2] * a[7] - a[1] * a[8]) * id;
+	inv[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+	inv[3] = (a[5] * a[6] - a[3] * a[8]) * id;
+	inv[4] = (a[0] * a[8] - a[2] * a[6]) * id;
+	inv[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+	inv[6] = c02 * id;
+	inv[7] = (a[1] * a[6] - a[0] * a[7]) * id;
+	inv[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+}
+
+// d^T A d for symmetric A (upper triangle), accumulated row by row like Gaussian.Evaluate
+__device__ __forceinline__ double quad_sym(const double A[6], double d0, double d1, double d2)
+{
+	double r0 = A[0] * d0 + A[1] * d1 + A[2] * d2;
+	double r1 = A[1] * d0 + A[3] * d1 + A[4] * d2;
+	double r2 = A[2] * d0 + A[4] * d1 + A[5] * d2;
+	return d0 * r0 + d1 * r1 + d2 * r2;
+}
+
+__device__ __forceinline__ double quad_gen(const double A[9], double d0, double d1, double d2)
+{
+	double r0 = A[0] * d0 + A[1] * d1 + A[2] * d2;
+	double r1 = A[3] * d0 + A[4] * d1 + A[5] * d2;
+	double r2 = A[6] * d0 + A[7] * d1 + A[8] * d2;
+	return d0 * r0 + d1 * r1 + d2 * r2;
+}
+
+// radius gate of Map.Near / Map.Evaluate(x, r) on the squared distance
+__device__ __forceinline__ bool gate_near(int metric, double sq, double radius)
+{
+	if (metric == 2) return true;
+	if (metric == 1) return sq <= radius;
+	return sqrt(sq) <= radius;
+}
+
+// per-component measurement-space quantities of CorrectConditional (PHDNavigator.cs:857-870)
+struct CompMeas {
+	double zh[3];     // h(m)
+	double H[9];
+	double PH[9];     // P H^T
+	double Sinv[9];   // (H P H^T + R)^-1, full (S is not bitwise symmetric)
+	double qmult;     // multiplier of N(.; zh, S)
+	double pd;        // detection probability of the component
+};
+
+__device__ __forceinline__ void comp_measure(const DevParams& prm, const PoseD& pose, const double rq[9],
+                                             const double m[3], const double P[6], CompMeas& o)
+{
+	double l[3];
+	measure_perfect(prm, pose, m, o.zh, l);
+	jacobian_l(prm, l, rq, o.H);
+	const double Pf[9] = {P[0], P[1], P[2], P[1], P[3], P[4], P[2], P[4], P[5]};
+#pragma unroll
+	for (int a = 0; a < 3; a++) {
+#pragma unroll
+		for (int b = 0; b < 3; b++) {
+			double s = 0;
+#pragma unroll
+			for (int k = 0; k < 3; k++) {
+				s += Pf[a * 3 + k] * o.H[b * 3 + k];
+			}
+			o.PH[a * 3 + b] = s;
+		}
+	}
+	double S[9];
+#pragma unroll
+	for (int a = 0; a < 3; a++) {
+#pragma unroll
+		for (int b = 0; b < 3; b++) {
+			double s = 0;
+#pragma unroll
+			for (int k = 0; k < 3; k++) {
+				s += o.H[a * 3 + k] * o.PH[k * 3 + b];
+			}
+			S[a * 3 + b] = s + prm.R[a * 3 + b];
+		}
+	}
+	double det;
+	inv_gen3(S, o.Sinv, det);
+	o.qmult = PHD_INV_2PI / sqrt(fabs(det));
+	o.pd    = detection_probability_m(prm, o.zh);
+}
+
+// Kalman update of one (component, measurement) pair (PHDNavigator.cs:895-897):
+// K = PH Sinv, m' = m + K nu, P' = (I - K H) P (upper triangle kept)
+__device__ __forceinline__ void kalman_gain(const CompMeas& cm, double K[9])
+{
+#pragma unroll
+	for (int a = 0; a < 3; a++) {
+#pragma unroll
+		for (int b = 0; b < 3; b++) {
+			double s = 0;
+#pragma unroll
+			for (int e = 0; e < 3; e++) {
+				s += cm.PH[a * 3 + e] * cm.Sinv[e * 3 + b];
+			}
+			K[a * 3 + b] = s;
+		}
+	}
+}
+
+__device__ __forceinline__ void kalman_cov(const CompMeas& cm, const double K[9], const double P[6], double Pn[6])
+{
+	const double Pf[9] = {P[0], P[1], P[2], P[1], P[3], P[4], P[2], P[4], P[5]};
+	double IKH[9];
+#pragma unroll
+	for (int a = 0; a < 3; a++) {
+#pragma unroll
+		for (int b = 0; b < 3; b++) {
+			double s = 0;
+#pragma unroll
+			for (int e = 0; e < 3; e++) {
+				s += K[a * 3 + e] * cm.H[e * 3 + b];
+			}
+			IKH[a * 3 + b] = ((a == b) ? 1.0 : 0.0) - s;
+		}
+	}
+	const int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};
+#pragma unroll
+	for (int t = 0; t < 6; t++) {
+		double s = 0;
+#pragma unroll
+		for (int e = 0; e < 3; e++) {
+			s += IKH[ia[t] * 3 + e] * Pf[e * 3 + ib[t]];
+		}
+		Pn[t] = s;
+	}
+}
+
+// wave-level helpers (wave = 64)
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ unsigned long long lanemask_lt()
+{
+	return (1ull << lane_id()) - 1ull;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		v += __shfl_xor(v, o, 64);
+	}
+	return v;
+}

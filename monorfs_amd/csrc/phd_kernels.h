@@ -1,0 +1,1116 @@
+// phd_kernels.h — hand-written HIP kernels (gfx950, wave64) of the RB-PHD-SLAM inner loop.
+//
+// One workgroup per particle everywhere (particles are independent through predict / correct /
+// prune / reweight: PHDNavigator.cs:326-339). Mixtures live in HBM as struct-of-arrays planes
+// (w, mean x/y/z, covariance xx/xy/xz/yy/yz/zz), each [particle][slot], so a wavefront reads 64
+// consecutive components of one particle as one 512-B line per plane.
+//
+//   k_predict_correct : PredictConditional + CorrectConditional (+ the MinWeight cut of PruneModel)
+//   k_prune_merge     : PruneModel (sort by weight, MaxQuantity cap, greedy merge)
+//   k_weight_alpha    : WeightAlpha = BestMapEstimate + mixture densities + SetLogLikelihood
+//   k_normalise_resample, k_gather_particles : particle weights, BestParticle, systematic resampling
+#pragma once
+#include "phd_device.h"
+
+// status bits written by the kernels into StepBufs::flags
+#define PHD_FLAG_EMIT_OVERFLOW   1   // corrected components did not fit emit_capacity
+#define PHD_FLAG_J_OVERFLOW      2   // map estimate larger than the landmark scratch
+#define PHD_FLAG_BIG_CLUSTER     4   // association cluster beyond the on-device solver's cap
+
+struct MixView {
+	double* w;
+	double* m[3];
+	double* P[6];
+	int*    count;
+};
+
+// one of the three state banks: mixture slabs (10 planes of [Pcap][cap]), counts, poses, weights
+struct Bank {
+	double* mix;
+	int*    count;
+	double* poses;    // [Pcap][7]
+	double* weights;  // [Pcap]
+};
+
+#define SEL_IN  0   // bank a step reads
+#define SEL_OUT 1   // bank a step writes
+#define SEL_TMP 2   // bank a resampling copy goes to
+
+struct StepBufs {
+	int P;          // particles in this launch
+	int cap;        // slots per particle in a mixture slab
+	int M;          // measurements
+	int Mcap;       // stride of per-measurement scratch
+	int ecap;       // emit scratch slots per particle
+	int Jcap;       // landmark scratch per particle
+	size_t plane;   // doubles per plane = Pcap * cap
+	Bank bank[3];
+	const int* sel; // [3] device-resident roles of the banks for this step (no host round trip to rotate them)
+	const double* z;         // [M][3]
+	// corrected-but-unpruned components (weight >= MinWeight), unsorted
+	double* emit_w;      // [P][ecap]
+	int*    emit_idx;    // [P][ecap] canonical position in the reference's `corrected` list
+	double* emit_rec;    // [P][ecap][9]  mean, covariance upper triangle
+	int*    emit_count;  // [P]
+	// births of the predict step
+	int*    born_count;  // [P]
+	int*    born_k;      // [P][Mcap]
+	double* born_mean;   // [P][Mcap][3]
+	// reweight outputs
+	double* alpha;       // [P]
+	double* setll;       // [P]
+	int*    flags;       // [1]
+};
+
+__device__ __forceinline__ MixView bank_view(const StepBufs& a, int role)
+{
+	const Bank& b = a.bank[a.sel[role]];
+	MixView v;
+	v.w = b.mix;
+#pragma unroll
+	for (int t = 0; t < 3; t++) v.m[t] = b.mix + (size_t) (1 + t) * a.plane;
+#pragma unroll
+	for (int t = 0; t < 6; t++) v.P[t] = b.mix + (size_t) (4 + t) * a.plane;
+	v.count = b.count;
+	return v;
+}
+
+#define TILE 256   // components staged per LDS tile
+
+// =================================================================================================
+// k_predict_correct
+//
+// LDS: the measurement block (raw + mapped into world space), per-wave partial sums, and one tile
+// of per-component quantities that the "measurement-in-lanes" loops read as broadcasts.
+// Mapping: per-component work (Jacobian, innovation covariance and its inverse, detection
+// probability) is done component-per-lane; every (component, measurement) pair is then visited
+// measurement-per-lane with the component broadcast from LDS, so the per-measurement sums
+// (explored density, PHD weight sum) are private to a lane and need no cross-lane reduction inside
+// the loop; the four waves split the components of a tile and are combined once, in wave order.
+// =================================================================================================
+template <int ZB>
+__global__ __launch_bounds__(256) void k_predict_correct(const DevParams prm, const StepBufs a)
+{
+	constexpr int MP = ZB * 64;
+	extern __shared__ __align__(16) double smem[];
+	double* zs    = smem;              // [MP][3]
+	double* zmap  = zs + 3 * MP;       // [MP][3]
+	double* part  = zmap + 3 * MP;     // [4][MP]
+	double* denom = part + 4 * MP;     // [MP]
+	double* tile  = denom + MP;        // [18][TILE]
+	int*    born  = (int*) (tile + 18 * TILE);   // [MP] flags, then compacted list
+	int*    cnt   = born + MP;         // [0] births, [1] emitted
+
+	const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int M = a.M, cap = a.cap;
+	const MixView vin = bank_view(a, SEL_IN);
+	const Bank& bin  = a.bank[a.sel[SEL_IN]];
+	const Bank& bout = a.bank[a.sel[SEL_OUT]];
+	const int n = vin.count[p];
+	const size_t sb = (size_t) p * cap;
+	const PoseD pose = load_pose(bin.poses + (size_t) p * 7);
+	double rq[9];
+	conj_matrix(pose, rq);
+	// the particle keeps its pose and (until the reweight kernel runs) its weight in the output bank
+	if (tid < 7) bout.poses[(size_t) p * 7 + tid] = bin.poses[(size_t) p * 7 + tid];
+	if (tid == 7) bout.weights[p] = bin.weights[p];
+
+	for (int k = tid; k < MP; k += 256) {
+		double z[3] = {0, 0, 1}, x[3] = {0, 0, 0};
+		if (k < M) {
+			z[0] = a.z[k * 3]; z[1] = a.z[k * 3 + 1]; z[2] = a.z[k * 3 + 2];
+			measure_to_map(prm, pose, z, x);
+		}
+		zs[k * 3] = z[0]; zs[k * 3 + 1] = z[1]; zs[k * 3 + 2] = z[2];
+		zmap[k * 3] = x[0]; zmap[k * 3 + 1] = x[1]; zmap[k * 3 + 2] = x[2];
+	}
+	if (tid < 2) cnt[tid] = 0;
+	__syncthreads();
+
+	// the measurements this lane owns
+	double zx[ZB], zy[ZB], zr[ZB], wx[ZB], wy[ZB], wz[ZB];
+	bool   zv[ZB];
+#pragma unroll
+	for (int b = 0; b < ZB; b++) {
+		int k = b * 64 + lane;
+		zv[b] = k < M;
+		zx[b] = zs[k * 3]; zy[b] = zs[k * 3 + 1]; zr[b] = zs[k * 3 + 2];
+		wx[b] = zmap[k * 3]; wy[b] = zmap[k * 3 + 1]; wz[b] = zmap[k * 3 + 2];
+	}
+
+	// ---- PredictConditional: Explored(model, MeasureToMap(z)) on the PRIOR map (PHDNavigator.cs:806-811)
+	{
+		double acc[ZB];
+#pragma unroll
+		for (int b = 0; b < ZB; b++) acc[b] = 0;
+		for (int c0 = 0; c0 < n; c0 += TILE) {
+			int c = c0 + tid;
+			if (c < n) {
+				double P[6], Pi[6], det;
+#pragma unroll
+				for (int t = 0; t < 6; t++) P[t] = vin.P[t][sb + c];
+				inv_sym3(P, Pi, det);
+				tile[0 * TILE + tid] = vin.m[0][sb + c];
+				tile[1 * TILE + tid] = vin.m[1][sb + c];
+				tile[2 * TILE + tid] = vin.m[2][sb + c];
+#pragma unroll
+				for (int t = 0; t < 6; t++) tile[(3 + t) * TILE + tid] = Pi[t];
+				tile[9 * TILE + tid]  = vin.w[sb + c];
+				tile[10 * TILE + tid] = PHD_INV_2PI / sqrt(fabs(det));
+			}
+			__syncthreads();
+			int cend = min(TILE, n - c0);
+			for (int cc = wv; cc < cend; cc += 4) {
+				double m0 = tile[cc], m1 = tile[TILE + cc], m2 = tile[2 * TILE + cc];
+				double Pi[6];
+#pragma unroll
+				for (int t = 0; t < 6; t++) Pi[t] = tile[(3 + t) * TILE + cc];
+				double w = tile[9 * TILE + cc], mult = tile[10 * TILE + cc];
+#pragma unroll
+				for (int b = 0; b < ZB; b++) {
+					double d0 = wx[b] - m0, d1 = wy[b] - m1, d2 = wz[b] - m2;
+					double sq = d0 * d0 + d1 * d1 + d2 * d2;
+					if (zv[b] && gate_near(prm.gate_metric, sq, prm.r_explore)) {
+						acc[b] += w * (mult * exp(-0.5 * quad_sym(Pi, d0, d1, d2)));   // Map.cs:216
+					}
+				}
+			}
+			__syncthreads();
+		}
+#pragma unroll
+		for (int b = 0; b < ZB; b++) part[wv * MP + b * 64 + lane] = acc[b];
+		__syncthreads();
+		for (int k = tid; k < MP; k += 256) {
+			double dens = part[k] + part[MP + k] + part[2 * MP + k] + part[3 * MP + k];
+			born[k] = (k < M) && !(dens >= prm.expl_thr);
+		}
+		__syncthreads();
+		if (tid == 0) {   // births keep measurement order (PHDNavigator.cs:814-816)
+			int nb = 0;
+			for (int k = 0; k < M; k++) {
+				if (born[k]) {
+					born[nb] = k;   // nb <= k: in-place compaction
+					a.born_k[(size_t) p * a.Mcap + nb] = k;
+					a.born_mean[((size_t) p * a.Mcap + nb) * 3]     = zmap[k * 3];
+					a.born_mean[((size_t) p * a.Mcap + nb) * 3 + 1] = zmap[k * 3 + 1];
+					a.born_mean[((size_t) p * a.Mcap + nb) * 3 + 2] = zmap[k * 3 + 2];
+					nb++;
+				}
+			}
+			cnt[0] = nb;
+			a.born_count[p] = nb;
+		}
+		__syncthreads();
+	}
+	const int np = n + cnt[0];   // predicted = prior + births
+
+	// component c of the predicted mixture
+	auto load_comp = [&](int c, double& w, double m[3], double P[6]) {
+		if (c < n) {
+			w = vin.w[sb + c];
+#pragma unroll
+			for (int t = 0; t < 3; t++) m[t] = vin.m[t][sb + c];
+#pragma unroll
+			for (int t = 0; t < 6; t++) P[t] = vin.P[t][sb + c];
+		}
+		else {
+			int k = born[c - n];
+			w = prm.birthw;
+			m[0] = zmap[k * 3]; m[1] = zmap[k * 3 + 1]; m[2] = zmap[k * 3 + 2];
+#pragma unroll
+			for (int t = 0; t < 6; t++) P[t] = prm.birthP[t];
+		}
+	};
+
+	auto emit = [&](bool flag, double w, int idx, const double m[3], const double P[6]) {
+		unsigned long long bal = __ballot(flag);
+		if (bal == 0) return;
+		int base = 0;
+		int first = __ffsll((long long) bal) - 1;
+		if (lane == first) base = atomicAdd(&cnt[1], __popcll(bal));
+		base = __shfl(base, first, 64);
+		if (flag) {
+			int slot = base + __popcll(bal & lanemask_lt());
+			if (slot < a.ecap) {
+				size_t e = (size_t) p * a.ecap + slot;
+				a.emit_w[e]   = w;
+				a.emit_idx[e] = idx;
+				double* r = a.emit_rec + e * 9;
+				r[0] = m[0]; r[1] = m[1]; r[2] = m[2];
+#pragma unroll
+				for (int t = 0; t < 6; t++) r[3 + t] = P[t];
+			}
+		}
+	};
+
+	// ---- CorrectConditional, two sweeps over the predicted mixture
+	//   sweep 0: misdetection copies (:837-840) and weightsum[z] = sum over near components of PD w q(z) (:886-890)
+	//   sweep 1: emission of w' = PD w q / (kappa + weightsum) with m', P' (:892-902), for w' >= MinWeight
+	double wsum[ZB];
+#pragma unroll
+	for (int b = 0; b < ZB; b++) wsum[b] = 0;
+
+	for (int sweep = 0; sweep < 2; sweep++) {
+		for (int c0 = 0; c0 < np; c0 += TILE) {
+			int  c = c0 + tid;
+			bool valid = c < np;
+			bool mis = false;
+			double w = 0, m[3] = {0, 0, 0}, P[6] = {1, 0, 0, 1, 0, 1}, wm = 0;
+			if (valid) {
+				load_comp(c, w, m, P);
+				CompMeas cm;
+				comp_measure(prm, pose, rq, m, P, cm);
+#pragma unroll
+				for (int t = 0; t < 3; t++) tile[t * TILE + tid] = cm.zh[t];
+#pragma unroll
+				for (int t = 0; t < 9; t++) tile[(3 + t) * TILE + tid] = cm.Sinv[t];
+				double pdw = cm.pd * w;
+				tile[12 * TILE + tid] = cm.qmult;
+				tile[13 * TILE + tid] = pdw;
+#pragma unroll
+				for (int t = 0; t < 3; t++) tile[(14 + t) * TILE + tid] = m[t];
+				// no pair can reach MinWeight unless  PD w mult exp(-d2/2) >= MinWeight * kappa
+				double dc = 2.0 * (log(pdw * cm.qmult) - prm.emit_log_floor) + 1.0;
+				tile[17 * TILE + tid] = isinf(prm.emit_log_floor) ? INFINITY : dc;
+				wm  = (1 - cm.pd) * w;
+				mis = !(wm < prm.minw);
+			}
+			if (sweep == 0) emit(mis, wm, c, m, P);
+			__syncthreads();
+			int cend = min(TILE, np - c0);
+			for (int cc = wv; cc < cend; cc += 4) {
+				double zh0 = tile[cc], zh1 = tile[TILE + cc], zh2 = tile[2 * TILE + cc];
+				double Si[9];
+#pragma unroll
+				for (int t = 0; t < 9; t++) Si[t] = tile[(3 + t) * TILE + cc];
+				double qmult = tile[12 * TILE + cc], pdw = tile[13 * TILE + cc];
+				double m0 = tile[14 * TILE + cc], m1 = tile[15 * TILE + cc], m2 = tile[16 * TILE + cc];
+				double dc = tile[17 * TILE + cc];
+				if (sweep == 0) {
+#pragma unroll
+					for (int b = 0; b < ZB; b++) {
+						double e0 = wx[b] - m0, e1 = wy[b] - m1, e2 = wz[b] - m2;
+						double sq = e0 * e0 + e1 * e1 + e2 * e2;
+						double d2 = quad_gen(Si, zx[b] - zh0, zy[b] - zh1, zr[b] - zh2);
+						double q  = qmult * exp(-0.5 * d2);
+						if (zv[b] && gate_near(prm.gate_metric, sq, prm.r_correct)) {
+							wsum[b] += pdw * q;
+						}
+					}
+				}
+				else {
+#pragma unroll
+					for (int b = 0; b < ZB; b++) {
+						double e0 = wx[b] - m0, e1 = wy[b] - m1, e2 = wz[b] - m2;
+						double sq = e0 * e0 + e1 * e1 + e2 * e2;
+						double n0 = zx[b] - zh0, n1 = zy[b] - zh1, n2 = zr[b] - zh2;
+						double d2 = quad_gen(Si, n0, n1, n2);
+						bool cand = zv[b] && gate_near(prm.gate_metric, sq, prm.r_correct) && (d2 <= dc);
+						if (__ballot(cand)) {
+							double q   = qmult * exp(-0.5 * d2);
+							double wgt = pdw * q / denom[b * 64 + lane];   // PHDNavigator.cs:899
+							bool   em  = cand && !(wgt < prm.minw);
+							if (__ballot(em)) {
+								// the component is wave-uniform: every lane rebuilds its gain and posterior covariance
+								int cg = c0 + cc;
+								double cw, cmn[3], cP[6];
+								load_comp(cg, cw, cmn, cP);
+								CompMeas cm;
+								comp_measure(prm, pose, rq, cmn, cP, cm);
+								double K[9], Pn[6], mn[3];
+								kalman_gain(cm, K);
+								kalman_cov(cm, K, cP, Pn);
+#pragma unroll
+								for (int t = 0; t < 3; t++) {
+									mn[t] = cmn[t] + (K[t * 3] * n0 + K[t * 3 + 1] * n1 + K[t * 3 + 2] * n2);
+								}
+								int k = b * 64 + lane;
+								emit(em, wgt, np + k * np + cg, mn, Pn);
+							}
+						}
+					}
+				}
+			}
+			__syncthreads();
+		}
+		if (sweep == 0) {
+#pragma unroll
+			for (int b = 0; b < ZB; b++) part[wv * MP + b * 64 + lane] = wsum[b];
+			__syncthreads();
+			for (int k = tid; k < MP; k += 256) {
+				denom[k] = prm.kappa + (part[k] + part[MP + k] + part[2 * MP + k] + part[3 * MP + k]);
+			}
+			__syncthreads();
+		}
+	}
+	if (tid == 0) {
+		int ne = cnt[1];
+		if (ne > a.ecap) {
+			atomicOr(a.flags, PHD_FLAG_EMIT_OVERFLOW);
+			ne = a.ecap;
+		}
+		a.emit_count[p] = ne;
+	}
+}
+
+// =================================================================================================
+// k_prune_merge — PruneModel (PHDNavigator.cs:913-948)
+//
+// One wave per particle: the greedy merge is sequential in weight order (candidate i absorbs every
+// later close component), so the loop over candidates runs wave-synchronously with the later
+// components spread over the lanes; no workgroup barrier sits inside it.
+//   1. rank every emitted component by (weight desc, canonical index asc)  == stable descending sort
+//   2. keep ranks < min(MaxQuantity, count) (all weights are already >= MinWeight) -> LDS, sorted
+//   3. for each still-unassigned i in order: close(k) = (m_i - m_k)^T P_i^-1 (m_i - m_k) < T^2 for k > i
+//      (Gaussian.AreClose uses the candidate's covariance only, Gaussian.cs:243-246); moment-match the
+//      set (Gaussian.Merge, Gaussian.cs:329-346) and write it over slot `nout` (nout <= i).
+// =================================================================================================
+__global__ __launch_bounds__(64) void k_prune_merge(const DevParams prm, const StepBufs a, int cutcap)
+{
+	extern __shared__ __align__(16) double smem[];
+	double* keyw = smem;                     // [ecap]
+	double* sw   = keyw + a.ecap;            // [cutcap] sorted weight
+	double* sm   = sw + cutcap;              // [3][cutcap]
+	double* sP   = sm + 3 * cutcap;          // [6][cutcap]
+	int*    keyi = (int*) (sP + 6 * cutcap); // [ecap]
+
+	const int p = blockIdx.x, lane = threadIdx.x;
+	const MixView vout = bank_view(a, SEL_OUT);
+	const int ne = a.emit_count[p];
+	const size_t eb = (size_t) p * a.ecap;
+	for (int e = lane; e < ne; e += 64) {
+		keyw[e] = a.emit_w[eb + e];
+		keyi[e] = a.emit_idx[eb + e];
+	}
+	__syncthreads();
+	const int cut = min(min(prm.maxq, ne), cutcap);
+
+	// 1+2: counting rank, four elements per lane per sweep so each broadcast key is used four times
+	for (int e0 = 0; e0 < ne; e0 += 256) {
+		double we[4];
+		int    ie[4], rank[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			int e = e0 + u * 64 + lane;
+			we[u] = (e < ne) ? keyw[e] : 0.0;
+			ie[u] = (e < ne) ? keyi[e] : 0x7fffffff;
+			rank[u] = 0;
+		}
+		for (int j = 0; j < ne; j++) {
+			double wj = keyw[j];
+			int    ij = keyi[j];
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				rank[u] += (wj > we[u]) || (wj == we[u] && ij < ie[u]);
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < 4; u++) {
+			int e = e0 + u * 64 + lane;
+			if (e < ne && rank[u] < cut) {
+				int r = rank[u];
+				const double* rec = a.emit_rec + (eb + e) * 9;
+				sw[r] = we[u];
+#pragma unroll
+				for (int t = 0; t < 3; t++) sm[t * cutcap + r] = rec[t];
+#pragma unroll
+				for (int t = 0; t < 6; t++) sP[t * cutcap + r] = rec[3 + t];
+			}
+		}
+	}
+	__syncthreads();
+
+	// 3: greedy merge. assigned: bit s of a lane <-> element s*64 + lane
+	unsigned int assigned = 0;
+	const int nslots = (cut + 63) >> 6;
+	int nout = 0;
+	for (int i = 0; i < cut; i++) {
+		unsigned int om = __builtin_amdgcn_readlane(assigned, i & 63);
+		if ((om >> (i >> 6)) & 1u) continue;
+		double lw = sw[i];
+		double lm[3] = {sm[i], sm[cutcap + i], sm[2 * cutcap + i]};
+		double lP[6], Pi[6], det;
+#pragma unroll
+		for (int t = 0; t < 6; t++) lP[t] = sP[t * cutcap + i];
+		inv_sym3(lP, Pi, det);
+
+		double aw = 0, am[3] = {0, 0, 0}, aP[6] = {0, 0, 0, 0, 0, 0};
+		bool any = false;
+		for (int s = i >> 6; s < nslots; s++) {
+			int k = s * 64 + lane;
+			bool ok = (k > i) && (k < cut) && !((assigned >> s) & 1u);
+			if (ok) {
+				double k0 = sm[k], k1 = sm[cutcap + k], k2 = sm[2 * cutcap + k];
+				double d2 = quad_sym(Pi, lm[0] - k0, lm[1] - k1, lm[2] - k2);   // Gaussian.SquareMahalanobis
+				if (d2 < prm.merge_thr2) {
+					assigned |= 1u << s;
+					any = true;
+					double w = sw[k];
+					aw += w;
+					am[0] += w * k0; am[1] += w * k1; am[2] += w * k2;
+					aP[0] += w * (sP[0 * cutcap + k] + k0 * k0);
+					aP[1] += w * (sP[1 * cutcap + k] + k0 * k1);
+					aP[2] += w * (sP[2 * cutcap + k] + k0 * k2);
+					aP[3] += w * (sP[3 * cutcap + k] + k1 * k1);
+					aP[4] += w * (sP[4 * cutcap + k] + k1 * k2);
+					aP[5] += w * (sP[5 * cutcap + k] + k2 * k2);
+				}
+			}
+		}
+		if (__ballot(any)) {
+			aw = wave_sum(aw);
+#pragma unroll
+			for (int t = 0; t < 3; t++) am[t] = wave_sum(am[t]);
+#pragma unroll
+			for (int t = 0; t < 6; t++) aP[t] = wave_sum(aP[t]);
+		}
+		// Gaussian.Merge: raw moments, leader first (Gaussian.cs:329-346)
+		double W = (0.0 + lw) + aw;
+		double Mv[3] = {(0.0 + lw * lm[0]) + am[0], (0.0 + lw * lm[1]) + am[1], (0.0 + lw * lm[2]) + am[2]};
+		double C[6] = {(0.0 + lw * (lP[0] + lm[0] * lm[0])) + aP[0], (0.0 + lw * (lP[1] + lm[0] * lm[1])) + aP[1],
+		               (0.0 + lw * (lP[2] + lm[0] * lm[2])) + aP[2], (0.0 + lw * (lP[3] + lm[1] * lm[1])) + aP[3],
+		               (0.0 + lw * (lP[4] + lm[1] * lm[2])) + aP[4], (0.0 + lw * (lP[5] + lm[2] * lm[2])) + aP[5]};
+		double ow, omn[3], oP[6];
+		if (W < 1e-15) {   // Gaussian.cs:339-341
+			ow = 0.0;
+			omn[0] = lm[0]; omn[1] = lm[1]; omn[2] = lm[2];
+			oP[0] = 1e12; oP[1] = 0; oP[2] = 0; oP[3] = 1e12; oP[4] = 0; oP[5] = 1e12;
+		}
+		else {
+			ow = W;
+			omn[0] = Mv[0] / W; omn[1] = Mv[1] / W; omn[2] = Mv[2] / W;
+			oP[0] = C[0] / W - omn[0] * omn[0];
+			oP[1] = C[1] / W - omn[0] * omn[1];
+			oP[2] = C[2] / W - omn[0] * omn[2];
+			oP[3] = C[3] / W - omn[1] * omn[1];
+			oP[4] = C[4] / W - omn[1] * omn[2];
+			oP[5] = C[5] / W - omn[2] * omn[2];
+		}
+		if (lane == 0) {   // nout <= i: the slot is never read again inside the loop
+			sw[nout] = ow;
+#pragma unroll
+			for (int t = 0; t < 3; t++) sm[t * cutcap + nout] = omn[t];
+#pragma unroll
+			for (int t = 0; t < 6; t++) sP[t * cutcap + nout] = oP[t];
+		}
+		nout++;
+	}
+	__syncthreads();
+	const size_t ob = (size_t) p * a.cap;
+	for (int o = lane; o < nout; o += 64) {
+		vout.w[ob + o] = sw[o];
+#pragma unroll
+		for (int t = 0; t < 3; t++) vout.m[t][ob + o] = sm[t * cutcap + o];
+#pragma unroll
+		for (int t = 0; t < 6; t++) vout.P[t][ob + o] = sP[t * cutcap + o];
+	}
+	if (lane == 0) vout.count[p] = nout;
+}
+
+// =================================================================================================
+// k_weight_alpha — WeightAlpha (PHDNavigator.cs:373-393)
+// =================================================================================================
+
+// next permutation of LexicographicalPairing (GraphCombinatorics.cs:306-332) on n <= 5 entries
+__device__ __forceinline__ bool lex_last(const int* perm, int n)
+{
+	for (int i = 1; i < n; i++) {
+		if (perm[i - 1] < perm[i]) return false;
+	}
+	return true;
+}
+
+__device__ __forceinline__ void lex_reverse(int* perm, int from, int to)   // [from, to)
+{
+	for (int i = from, j = to - 1; i < j; i++, j--) {
+		int t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+	}
+}
+
+__device__ __forceinline__ void lex_next(int* perm, int n, int measurestart)
+{
+	int x, y;
+	for (x = n - 2; x > 0; x--) {
+		if (perm[x] < perm[x + 1]) break;
+	}
+	for (y = n - 1; y > x; y--) {
+		if (perm[x] < perm[y]) break;
+	}
+	int t = perm[x]; perm[x] = perm[y]; perm[y] = t;
+	lex_reverse(perm, x + 1, n);
+	lex_reverse(perm, measurestart, n);
+}
+
+// log-sum-exp over every pairing of a cluster with n <= 5 rows, enumerated exactly like
+// LexicographicalPairing(component, map.Count) (`modelsize` is compared with COMPACTED row indices,
+// PHDNavigator.cs:493 / GraphCombinatorics.cs:293-299). mat: n x n, row stride 5, stride `ms` between entries.
+__device__ double cluster_enumerate(const double* mat, int ms, int n, int modelsize)
+{
+	int perm[5], first[5];
+	int measurestart = n;
+	for (int i = 0; i < n; i++) {
+		if (i >= modelsize) { measurestart = i; break; }
+	}
+	for (int i = 0; i < n; i++) first[i] = i;
+	lex_reverse(first, measurestart, n);
+
+	double mx = -INFINITY, value = 0;
+	for (int pass = 0; pass < 2; pass++) {
+		for (int i = 0; i < n; i++) perm[i] = first[i];
+		for (;;) {
+			double v = 0;
+			for (int i = 0; i < n; i++) v += mat[(i * 5 + perm[i]) * ms];   // AssignmentValue
+			if (pass == 0) mx = fmax(mx, v);
+			else value += exp(v - mx);
+			if (lex_last(perm, n)) break;
+			lex_next(perm, n, measurestart);
+		}
+		if (pass == 0 && isinf(mx) && mx < 0) return -INFINITY;   // LogSumExp, MatrixExtensions.cs:379-381
+	}
+	return mx + log(value);
+}
+
+// LDS layout of k_weight_alpha, shared with the host so the launch sizes it identically.
+struct AlphaLds {
+	int zs, lm, red, pick, scr;   // offsets in doubles
+	int bytes;
+};
+
+__host__ __device__ inline AlphaLds alpha_lds(int MP, int JP, int ncap)
+{
+	AlphaLds l;
+	l.zs   = 0;
+	l.lm   = l.zs + 3 * MP;
+	l.red  = l.lm + 3 * JP;
+	l.pick = l.red + 256;
+	l.scr  = l.pick + (JP + 1) / 2;
+	int MW = MP / 64;
+	int ph1 = 2 * ncap + JP + (ncap + JP + 1) / 2;                       // keyw, sortw, dw | sortsrc, dsrc
+	int ph2 = 11 * TILE + 256;                                           // tile | part
+	int ph3 = 5 * JP + JP * MW + 25 * 64 + (2 * JP + MP + 1) / 2;        // zh, pdj, res | adj | mats | labl, roots, labz
+	int mx = ph1 > ph2 ? ph1 : ph2;
+	mx = mx > ph3 ? mx : ph3;
+	l.bytes = (l.scr + mx) * 8;
+	return l;
+}
+
+template <int ZB>
+__global__ __launch_bounds__(256) void k_weight_alpha(const DevParams prm, const StepBufs a, int ncap)
+{
+	constexpr int MP = ZB * 64;
+	constexpr int MW = ZB;   // 64-bit adjacency words per landmark
+	const int JP = a.Jcap;   // multiple of 64
+	extern __shared__ __align__(16) double smem[];
+	const AlphaLds lay = alpha_lds(MP, JP, ncap);
+	double* zs   = smem + lay.zs;          // [MP][3] measurements
+	double* lm   = smem + lay.lm;          // [3][JP] landmark means of the map estimate
+	double* red  = smem + lay.red;         // [256] reduction scratch
+	int*    pick = (int*) (smem + lay.pick);   // [JP] component picked for landmark j
+	double* scr  = smem + lay.scr;         // per-phase scratch
+	__shared__ int s_J, s_changed, s_nroots, s_big;
+	__shared__ double s_ccount, s_total;
+
+	const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int M = a.M, cap = a.cap;
+	const MixView vin = bank_view(a, SEL_IN), vout = bank_view(a, SEL_OUT);
+	const Bank& bin  = a.bank[a.sel[SEL_IN]];
+	const Bank& bout = a.bank[a.sel[SEL_OUT]];
+	const int n = vin.count[p], nb = a.born_count[p], no = vout.count[p];
+	const int np = n + nb;
+	const size_t sbi = (size_t) p * cap, sbo = (size_t) p * cap;
+	const PoseD pose = load_pose(bin.poses + (size_t) p * 7);
+
+	for (int k = tid; k < MP * 3; k += 256) zs[k] = (k < M * 3) ? a.z[k] : 0.0;
+
+	// ---- phase 1: BestMapEstimate (Map.cs:119-142)
+	{
+		double* keyw    = scr;               // [ncap] weights in map order
+		double* sortw   = keyw + ncap;       // [ncap] weights, stable descending
+		double* dw      = sortw + ncap;      // [JP]   derived (w - 1) entries, FIFO
+		int*    sortsrc = (int*) (dw + JP);  // [ncap]
+		int*    dsrc    = sortsrc + ncap;    // [JP]
+		for (int c = tid; c < no; c += 256) keyw[c] = vout.w[sbo + c];
+		__syncthreads();
+		if (tid == 0) {   // ExpectedSize, summed in map order (Map.cs:61-71); size = (int) ExpectedSize (:126)
+			double e = 0;
+			for (int c = 0; c < no; c++) e += keyw[c];
+			s_ccount = e;
+			int J = (int) e;
+			if (J < 0) J = 0;
+			if (J > JP) {
+				atomicOr(a.flags, PHD_FLAG_J_OVERFLOW);
+				J = JP;
+			}
+			s_J = J;
+		}
+		// stable descending order by counting rank (mlist.Sort, :129)
+		for (int c = tid; c < no; c += 256) {
+			double wc = keyw[c];
+			int rank = 0;
+			for (int j = 0; j < no; j++) {
+				double wj = keyw[j];
+				rank += (wj > wc) || (wj == wc && j < c);
+			}
+			sortw[rank]   = wc;
+			sortsrc[rank] = c;
+		}
+		__syncthreads();
+		if (tid == 0) {
+			// "take the i-th entry, append a copy with w - 1, sort again" (:131-138) is a two-way merge:
+			// every appended weight is <= the one it came from, so the appended entries are produced in
+			// non-increasing order and form a FIFO merged with the original sorted list; on a tie the
+			// original entry stays first (stable sort of an appended element).
+			const int J = s_J;
+			int ia = 0, id = 0, nd = 0;
+			for (int j = 0; j < J; j++) {
+				bool takeorig;
+				if (ia < no && id < nd) takeorig = !(dw[id] > sortw[ia]);
+				else takeorig = ia < no;
+				double wpick;
+				int    src;
+				if (takeorig) { wpick = sortw[ia]; src = sortsrc[ia]; ia++; }
+				else          { wpick = dw[id];    src = dsrc[id];    id++; }
+				dw[nd]   = wpick - 1;
+				dsrc[nd] = src;
+				nd++;
+				pick[j] = src;
+			}
+		}
+		__syncthreads();
+	}
+	const int J = s_J;
+	for (int j = tid; j < J; j += 256) {
+		int c = pick[j];
+		lm[j] = vout.m[0][sbo + c]; lm[JP + j] = vout.m[1][sbo + c]; lm[2 * JP + j] = vout.m[2][sbo + c];
+	}
+	__syncthreads();
+
+	// ---- phase 2: sum_j log v_pred(m_j), sum_j log v_corr(m_j) with v = full ungated mixture density (Map.cs:192-202)
+	double plog_part = 0, clog_part = 0, pcount_part = 0;
+	{
+		double* tile = scr;                 // [11][TILE]
+		double* part = tile + 11 * TILE;    // [4][64]
+		for (int c = tid; c < n; c += 256) pcount_part += vin.w[sbi + c];
+		for (int jb = 0; jb * 64 < J; jb++) {
+			int  j  = jb * 64 + lane;
+			bool jv = j < J;
+			double x0 = jv ? lm[j] : 0, x1 = jv ? lm[JP + j] : 0, x2 = jv ? lm[2 * JP + j] : 0;
+			for (int src = 0; src < 2; src++) {
+				const int total = (src == 0) ? np : no;
+				double acc = 0;
+				for (int c0 = 0; c0 < total; c0 += TILE) {
+					int c = c0 + tid;
+					if (c < total) {
+						double w, m[3], P[6], Pi[6], det;
+						if (src == 1) {
+							w = vout.w[sbo + c];
+#pragma unroll
+							for (int t = 0; t < 3; t++) m[t] = vout.m[t][sbo + c];
+#pragma unroll
+							for (int t = 0; t < 6; t++) P[t] = vout.P[t][sbo + c];
+						}
+						else if (c < n) {
+							w = vin.w[sbi + c];
+#pragma unroll
+							for (int t = 0; t < 3; t++) m[t] = vin.m[t][sbi + c];
+#pragma unroll
+							for (int t = 0; t < 6; t++) P[t] = vin.P[t][sbi + c];
+						}
+						else {
+							const double* bm = a.born_mean + ((size_t) p * a.Mcap + (c - n)) * 3;
+							w = prm.birthw;
+							m[0] = bm[0]; m[1] = bm[1]; m[2] = bm[2];
+#pragma unroll
+							for (int t = 0; t < 6; t++) P[t] = prm.birthP[t];
+						}
+						inv_sym3(P, Pi, det);
+#pragma unroll
+						for (int t = 0; t < 3; t++) tile[t * TILE + tid] = m[t];
+#pragma unroll
+						for (int t = 0; t < 6; t++) tile[(3 + t) * TILE + tid] = Pi[t];
+						tile[9 * TILE + tid]  = w;
+						tile[10 * TILE + tid] = PHD_INV_2PI / sqrt(fabs(det));
+					}
+					__syncthreads();
+					int cend = min(TILE, total - c0);
+					for (int cc = wv; cc < cend; cc += 4) {
+						double d0 = x0 - tile[cc], d1 = x1 - tile[TILE + cc], d2 = x2 - tile[2 * TILE + cc];
+						double Pi[6];
+#pragma unroll
+						for (int t = 0; t < 6; t++) Pi[t] = tile[(3 + t) * TILE + cc];
+						acc += tile[9 * TILE + cc] * (tile[10 * TILE + cc] * exp(-0.5 * quad_sym(Pi, d0, d1, d2)));
+					}
+					__syncthreads();
+				}
+				part[wv * 64 + lane] = acc;
+				__syncthreads();
+				if (wv == 0 && jv) {
+					double v = part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane];
+					if (src == 0) plog_part += log(v);
+					else          clog_part += log(v);
+				}
+				__syncthreads();
+			}
+		}
+	}
+	// block reductions (fixed order)
+	auto block_sum = [&](double v) {
+		red[tid] = v;
+		__syncthreads();
+		for (int s = 128; s > 0; s >>= 1) {
+			if (tid < s) red[tid] += red[tid + s];
+			__syncthreads();
+		}
+		double r = red[0];
+		__syncthreads();
+		return r;
+	};
+	const double plog = block_sum(plog_part);
+	const double clog = block_sum(clog_part);
+	const double pcount = block_sum(pcount_part) + nb * prm.birthw;
+	const double ccount = s_ccount;
+
+	// ---- phase 3: SetLogLikelihood (PHDNavigator.cs:462-515) on the matrix of SetLogLikeMatrix (:415-453)
+	{
+		double* zh   = scr;                 // [3][JP] h(m_j)
+		double* pdj  = zh + 3 * JP;         // [JP] detection probability of landmark j
+		double* res  = pdj + JP;            // [JP] per-cluster log-sum-exp, in cluster order
+		unsigned long long* adj = (unsigned long long*) (res + JP);   // [JP][MW] gated measurements of landmark j
+		double* mats = (double*) (adj + (size_t) JP * MW);             // [25][64] one 5x5 matrix per lane
+		int*    labl = (int*) (mats + 25 * 64);   // [JP]
+		int*    roots = labl + JP;                // [JP]
+		int*    labz = roots + JP;                // [MP]
+
+		for (int j = tid; j < J; j += 256) {
+			double m[3] = {lm[j], lm[JP + j], lm[2 * JP + j]}, z[3], l[3];
+			measure_perfect(prm, pose, m, z, l);
+			zh[j] = z[0]; zh[JP + j] = z[1]; zh[2 * JP + j] = z[2];
+			pdj[j] = detection_probability_m(prm, z);
+			unsigned long long bits[MW];
+#pragma unroll
+			for (int b = 0; b < MW; b++) bits[b] = 0;
+			for (int k = 0; k < M; k++) {
+				double dist = sqrt(quad_gen(prm.Rinv, z[0] - zs[k * 3], z[1] - zs[k * 3 + 1], z[2] - zs[k * 3 + 2]));
+				if (dist < 5) bits[k >> 6] |= 1ull << (k & 63);   // :436
+			}
+#pragma unroll
+			for (int b = 0; b < MW; b++) adj[(size_t) j * MW + b] = bits[b];
+			labl[j] = j;
+		}
+		for (int k = tid; k < M; k += 256) labz[k] = J + k;
+		if (tid == 0) { s_nroots = 0; s_big = 0; }
+		__syncthreads();
+
+		// connected components of the bipartite (landmark, measurement) graph by min-label propagation;
+		// a cluster's label ends as its smallest landmark index, which is also its position in the
+		// reference's component list (rows with detection entries are inserted first, ascending).
+		for (int it = 0; it < J + M + 1; it++) {
+			if (tid == 0) s_changed = 0;
+			__syncthreads();
+			for (int j = tid; j < J; j += 256) {
+				int l = labl[j];
+#pragma unroll
+				for (int b = 0; b < MW; b++) {
+					unsigned long long bits = adj[(size_t) j * MW + b];
+					while (bits) {
+						int k = b * 64 + __ffsll((long long) bits) - 1;
+						bits &= bits - 1;
+						l = min(l, labz[k]);
+					}
+				}
+				if (l < labl[j]) { labl[j] = l; s_changed = 1; }
+			}
+			__syncthreads();
+			for (int k = tid; k < M; k += 256) {
+				int l = labz[k];
+				for (int j = 0; j < J; j++) {
+					if ((adj[(size_t) j * MW + (k >> 6)] >> (k & 63)) & 1ull) l = min(l, labl[j]);
+				}
+				if (l < labz[k]) { labz[k] = l; s_changed = 1; }
+			}
+			__syncthreads();
+			if (!s_changed) break;
+			__syncthreads();
+		}
+		if (tid == 0) {
+			int nr = 0;
+			for (int j = 0; j < J; j++) {
+				bool has = false;
+				for (int b = 0; b < MW; b++) has |= adj[(size_t) j * MW + b] != 0;
+				if (labl[j] == j && has) roots[nr++] = j;
+			}
+			s_nroots = nr;
+		}
+		__syncthreads();
+		const int nroots = s_nroots;
+		const double logmult = prm.logRmult;
+
+		// clusters with n <= 5 rows: every pairing (PHDNavigator.cs:492-494), one lane per cluster
+		if (wv == 0) {
+			for (int r0 = 0; r0 < nroots; r0 += 64) {
+				int ri = r0 + lane;
+				if (ri < nroots) {
+					int root = roots[ri];
+					int L[5], Z[5], nl = 0, nz = 0, nrow = 0;
+					for (int j = root; j < J; j++) {
+						if (labl[j] == root) { if (nl < 5) L[nl] = j; nl++; }
+					}
+					for (int k = 0; k < M; k++) {
+						if (labz[k] == root) { if (nz < 5) Z[nz] = k; nz++; }
+					}
+					nrow = nl + nz;
+					if (nrow > 5) {
+						res[ri] = 0;
+						s_big = 1;
+					}
+					else {
+						double* mat = mats + lane;   // entry e at mat[e * 64]
+						for (int e = 0; e < 25; e++) mat[e * 64] = -INFINITY;
+						for (int x = 0; x < nl; x++) {
+							int j = L[x];
+							for (int y = 0; y < nz; y++) {
+								int k = Z[y];
+								if ((adj[(size_t) j * MW + (k >> 6)] >> (k & 63)) & 1ull) {
+									double dist = sqrt(quad_gen(prm.Rinv, zh[j] - zs[k * 3], zh[JP + j] - zs[k * 3 + 1],
+									                            zh[2 * JP + j] - zs[k * 3 + 2]));
+									mat[(x * 5 + y) * 64] = log(pdj[j]) + logmult - 0.5 * dist * dist;   // :439
+								}
+							}
+							mat[(x * 5 + nz + x) * 64] = log(1 - pdj[j]);   // :445
+						}
+						for (int y = 0; y < nz; y++) {
+							mat[((nl + y) * 5 + y) * 64] = prm.logkappa;   // :449
+							for (int x = 0; x < nl; x++) mat[((nl + y) * 5 + nz + x) * 64] = 0;   // :480-488
+						}
+						res[ri] = cluster_enumerate(mat, 64, nrow, J);
+					}
+				}
+			}
+		}
+		__syncthreads();
+		if (tid == 0) {
+			if (s_big) atomicOr(a.flags, PHD_FLAG_BIG_CLUSTER);
+			// total in the reference's component order: clusters holding detections (ascending first
+			// landmark), then the lone landmarks (misdetection only), then the lone measurements (clutter)
+			double total = 0;
+			for (int r = 0; r < nroots; r++) total += res[r];
+			for (int j = 0; j < J; j++) {
+				bool has = false;
+				for (int b = 0; b < MW; b++) has |= adj[(size_t) j * MW + b] != 0;
+				if (!has) total += log(1 - pdj[j]);
+			}
+			for (int k = 0; k < M; k++) {
+				if (labz[k] == J + k) total += prm.logkappa;
+			}
+			s_total = total;
+		}
+		__syncthreads();
+	}
+	if (tid == 0) {
+		double setll = s_total;
+		double ratio = (plog - pcount) - (clog - ccount);   // :390
+		double alpha = exp(setll + ratio);                  // :392
+		a.setll[p] = setll;
+		a.alpha[p] = alpha;
+		bout.weights[p] = bin.weights[p] * alpha;         // :335
+	}
+}
+
+// =================================================================================================
+// k_normalise_resample — PHDNavigator.cs:343-358, 724-777 on the whole weight vector (all ranks'
+// particles when sharded). Sums and the systematic-resampling recurrence run in the reference's
+// sequential order on one lane, so the result is bit-identical for any number of GPUs.
+//   w      : [P] in: un-normalised weights, out: normalised weights, or 1/P after resampling
+//   src    : [P] source slot of each particle (identity when not resampled)
+//   info   : [0] BestParticle, [1] resampled flag
+// =================================================================================================
+__global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, double* gw, int P, double min_eff, double u,
+                                                             int force_resample, int skip_normalise,
+                                                             int* src, int* info)
+{
+	__shared__ double s_sum;
+	__shared__ int s_res;
+	const int tid = threadIdx.x;
+	double* w = gw ? gw : a.bank[a.sel[SEL_OUT]].weights;
+	if (tid == 0) {
+		double sum = 0;
+		for (int i = 0; i < P; i++) sum += w[i];   // Accord Sum(): sequential
+		s_sum = (sum == 0) ? 1 : sum;               // :344
+	}
+	__syncthreads();
+	if (!skip_normalise) {
+		const double sum = s_sum;
+		for (int i = tid; i < P; i += 1024) w[i] = w[i] / sum;   // :345
+	}
+	__threadfence_block();
+	__syncthreads();
+	if (tid == 0) {
+		double maxweight = 0, cum = 0;
+		int best = 0;
+		for (int i = 0; i < P; i++) {
+			double wi = w[i];
+			if (wi > maxweight) { maxweight = wi; best = i; }   // :349-354
+			cum += wi * wi;                                     // :772-774
+		}
+		bool depleted = (1.0 / cum < min_eff * P);              // :776
+		if (force_resample > 0) depleted = true;
+		if (force_resample < 0) depleted = false;
+		s_res = depleted;
+		if (depleted) {   // ResampleParticles, :727-749
+			double random = u / P;
+			maxweight = 0;
+			int k = 0;
+			for (int i = 0; i < P; i++) {
+				for (; random > 0 && k < P; k++) random -= w[k];
+				int s = (k - 1 < 0) ? 0 : k - 1;   // u == 0 would index -1 in the reference: clamped
+				src[i] = s;
+				random += 1.0 / P;
+				if (w[s] > maxweight) { maxweight = w[s]; best = i; }
+			}
+		}
+		info[0] = best;
+		info[1] = depleted;
+	}
+	__syncthreads();
+	if (s_res) {
+		for (int i = tid; i < P; i += 1024) w[i] = 1.0 / P;   // :742
+	}
+	else {
+		for (int i = tid; i < P; i += 1024) src[i] = i;
+	}
+}
+
+// Deep copy of the resampled particles (PHDNavigator.cs:740-741) and rotation of the bank roles for the
+// next step, decided on the device from the resampling flag so the host never waits inside a step.
+//   not resampled: the new state is the OUT bank      -> next roles (IN, OUT, TMP) = (OUT, TMP, IN)
+//   resampled    : particle i <- OUT[src[first + i] - first] written to TMP -> next roles = (TMP, IN, OUT)
+//   frozen       : roles stay (benchmark steady state)
+__global__ __launch_bounds__(256) void k_gather_rotate(const StepBufs a, const int* src, const int* info, int first,
+                                                       int* sel_next, int frozen)
+{
+	const int i = blockIdx.x, tid = threadIdx.x;
+	const int resampled = info[1];
+	const int I = a.sel[SEL_IN], O = a.sel[SEL_OUT], T = a.sel[SEL_TMP];
+	if (i == 0 && tid == 0) {
+		if (frozen)         { sel_next[0] = I; sel_next[1] = O; sel_next[2] = T; }
+		else if (resampled) { sel_next[0] = T; sel_next[1] = I; sel_next[2] = O; }
+		else                { sel_next[0] = O; sel_next[1] = T; sel_next[2] = I; }
+		sel_next[3] = resampled ? T : O;   // where the result of this step lives
+	}
+	if (!resampled) return;
+	const MixView from = bank_view(a, SEL_OUT), dst = bank_view(a, SEL_TMP);
+	const int s = src[first + i] - first;
+	const int n = from.count[s];
+	const size_t db = (size_t) i * a.cap, fb = (size_t) s * a.cap;
+	for (int c = tid; c < n; c += 256) {
+		dst.w[db + c] = from.w[fb + c];
+#pragma unroll
+		for (int t = 0; t < 3; t++) dst.m[t][db + c] = from.m[t][fb + c];
+#pragma unroll
+		for (int t = 0; t < 6; t++) dst.P[t][db + c] = from.P[t][fb + c];
+	}
+	if (tid == 0) {
+		dst.count[i] = n;
+		a.bank[T].weights[i] = a.bank[O].weights[i];
+	}
+	if (tid < 7) a.bank[T].poses[(size_t) i * 7 + tid] = a.bank[O].poses[(size_t) s * 7 + tid];
+}
+
+// replicate particle 0 of the IN bank over `P` particles of the OUT bank (PHDNavigator.reset, :256-263)
+__global__ __launch_bounds__(256) void k_replicate(const StepBufs a, double weight)
+{
+	const int i = blockIdx.x, tid = threadIdx.x;
+	const MixView from = bank_view(a, SEL_IN), dst = bank_view(a, SEL_OUT);
+	const int n = from.count[0];
+	const size_t db = (size_t) i * a.cap;
+	for (int c = tid; c < n; c += 256) {
+		dst.w[db + c] = from.w[c];
+#pragma unroll
+		for (int t = 0; t < 3; t++) dst.m[t][db + c] = from.m[t][c];
+#pragma unroll
+		for (int t = 0; t < 6; t++) dst.P[t][db + c] = from.P[t][c];
+	}
+	const Bank& bi = a.bank[a.sel[SEL_IN]];
+	const Bank& bo = a.bank[a.sel[SEL_OUT]];
+	if (tid == 0) {
+		dst.count[i]  = n;
+		bo.weights[i] = weight;
+	}
+	if (tid < 7) bo.poses[(size_t) i * 7 + tid] = bi.poses[tid];
+}
+
+// =================================================================================================
+// multi-GPU resampling: particles are sharded contiguously over ranks; after the global resample a
+// slot may need a particle that lives on another rank. A migrating particle travels as one
+// fixed-size record: [count, pose(7), planes(10 x cap)] doubles.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_scatter_weights(const StepBufs a, const double* gw, int first)
+{
+	int i = blockIdx.x * 256 + threadIdx.x;
+	if (i < a.P) a.bank[a.sel[SEL_OUT]].weights[i] = gw[first + i];
+}
+
+__global__ __launch_bounds__(256) void k_pack_particles(const StepBufs a, const int* sendlist, double* sendbuf)
+{
+	const int r = blockIdx.x, tid = threadIdx.x;
+	const int s = sendlist[r];
+	const MixView from = bank_view(a, SEL_OUT);
+	const Bank& bo = a.bank[a.sel[SEL_OUT]];
+	const size_t rec = (size_t) 8 + (size_t) 10 * a.cap;
+	double* o = sendbuf + (size_t) r * rec;
+	const int n = from.count[s];
+	if (tid == 0) o[0] = (double) n;
+	if (tid < 7) o[1 + tid] = bo.poses[(size_t) s * 7 + tid];
+	const size_t fb = (size_t) s * a.cap;
+	for (int c = tid; c < n; c += 256) {
+		o[8 + c] = from.w[fb + c];
+#pragma unroll
+		for (int t = 0; t < 3; t++) o[8 + (size_t) (1 + t) * a.cap + c] = from.m[t][fb + c];
+#pragma unroll
+		for (int t = 0; t < 6; t++) o[8 + (size_t) (4 + t) * a.cap + c] = from.P[t][fb + c];
+	}
+}
+
+// dstsrc[i] >= 0: local source slot in the OUT bank; < 0: record -(dstsrc[i] + 1) of the receive buffer
+__global__ __launch_bounds__(256) void k_unpack_gather(const StepBufs a, const int* dstsrc, const double* recvbuf,
+                                                       double weight, int* sel_next, int frozen)
+{
+	const int i = blockIdx.x, tid = threadIdx.x;
+	const int I = a.sel[SEL_IN], O = a.sel[SEL_OUT], T = a.sel[SEL_TMP];
+	if (i == 0 && tid == 0) {
+		if (frozen) { sel_next[0] = I; sel_next[1] = O; sel_next[2] = T; }
+		else        { sel_next[0] = T; sel_next[1] = I; sel_next[2] = O; }
+		sel_next[3] = T;
+	}
+	const MixView from = bank_view(a, SEL_OUT), dst = bank_view(a, SEL_TMP);
+	const size_t db = (size_t) i * a.cap;
+	const int code = dstsrc[i];
+	if (code >= 0) {
+		const int n = from.count[code];
+		const size_t fb = (size_t) code * a.cap;
+		for (int c = tid; c < n; c += 256) {
+			dst.w[db + c] = from.w[fb + c];
+#pragma unroll
+			for (int t = 0; t < 3; t++) dst.m[t][db + c] = from.m[t][fb + c];
+#pragma unroll
+			for (int t = 0; t < 6; t++) dst.P[t][db + c] = from.P[t][fb + c];
+		}
+		if (tid == 0) dst.count[i] = n;
+		if (tid < 7) a.bank[T].poses[(size_t) i * 7 + tid] = a.bank[O].poses[(size_t) code * 7 + tid];
+	}
+	else {
+		const size_t rec = (size_t) 8 + (size_t) 10 * a.cap;
+		const double* r = recvbuf + (size_t) (-(code + 1)) * rec;
+		const int n = (int) r[0];
+		for (int c = tid; c < n; c += 256) {
+			dst.w[db + c] = r[8 + c];
+#pragma unroll
+			for (int t = 0; t < 3; t++) dst.m[t][db + c] = r[8 + (size_t) (1 + t) * a.cap + c];
+#pragma unroll
+			for (int t = 0; t < 6; t++) dst.P[t][db + c] = r[8 + (size_t) (4 + t) * a.cap + c];
+		}
+		if (tid == 0) dst.count[i] = n;
+		if (tid < 7) a.bank[T].poses[(size_t) i * 7 + tid] = r[1 + tid];
+	}
+	if (tid == 0) a.bank[T].weights[i] = weight;
+}

@@ -1,0 +1,1012 @@
+// phdhip.hip — host side of libphdhip.so: the C-ABI of include/phdhip.h over the kernels of
+// phd_kernels.h. Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -shared -fPIC
+//
+// There is no CPU implementation behind this ABI: without a HIP device phd_create fails with
+// PHD_ERR_NO_DEVICE and every other entry point needs a handle.
+#include "../../include/phdhip.h"
+#include "phd_kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Timer {
+	const char* name;
+	hipEvent_t  t0, t1;
+	bool        used;
+};
+
+}  // namespace
+
+struct phd_navigator {
+	phd_params  prm;
+	DevParams   dp;
+	int         device = 0;
+	hipStream_t stream = nullptr;
+	int Pcap = 0, cap = 0, Mcap = 0, ecap = 0, Jcap = 0, cutcap = 0;
+	int P = 0, M = 0;
+	bool frozen = false;
+
+	Bank   bank[3];
+	int*   d_sel = nullptr;      // [2][4]: roles for the current / next step (+ result bank)
+	int    parity = 0;
+	int    h_sel[4] = {0, 1, 2, 0};
+
+	double* d_z = nullptr;
+	double* d_emit_w = nullptr;  int* d_emit_idx = nullptr; double* d_emit_rec = nullptr; int* d_emit_count = nullptr;
+	int*    d_born_count = nullptr; int* d_born_k = nullptr; double* d_born_mean = nullptr;
+	double* d_alpha = nullptr; double* d_setll = nullptr;
+	int*    d_flags = nullptr; int* d_src = nullptr; int* d_info = nullptr;
+	double* d_gw = nullptr; int gwcap = 0;           // gathered weights of all ranks
+	double* d_stage = nullptr;                       // staging for uploads
+	// migration (multi-GPU resampling)
+	double* d_send = nullptr; double* d_recv = nullptr; int* d_plan = nullptr; int migcap = 0;
+	std::vector<int> h_plan_send, h_plan_recv;       // particle lists
+	int nsend = 0, nrecv = 0, last_world_particles = 1;
+
+	// host mirrors handed out by the getters
+	std::vector<double> h_weights, h_poses, h_mw, h_mm, h_mc, h_alpha, h_setll, h_tmp;
+	std::vector<int32_t> h_src;
+	int  h_info[2] = {0, 0};
+	int  h_flags = 0;
+	bool stage_valid = false;
+
+	std::vector<Timer>       timers;
+	std::vector<const char*> tnames;
+	std::vector<double>      tms;
+	std::string err;
+
+	int fail(int code, const std::string& what)
+	{
+		err = what;
+		return code;
+	}
+};
+
+namespace {
+
+#define HC(call)                                                                                    \
+	do {                                                                                            \
+		hipError_t e_ = (call);                                                                     \
+		if (e_ != hipSuccess) {                                                                     \
+			return nav->fail(PHD_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_));    \
+		}                                                                                           \
+	} while (0)
+
+void inv3_host(const double* a, double* inv, double* det)
+{
+	double c00 = a[4] * a[8] - a[5] * a[7];
+	double c01 = a[3] * a[8] - a[5] * a[6];
+	double c02 = a[3] * a[7] - a[4] * a[6];
+	double d   = a[0] * c00 - a[1] * c01 + a[2] * c02;
+	double id  = 1.0 / d;
+	inv[0] = c00 * id;
+	inv[1] = (a[2] * a[7] - a[1] * a[8]) * id;
+	inv[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+	inv[3] = (a[5] * a[6] - a[3] * a[8]) * id;
+	inv[4] = (a[0] * a[8] - a[2] * a[6]) * id;
+	inv[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+	inv[6] = c02 * id;
+	inv[7] = (a[1] * a[6] - a[0] * a[7]) * id;
+	inv[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+	*det = d;
+}
+
+DevParams make_dev_params(const phd_params& p)
+{
+	DevParams d;
+	d.focal  = p.measurer[0];
+	d.rmin   = (double) (float) p.measurer[1];   // AForge.Range is float32 (PRM3DMeasurer.cs:65,110)
+	d.rmax   = (double) (float) p.measurer[2];
+	d.left   = (double) (int) p.measurer[3];     // XNA Rectangle is int (PRM3DMeasurer.cs:111)
+	d.top    = (double) (int) p.measurer[4];
+	d.right  = (double) ((int) p.measurer[3] + (int) p.measurer[5]);
+	d.bottom = (double) ((int) p.measurer[4] + (int) p.measurer[6]);
+	for (int i = 0; i < 3; i++) d.ramp[i] = p.visibility_ramp[i];
+	for (int i = 0; i < 9; i++) d.R[i] = p.R[i];
+	double det;
+	inv3_host(p.R, d.Rinv, &det);
+	d.logRmult = std::log(std::pow(2 * 3.14159265358979323846, -1.0) / std::sqrt(std::fabs(det)));
+	d.pd       = p.pd;
+	d.kappa    = p.clutter_density;
+	d.logkappa = std::log(p.clutter_density);
+	const double* B = p.birth_covariance;
+	d.birthP[0] = B[0]; d.birthP[1] = B[1]; d.birthP[2] = B[2]; d.birthP[3] = B[4]; d.birthP[4] = B[5]; d.birthP[5] = B[8];
+	d.birthw     = p.birth_weight;
+	d.minw       = p.min_weight;
+	d.expl_thr   = p.exploration_threshold;
+	d.r_correct  = p.density_distance_threshold;
+	d.r_explore  = 3 * p.density_distance_threshold;
+	d.merge_thr2 = p.merge_threshold * p.merge_threshold;
+	d.min_eff    = p.min_effective_particle;
+	double floor = p.min_weight * p.clutter_density;
+	d.emit_log_floor = (floor > 0) ? std::log(floor) : -INFINITY;
+	d.gate_metric = p.gate_metric;
+	d.maxq        = p.max_quantity;
+	return d;
+}
+
+StepBufs make_bufs(phd_navigator* nav)
+{
+	StepBufs b;
+	b.P = nav->P; b.cap = nav->cap; b.M = nav->M; b.Mcap = nav->Mcap; b.ecap = nav->ecap; b.Jcap = nav->Jcap;
+	b.plane = (size_t) nav->Pcap * nav->cap;
+	for (int i = 0; i < 3; i++) b.bank[i] = nav->bank[i];
+	b.sel = nav->d_sel + nav->parity * 4;
+	b.z = nav->d_z;
+	b.emit_w = nav->d_emit_w; b.emit_idx = nav->d_emit_idx; b.emit_rec = nav->d_emit_rec; b.emit_count = nav->d_emit_count;
+	b.born_count = nav->d_born_count; b.born_k = nav->d_born_k; b.born_mean = nav->d_born_mean;
+	b.alpha = nav->d_alpha; b.setll = nav->d_setll; b.flags = nav->d_flags;
+	return b;
+}
+
+int zb_of(int M) { return M <= 64 ? 1 : (M <= 128 ? 2 : 4); }
+
+size_t lds_predict_correct(int ZB)
+{
+	int MP = ZB * 64;
+	return (size_t) (3 * MP + 3 * MP + 4 * MP + MP + 18 * TILE) * 8 + (size_t) (MP + 2) * 4;
+}
+
+size_t lds_prune(int ecap, int cutcap) { return (size_t) (ecap + 10 * cutcap) * 8 + (size_t) ecap * 4; }
+
+void timer_begin(phd_navigator* nav, const char* name)
+{
+	for (Timer& t : nav->timers) {
+		if (t.name == name) {
+			hipEventRecord(t.t0, nav->stream);
+			t.used = true;
+			return;
+		}
+	}
+	Timer t;
+	t.name = name;
+	hipEventCreate(&t.t0);
+	hipEventCreate(&t.t1);
+	t.used = true;
+	hipEventRecord(t.t0, nav->stream);
+	nav->timers.push_back(t);
+}
+
+void timer_end(phd_navigator* nav, const char* name)
+{
+	for (Timer& t : nav->timers) {
+		if (t.name == name) hipEventRecord(t.t1, nav->stream);
+	}
+}
+
+const char* T_PC = "k_predict_correct";
+const char* T_PM = "k_prune_merge";
+const char* T_WA = "k_weight_alpha";
+const char* T_NR = "k_normalise_resample";
+const char* T_GR = "k_gather_rotate";
+
+template <int ZB>
+int launch_map_kernels(phd_navigator* nav, const StepBufs& b, bool with_alpha)
+{
+	const int P = nav->P;
+	HC(hipFuncSetAttribute((const void*) k_predict_correct<ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_predict_correct(ZB)));
+	timer_begin(nav, T_PC);
+	hipLaunchKernelGGL(k_predict_correct<ZB>, dim3(P), dim3(256), lds_predict_correct(ZB), nav->stream, nav->dp, b);
+	timer_end(nav, T_PC);
+	HC(hipGetLastError());
+
+	size_t lp = lds_prune(nav->ecap, nav->cutcap);
+	HC(hipFuncSetAttribute((const void*) k_prune_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lp));
+	timer_begin(nav, T_PM);
+	hipLaunchKernelGGL(k_prune_merge, dim3(P), dim3(64), lp, nav->stream, nav->dp, b, nav->cutcap);
+	timer_end(nav, T_PM);
+	HC(hipGetLastError());
+
+	if (with_alpha) {
+		AlphaLds lay = alpha_lds(ZB * 64, nav->Jcap, nav->cutcap);
+		HC(hipFuncSetAttribute((const void*) k_weight_alpha<ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
+		timer_begin(nav, T_WA);
+		hipLaunchKernelGGL(k_weight_alpha<ZB>, dim3(P), dim3(256), lay.bytes, nav->stream, nav->dp, b, nav->cutcap);
+		timer_end(nav, T_WA);
+		HC(hipGetLastError());
+	}
+	return PHD_OK;
+}
+
+int launch_map(phd_navigator* nav, const StepBufs& b, bool with_alpha)
+{
+	switch (zb_of(nav->M)) {
+	case 1:  return launch_map_kernels<1>(nav, b, with_alpha);
+	case 2:  return launch_map_kernels<2>(nav, b, with_alpha);
+	default: return launch_map_kernels<4>(nav, b, with_alpha);
+	}
+}
+
+int check_flags(phd_navigator* nav)
+{
+	int f = nav->h_flags;
+	if (f & PHD_FLAG_EMIT_OVERFLOW) {
+		return nav->fail(PHD_ERR_CAPACITY, "corrected mixture outgrew emit_capacity (" + std::to_string(nav->ecap) + " components per particle)");
+	}
+	if (f & PHD_FLAG_J_OVERFLOW) {
+		return nav->fail(PHD_ERR_CAPACITY, "map estimate larger than the landmark scratch (" + std::to_string(nav->Jcap) + ")");
+	}
+	if (f & PHD_FLAG_BIG_CLUSTER) {
+		return nav->fail(PHD_ERR_ASSOCIATION, "data-association cluster with more than 5 rows: beyond the on-device solver");
+	}
+	return PHD_OK;
+}
+
+// copy one particle's mixture out of a bank into h_mw / h_mm / h_mc (row-major mean[3n], cov[9n])
+int fetch_map(phd_navigator* nav, int bankidx, int particle, int* ncomp)
+{
+	int n = 0;
+	HC(hipMemcpyAsync(&n, nav->bank[bankidx].count + particle, sizeof(int), hipMemcpyDeviceToHost, nav->stream));
+	HC(hipStreamSynchronize(nav->stream));
+	if (n < 0 || n > nav->cap) return nav->fail(PHD_ERR_GENERIC, "corrupt component count");
+	nav->h_tmp.resize((size_t) 10 * std::max(n, 1));
+	size_t plane = (size_t) nav->Pcap * nav->cap;
+	if (n > 0) {
+		HC(hipMemcpy2DAsync(nav->h_tmp.data(), (size_t) n * 8, nav->bank[bankidx].mix + (size_t) particle * nav->cap,
+		                    plane * 8, (size_t) n * 8, 10, hipMemcpyDeviceToHost, nav->stream));
+		HC(hipStreamSynchronize(nav->stream));
+	}
+	nav->h_mw.resize(std::max(n, 1));
+	nav->h_mm.resize((size_t) 3 * std::max(n, 1));
+	nav->h_mc.resize((size_t) 9 * std::max(n, 1));
+	const double* t = nav->h_tmp.data();
+	for (int c = 0; c < n; c++) {
+		nav->h_mw[c] = t[c];
+		for (int k = 0; k < 3; k++) nav->h_mm[c * 3 + k] = t[(size_t) (1 + k) * n + c];
+		double xx = t[(size_t) 4 * n + c], xy = t[(size_t) 5 * n + c], xz = t[(size_t) 6 * n + c];
+		double yy = t[(size_t) 7 * n + c], yz = t[(size_t) 8 * n + c], zz = t[(size_t) 9 * n + c];
+		double* C = &nav->h_mc[(size_t) c * 9];
+		C[0] = xx; C[1] = xy; C[2] = xz; C[3] = xy; C[4] = yy; C[5] = yz; C[6] = xz; C[7] = yz; C[8] = zz;
+	}
+	*ncomp = n;
+	return PHD_OK;
+}
+
+// host arrays -> the 10 planes of one particle (covariance: upper triangle of the given 3x3)
+void pack_planes(const double* w, const double* mean3, const double* cov9, int n, int stride, double* planes)
+{
+	static const int tri[6] = {0, 1, 2, 4, 5, 8};
+	for (int c = 0; c < n; c++) {
+		planes[c] = w[c];
+		for (int k = 0; k < 3; k++) planes[(size_t) (1 + k) * stride + c] = mean3[c * 3 + k];
+		for (int k = 0; k < 6; k++) planes[(size_t) (4 + k) * stride + c] = cov9[c * 9 + tri[k]];
+	}
+}
+
+int upload_particle(phd_navigator* nav, int bankidx, int particle, const double* w, const double* mean3,
+                    const double* cov9, int n)
+{
+	if (n < 0 || n > nav->cap) return nav->fail(PHD_ERR_CAPACITY, "map larger than max_components");
+	size_t plane = (size_t) nav->Pcap * nav->cap;
+	if (n > 0) {
+		std::vector<double> planes((size_t) 10 * n);
+		pack_planes(w, mean3, cov9, n, n, planes.data());
+		HC(hipMemcpy2D(nav->bank[bankidx].mix + (size_t) particle * nav->cap, plane * 8, planes.data(), (size_t) n * 8,
+		               (size_t) n * 8, 10, hipMemcpyHostToDevice));
+	}
+	HC(hipMemcpy(nav->bank[bankidx].count + particle, &n, sizeof(int), hipMemcpyHostToDevice));
+	return PHD_OK;
+}
+
+int sync_state(phd_navigator* nav)
+{
+	HC(hipStreamSynchronize(nav->stream));
+	HC(hipMemcpy(nav->h_sel, nav->d_sel + nav->parity * 4, 4 * sizeof(int), hipMemcpyDeviceToHost));
+	HC(hipMemcpy(nav->h_info, nav->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost));
+	HC(hipMemcpy(&nav->h_flags, nav->d_flags, sizeof(int), hipMemcpyDeviceToHost));
+	return PHD_OK;
+}
+
+int cur_bank(const phd_navigator* nav) { return nav->h_sel[SEL_IN]; }
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int phd_api_version(void) { return PHD_API_VERSION; }
+
+const char* phd_create_error(void) { return g_create_error.c_str(); }
+
+void phd_default_params(phd_params* p, int max_particles, int max_components, int max_measurements)
+{
+	std::memset(p, 0, sizeof(*p));
+	p->model = PHD_MODEL_PRM3D;
+	p->zdim  = 3;
+	const double meas[7] = {575.8156, (double) 0.1f, (double) 2.0f, -320, -240, 640, 480};   // PRM3DMeasurer.cs:70-73
+	std::memcpy(p->measurer, meas, sizeof(meas));
+	p->R[0] = 2.0; p->R[4] = 2.0; p->R[8] = 1e-3;                                             // Config.cs:251-253
+	for (int i = 0; i < 3; i++) p->visibility_ramp[i] = 3 * std::sqrt(p->R[i * 4]);          // Config.cs:257-259
+	p->pd = 0.9;                                                                              // Config.cs:63,90
+	p->clutter_density = 3e-7;                                                                // Config.cs:256,262
+	p->birth_covariance[0] = p->birth_covariance[4] = p->birth_covariance[8] = 1e-2;          // Config.cs:77-79
+	p->birth_weight = 0.05; p->min_weight = 1e-3; p->min_effective_particle = 0.1;            // Config.cs:80-82
+	p->max_quantity = 600; p->merge_threshold = 0.3; p->exploration_threshold = 1e-5;         // Config.cs:83-85
+	p->density_distance_threshold = 0.5;                                                      // Config.cs:74
+	p->gate_metric = PHD_GATE_SQUARED_EUCLIDEAN;
+	p->max_particles = max_particles; p->max_components = max_components; p->max_measurements = max_measurements;
+	p->emit_capacity = 0;
+}
+
+phd_navigator* phd_create(const phd_params* params, int device)
+{
+	g_create_error.clear();
+	if (!params) { g_create_error = "params is NULL"; return nullptr; }
+	if (params->model != PHD_MODEL_PRM3D || params->zdim != 3) {
+		g_create_error = "only the PRM3D model (Pose3D + PixelRangeMeasurement) runs on the device";
+		return nullptr;
+	}
+	if (params->max_particles < 1 || params->max_components < 1 || params->max_measurements < 0 ||
+	    params->max_measurements > 256 || params->max_quantity < 1 || params->max_components < params->max_quantity) {
+		g_create_error = "capacities out of range (need max_components >= max_quantity >= 1, max_measurements <= 256)";
+		return nullptr;
+	}
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+		g_create_error = "no HIP device: libphdhip has no CPU path";
+		return nullptr;
+	}
+	if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) {
+		g_create_error = "bad device ordinal";
+		return nullptr;
+	}
+	phd_navigator* nav = new phd_navigator();
+	nav->prm = *params;
+	nav->dp  = make_dev_params(*params);
+	nav->device = device;
+	nav->Pcap = params->max_particles;
+	nav->cap  = (params->max_components + 63) & ~63;
+	nav->Mcap = std::max(64, (params->max_measurements + 63) & ~63);
+	nav->cutcap = params->max_quantity;
+	int ecap = params->emit_capacity > 0 ? params->emit_capacity : 4 * (nav->cap + nav->Mcap);
+	nav->ecap = (std::max(ecap, nav->cutcap) + 63) & ~63;
+	nav->Jcap = std::min(512, (nav->cutcap + 63) & ~63);
+	nav->P = 0;
+
+	auto dalloc = [&](void** ptr, size_t bytes) { return hipMalloc(ptr, std::max<size_t>(bytes, 16)) == hipSuccess; };
+	bool ok = hipStreamCreateWithFlags(&nav->stream, hipStreamNonBlocking) == hipSuccess;
+	size_t plane = (size_t) nav->Pcap * nav->cap;
+	for (int i = 0; i < 3 && ok; i++) {
+		ok = ok && dalloc((void**) &nav->bank[i].mix, plane * 10 * 8);
+		ok = ok && dalloc((void**) &nav->bank[i].count, (size_t) nav->Pcap * 4);
+		ok = ok && dalloc((void**) &nav->bank[i].poses, (size_t) nav->Pcap * 7 * 8);
+		ok = ok && dalloc((void**) &nav->bank[i].weights, (size_t) nav->Pcap * 8);
+		if (ok) {
+			hipMemset(nav->bank[i].count, 0, (size_t) nav->Pcap * 4);
+			hipMemset(nav->bank[i].weights, 0, (size_t) nav->Pcap * 8);
+			hipMemset(nav->bank[i].poses, 0, (size_t) nav->Pcap * 7 * 8);
+		}
+	}
+	size_t E = (size_t) nav->Pcap * nav->ecap;
+	ok = ok && dalloc((void**) &nav->d_sel, 8 * 4);
+	ok = ok && dalloc((void**) &nav->d_z, (size_t) nav->Mcap * 3 * 8);
+	ok = ok && dalloc((void**) &nav->d_emit_w, E * 8) && dalloc((void**) &nav->d_emit_idx, E * 4);
+	ok = ok && dalloc((void**) &nav->d_emit_rec, E * 9 * 8) && dalloc((void**) &nav->d_emit_count, (size_t) nav->Pcap * 4);
+	ok = ok && dalloc((void**) &nav->d_born_count, (size_t) nav->Pcap * 4);
+	ok = ok && dalloc((void**) &nav->d_born_k, (size_t) nav->Pcap * nav->Mcap * 4);
+	ok = ok && dalloc((void**) &nav->d_born_mean, (size_t) nav->Pcap * nav->Mcap * 3 * 8);
+	ok = ok && dalloc((void**) &nav->d_alpha, (size_t) nav->Pcap * 8) && dalloc((void**) &nav->d_setll, (size_t) nav->Pcap * 8);
+	ok = ok && dalloc((void**) &nav->d_flags, 4) && dalloc((void**) &nav->d_info, 8);
+	ok = ok && dalloc((void**) &nav->d_src, (size_t) nav->Pcap * 4);
+	if (!ok) {
+		g_create_error = std::string("device allocation failed: ") + hipGetErrorString(hipGetLastError());
+		phd_destroy(nav);
+		return nullptr;
+	}
+	int sel[8] = {0, 1, 2, 0, 0, 1, 2, 0};
+	hipMemcpy(nav->d_sel, sel, sizeof(sel), hipMemcpyHostToDevice);
+	hipMemset(nav->d_flags, 0, 4);
+	hipMemset(nav->d_info, 0, 8);
+	hipMemset(nav->d_emit_count, 0, (size_t) nav->Pcap * 4);
+	hipMemset(nav->d_born_count, 0, (size_t) nav->Pcap * 4);
+	return nav;
+}
+
+void phd_destroy(phd_navigator* nav)
+{
+	if (!nav) return;
+	hipSetDevice(nav->device);
+	if (nav->stream) hipStreamSynchronize(nav->stream);
+	for (int i = 0; i < 3; i++) {
+		hipFree(nav->bank[i].mix); hipFree(nav->bank[i].count); hipFree(nav->bank[i].poses); hipFree(nav->bank[i].weights);
+	}
+	hipFree(nav->d_sel); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
+	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
+	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
+	hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
+	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
+	if (nav->stream) hipStreamDestroy(nav->stream);
+	delete nav;
+}
+
+const char* phd_last_error(const phd_navigator* nav) { return nav ? nav->err.c_str() : "null handle"; }
+
+int phd_particle_count(phd_navigator* nav) { return nav ? nav->P : 0; }
+
+int phd_reset(phd_navigator* nav, int nparticles, const double* pose7, const double* w, const double* mean3,
+              const double* cov9, int ncomp)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nparticles < 1 || nparticles > nav->Pcap || !pose7 || ncomp < 0) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_reset: bad particle count / pose / ncomp");
+	hipSetDevice(nav->device);
+	int rc = sync_state(nav);
+	if (rc) return rc;
+	int I = nav->h_sel[SEL_IN];
+	rc = upload_particle(nav, I, 0, w, mean3, cov9, ncomp);
+	if (rc) return rc;
+	HC(hipMemcpy(nav->bank[I].poses, pose7, 7 * 8, hipMemcpyHostToDevice));
+	nav->P = nparticles;
+	StepBufs b = make_bufs(nav);
+	hipLaunchKernelGGL(k_replicate, dim3(nparticles), dim3(256), 0, nav->stream, b, 1.0 / nparticles);
+	HC(hipGetLastError());
+	// the replicated state is in the OUT bank: make it current
+	int sel[4] = {nav->h_sel[SEL_OUT], nav->h_sel[SEL_TMP], nav->h_sel[SEL_IN], nav->h_sel[SEL_OUT]};
+	HC(hipStreamSynchronize(nav->stream));
+	HC(hipMemcpy(nav->d_sel + nav->parity * 4, sel, sizeof(sel), hipMemcpyHostToDevice));
+	std::memcpy(nav->h_sel, sel, sizeof(sel));
+	nav->h_info[0] = 0; nav->h_info[1] = 0;   // BestParticle = 0 (:265)
+	HC(hipMemcpy(nav->d_info, nav->h_info, 8, hipMemcpyHostToDevice));
+	nav->stage_valid = false;
+	return PHD_OK;
+}
+
+int phd_set_poses(phd_navigator* nav, const double* poses7, int nparticles)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nparticles != nav->P || !poses7) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_poses: particle count mismatch");
+	hipSetDevice(nav->device);
+	HC(hipMemcpyAsync(nav->bank[cur_bank(nav)].poses, poses7, (size_t) nparticles * 7 * 8, hipMemcpyHostToDevice, nav->stream));
+	HC(hipStreamSynchronize(nav->stream));
+	return PHD_OK;
+}
+
+int phd_set_weights(phd_navigator* nav, const double* weights, int nparticles)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nparticles != nav->P || !weights) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_weights: particle count mismatch");
+	hipSetDevice(nav->device);
+	HC(hipMemcpyAsync(nav->bank[cur_bank(nav)].weights, weights, (size_t) nparticles * 8, hipMemcpyHostToDevice, nav->stream));
+	HC(hipStreamSynchronize(nav->stream));
+	return PHD_OK;
+}
+
+int phd_set_map(phd_navigator* nav, int particle, const double* w, const double* mean3, const double* cov9, int ncomp)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (particle < 0 || particle >= nav->P) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_map: particle out of range");
+	hipSetDevice(nav->device);
+	HC(hipStreamSynchronize(nav->stream));
+	return upload_particle(nav, cur_bank(nav), particle, w, mean3, cov9, ncomp);
+}
+
+// bulk upload of the whole particle set in the device layout (bench / tests):
+// planes[10][nparticles][stride] (w, mx, my, mz, xx, xy, xz, yy, yz, zz), counts[nparticles],
+// poses[nparticles][7], weights[nparticles]. Sets the particle count.
+int phd_upload_state_soa(phd_navigator* nav, int nparticles, int stride, const double* planes, const int32_t* counts,
+                         const double* poses7, const double* weights)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nparticles < 1 || nparticles > nav->Pcap || stride < 0 || stride > nav->cap) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_upload_state_soa: sizes out of range");
+	hipSetDevice(nav->device);
+	int rc = sync_state(nav);
+	if (rc) return rc;
+	int I = cur_bank(nav);
+	size_t plane = (size_t) nav->Pcap * nav->cap;
+	for (int f = 0; f < 10 && stride > 0; f++) {
+		HC(hipMemcpy2D(nav->bank[I].mix + f * plane, (size_t) nav->cap * 8, planes + (size_t) f * nparticles * stride,
+		               (size_t) stride * 8, (size_t) stride * 8, nparticles, hipMemcpyHostToDevice));
+	}
+	HC(hipMemcpy(nav->bank[I].count, counts, (size_t) nparticles * 4, hipMemcpyHostToDevice));
+	HC(hipMemcpy(nav->bank[I].poses, poses7, (size_t) nparticles * 7 * 8, hipMemcpyHostToDevice));
+	HC(hipMemcpy(nav->bank[I].weights, weights, (size_t) nparticles * 8, hipMemcpyHostToDevice));
+	nav->P = nparticles;
+	nav->stage_valid = false;
+	return PHD_OK;
+}
+
+// bulk download in the same layout; planes must hold [10][P][stride] with stride >= the largest count
+int phd_download_state_soa(phd_navigator* nav, int stride, double* planes, int32_t* counts, double* poses7, double* weights)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	hipSetDevice(nav->device);
+	int rc = sync_state(nav);
+	if (rc) return rc;
+	if (stride < 0 || stride > nav->cap) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_download_state_soa: stride out of range");
+	int I = cur_bank(nav);
+	size_t plane = (size_t) nav->Pcap * nav->cap;
+	for (int f = 0; f < 10 && stride > 0; f++) {
+		HC(hipMemcpy2D(planes + (size_t) f * nav->P * stride, (size_t) stride * 8, nav->bank[I].mix + f * plane,
+		               (size_t) nav->cap * 8, (size_t) stride * 8, nav->P, hipMemcpyDeviceToHost));
+	}
+	HC(hipMemcpy(counts, nav->bank[I].count, (size_t) nav->P * 4, hipMemcpyDeviceToHost));
+	if (poses7) HC(hipMemcpy(poses7, nav->bank[I].poses, (size_t) nav->P * 7 * 8, hipMemcpyDeviceToHost));
+	if (weights) HC(hipMemcpy(weights, nav->bank[I].weights, (size_t) nav->P * 8, hipMemcpyDeviceToHost));
+	return PHD_OK;
+}
+
+int phd_set_measurements(phd_navigator* nav, const double* z3, int nmeasurements)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nmeasurements < 0 || nmeasurements > nav->prm.max_measurements || (nmeasurements > 0 && !z3)) {
+		return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_measurements: count out of range");
+	}
+	hipSetDevice(nav->device);
+	if (nmeasurements > 0) {
+		HC(hipMemcpyAsync(nav->d_z, z3, (size_t) nmeasurements * 3 * 8, hipMemcpyHostToDevice, nav->stream));
+		HC(hipStreamSynchronize(nav->stream));
+	}
+	nav->M = nmeasurements;
+	return PHD_OK;
+}
+
+int phd_set_frozen(phd_navigator* nav, uint8_t frozen)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	nav->frozen = frozen != 0;
+	return PHD_OK;
+}
+
+int phd_step_async(phd_navigator* nav, uint8_t onlymapping, double u_resample)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->P < 1) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step: no particles (call phd_reset first)");
+	hipSetDevice(nav->device);
+	StepBufs b = make_bufs(nav);
+	int rc = launch_map(nav, b, !onlymapping);
+	if (rc) return rc;
+	timer_begin(nav, T_NR);
+	hipLaunchKernelGGL(k_normalise_resample, dim3(1), dim3(1024), 0, nav->stream, b, (double*) nullptr, nav->P,
+	                   nav->dp.min_eff, u_resample, onlymapping ? -1 : 0, onlymapping ? 1 : 0, nav->d_src, nav->d_info);
+	timer_end(nav, T_NR);
+	HC(hipGetLastError());
+	int* sel_next = nav->d_sel + (nav->parity ^ 1) * 4;
+	timer_begin(nav, T_GR);
+	hipLaunchKernelGGL(k_gather_rotate, dim3(nav->P), dim3(256), 0, nav->stream, b, nav->d_src, nav->d_info, 0, sel_next,
+	                   nav->frozen ? 1 : 0);
+	timer_end(nav, T_GR);
+	HC(hipGetLastError());
+	nav->parity ^= 1;
+	nav->stage_valid = false;
+	return PHD_OK;
+}
+
+int phd_sync(phd_navigator* nav)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	hipSetDevice(nav->device);
+	int rc = sync_state(nav);
+	if (rc) return rc;
+	rc = check_flags(nav);
+	if (nav->h_flags) {
+		hipMemset(nav->d_flags, 0, 4);
+	}
+	return rc;
+}
+
+int phd_slam_update(phd_navigator* nav, const double* z3, int nmeasurements, uint8_t onlymapping, double u_resample)
+{
+	int rc = phd_set_measurements(nav, z3, nmeasurements);
+	if (rc) return rc;
+	rc = phd_step_async(nav, onlymapping, u_resample);
+	if (rc) return rc;
+	return phd_sync(nav);
+}
+
+const double* phd_weights(phd_navigator* nav, int* length)
+{
+	if (!nav) return nullptr;
+	hipSetDevice(nav->device);
+	if (sync_state(nav)) return nullptr;
+	// in frozen mode the roles do not advance: the result of the last step is in h_sel[3]
+	int bidx = nav->frozen ? nav->h_sel[3] : cur_bank(nav);
+	nav->h_weights.resize(std::max(nav->P, 1));
+	if (hipMemcpy(nav->h_weights.data(), nav->bank[bidx].weights, (size_t) nav->P * 8, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+	if (length) *length = nav->P;
+	return nav->h_weights.data();
+}
+
+int phd_best_particle(phd_navigator* nav)
+{
+	if (!nav) return -1;
+	hipSetDevice(nav->device);
+	if (sync_state(nav)) return -1;
+	return nav->h_info[0];
+}
+
+const double* phd_poses(phd_navigator* nav, int* length)
+{
+	if (!nav) return nullptr;
+	hipSetDevice(nav->device);
+	if (sync_state(nav)) return nullptr;
+	int bidx = nav->frozen ? nav->h_sel[3] : cur_bank(nav);
+	nav->h_poses.resize((size_t) std::max(nav->P, 1) * 7);
+	if (hipMemcpy(nav->h_poses.data(), nav->bank[bidx].poses, (size_t) nav->P * 7 * 8, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+	if (length) *length = nav->P * 7;
+	return nav->h_poses.data();
+}
+
+int phd_map(phd_navigator* nav, int particle, int* ncomp, const double** w, const double** mean3, const double** cov9)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (particle < 0 || particle >= nav->P || !ncomp) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_map: particle out of range");
+	hipSetDevice(nav->device);
+	int rc = sync_state(nav);
+	if (rc) return rc;
+	int bidx = nav->frozen ? nav->h_sel[3] : cur_bank(nav);
+	rc = fetch_map(nav, bidx, particle, ncomp);
+	if (rc) return rc;
+	if (w) *w = nav->h_mw.data();
+	if (mean3) *mean3 = nav->h_mm.data();
+	if (cov9) *cov9 = nav->h_mc.data();
+	return PHD_OK;
+}
+
+const int32_t* phd_resample_sources(phd_navigator* nav, int* length, uint8_t* resampled)
+{
+	if (!nav) return nullptr;
+	hipSetDevice(nav->device);
+	if (sync_state(nav)) return nullptr;
+	nav->h_src.resize(std::max(nav->P, 1));
+	if (hipMemcpy(nav->h_src.data(), nav->d_src, (size_t) nav->P * 4, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+	if (length) *length = nav->P;
+	if (resampled) *resampled = nav->h_info[1] ? 1 : 0;
+	return nav->h_src.data();
+}
+
+// ---- stage-level entry points ------------------------------------------------------------------
+int phd_stage_run(phd_navigator* nav, const double* z3, int nmeasurements, uint8_t with_alpha)
+{
+	int rc = phd_set_measurements(nav, z3, nmeasurements);
+	if (rc) return rc;
+	if (nav->P < 1) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_stage_run: no particles");
+	rc = sync_state(nav);
+	if (rc) return rc;
+	StepBufs b = make_bufs(nav);
+	rc = launch_map(nav, b, with_alpha != 0);
+	if (rc) return rc;
+	rc = sync_state(nav);
+	if (rc) return rc;
+	nav->stage_valid = true;
+	rc = check_flags(nav);
+	if (nav->h_flags) hipMemset(nav->d_flags, 0, 4);
+	return rc;
+}
+
+int phd_stage_map(phd_navigator* nav, int stage, int particle, int* ncomp, const double** w, const double** mean3,
+                  const double** cov9)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (!nav->stage_valid) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_stage_map: call phd_stage_run first");
+	if (particle < 0 || particle >= nav->P || !ncomp) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_stage_map: particle out of range");
+	hipSetDevice(nav->device);
+	int rc = PHD_OK;
+	if (stage == PHD_STAGE_PRUNED) {
+		rc = fetch_map(nav, nav->h_sel[SEL_OUT], particle, ncomp);
+	}
+	else if (stage == PHD_STAGE_PREDICTED) {
+		int n = 0;
+		rc = fetch_map(nav, nav->h_sel[SEL_IN], particle, &n);
+		if (rc) return rc;
+		int nb = 0;
+		HC(hipMemcpy(&nb, nav->d_born_count + particle, 4, hipMemcpyDeviceToHost));
+		std::vector<double> bm((size_t) std::max(nb, 1) * 3);
+		if (nb > 0) HC(hipMemcpy(bm.data(), nav->d_born_mean + (size_t) particle * nav->Mcap * 3, (size_t) nb * 3 * 8, hipMemcpyDeviceToHost));
+		nav->h_mw.resize(n + nb); nav->h_mm.resize((size_t) (n + nb) * 3); nav->h_mc.resize((size_t) (n + nb) * 9);
+		for (int i = 0; i < nb; i++) {
+			nav->h_mw[n + i] = nav->prm.birth_weight;
+			for (int k = 0; k < 3; k++) nav->h_mm[(size_t) (n + i) * 3 + k] = bm[i * 3 + k];
+			for (int k = 0; k < 9; k++) nav->h_mc[(size_t) (n + i) * 9 + k] = nav->prm.birth_covariance[k];
+		}
+		*ncomp = n + nb;
+	}
+	else if (stage == PHD_STAGE_CORRECTED) {
+		int ne = 0;
+		HC(hipMemcpy(&ne, nav->d_emit_count + particle, 4, hipMemcpyDeviceToHost));
+		size_t eb = (size_t) particle * nav->ecap;
+		std::vector<double> rec((size_t) std::max(ne, 1) * 9);
+		nav->h_mw.resize(std::max(ne, 1)); nav->h_mm.resize((size_t) std::max(ne, 1) * 3); nav->h_mc.resize((size_t) std::max(ne, 1) * 9);
+		if (ne > 0) {
+			HC(hipMemcpy(nav->h_mw.data(), nav->d_emit_w + eb, (size_t) ne * 8, hipMemcpyDeviceToHost));
+			HC(hipMemcpy(rec.data(), nav->d_emit_rec + eb * 9, (size_t) ne * 9 * 8, hipMemcpyDeviceToHost));
+		}
+		for (int c = 0; c < ne; c++) {
+			const double* r = &rec[(size_t) c * 9];
+			for (int k = 0; k < 3; k++) nav->h_mm[(size_t) c * 3 + k] = r[k];
+			double* C = &nav->h_mc[(size_t) c * 9];
+			C[0] = r[3]; C[1] = r[4]; C[2] = r[5]; C[3] = r[4]; C[4] = r[6]; C[5] = r[7]; C[6] = r[5]; C[7] = r[7]; C[8] = r[8];
+		}
+		*ncomp = ne;
+	}
+	else {
+		return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_stage_map: unknown stage");
+	}
+	if (rc) return rc;
+	if (w) *w = nav->h_mw.data();
+	if (mean3) *mean3 = nav->h_mm.data();
+	if (cov9) *cov9 = nav->h_mc.data();
+	return PHD_OK;
+}
+
+const double* phd_stage_alpha(phd_navigator* nav, int* length)
+{
+	if (!nav || !nav->stage_valid) return nullptr;
+	nav->h_alpha.resize(std::max(nav->P, 1));
+	if (hipMemcpy(nav->h_alpha.data(), nav->d_alpha, (size_t) nav->P * 8, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+	if (length) *length = nav->P;
+	return nav->h_alpha.data();
+}
+
+const double* phd_stage_setloglik(phd_navigator* nav, int* length)
+{
+	if (!nav || !nav->stage_valid) return nullptr;
+	nav->h_setll.resize(std::max(nav->P, 1));
+	if (hipMemcpy(nav->h_setll.data(), nav->d_setll, (size_t) nav->P * 8, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+	if (length) *length = nav->P;
+	return nav->h_setll.data();
+}
+
+static int ensure_gw(phd_navigator* nav, int n)
+{
+	if (n <= nav->gwcap) return PHD_OK;
+	hipFree(nav->d_gw);
+	nav->d_gw = nullptr;
+	hipFree(nav->d_plan);
+	nav->d_plan = nullptr;
+	HC(hipMalloc((void**) &nav->d_gw, (size_t) n * 8));
+	HC(hipMalloc((void**) &nav->d_plan, (size_t) n * 4));
+	nav->gwcap = n;
+	return PHD_OK;
+}
+
+int phd_resample(phd_navigator* nav, const double* weights, int nparticles, double u_resample, int32_t* sources,
+                 int32_t* best_particle)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nparticles < 1 || !weights || !sources) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_resample: bad arguments");
+	hipSetDevice(nav->device);
+	int rc = ensure_gw(nav, nparticles);
+	if (rc) return rc;
+	HC(hipStreamSynchronize(nav->stream));
+	HC(hipMemcpy(nav->d_gw, weights, (size_t) nparticles * 8, hipMemcpyHostToDevice));
+	StepBufs b = make_bufs(nav);
+	int* d_src2 = nullptr;
+	HC(hipMalloc((void**) &d_src2, (size_t) nparticles * 4 + 8));
+	hipLaunchKernelGGL(k_normalise_resample, dim3(1), dim3(1024), 0, nav->stream, b, nav->d_gw, nparticles, nav->dp.min_eff,
+	                   u_resample, 1, 1, d_src2 + 2, d_src2);
+	hipError_t e = hipStreamSynchronize(nav->stream);
+	int info[2] = {0, 0};
+	if (e == hipSuccess) e = hipMemcpy(sources, d_src2 + 2, (size_t) nparticles * 4, hipMemcpyDeviceToHost);
+	if (e == hipSuccess) e = hipMemcpy(info, d_src2, 8, hipMemcpyDeviceToHost);
+	hipFree(d_src2);
+	if (e != hipSuccess) return nav->fail(PHD_ERR_DEVICE, hipGetErrorString(e));
+	if (best_particle) *best_particle = info[0];
+	return PHD_OK;
+}
+
+int phd_particle_depleted(phd_navigator* nav, const double* weights, int nparticles, uint8_t* depleted)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nparticles < 1 || !weights || !depleted) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_particle_depleted: bad arguments");
+	hipSetDevice(nav->device);
+	int rc = ensure_gw(nav, nparticles);
+	if (rc) return rc;
+	HC(hipStreamSynchronize(nav->stream));
+	HC(hipMemcpy(nav->d_gw, weights, (size_t) nparticles * 8, hipMemcpyHostToDevice));
+	StepBufs b = make_bufs(nav);
+	int* d_tmp = nullptr;
+	HC(hipMalloc((void**) &d_tmp, (size_t) nparticles * 4 + 8));
+	hipLaunchKernelGGL(k_normalise_resample, dim3(1), dim3(1024), 0, nav->stream, b, nav->d_gw, nparticles, nav->dp.min_eff,
+	                   0.5, 0, 1, d_tmp + 2, d_tmp);
+	hipError_t e = hipStreamSynchronize(nav->stream);
+	int info[2] = {0, 0};
+	if (e == hipSuccess) e = hipMemcpy(info, d_tmp, 8, hipMemcpyDeviceToHost);
+	hipFree(d_tmp);
+	if (e != hipSuccess) return nav->fail(PHD_ERR_DEVICE, hipGetErrorString(e));
+	*depleted = info[1] ? 1 : 0;
+	return PHD_OK;
+}
+
+void* phd_stream(phd_navigator* nav) { return nav ? (void*) nav->stream : nullptr; }
+
+int phd_last_timings(phd_navigator* nav, const char*** names, const double** ms)
+{
+	if (!nav) return 0;
+	hipSetDevice(nav->device);
+	hipStreamSynchronize(nav->stream);
+	nav->tnames.clear();
+	nav->tms.clear();
+	for (Timer& t : nav->timers) {
+		if (!t.used) continue;
+		float f = 0;
+		if (hipEventElapsedTime(&f, t.t0, t.t1) == hipSuccess) {
+			nav->tnames.push_back(t.name);
+			nav->tms.push_back((double) f);
+		}
+	}
+	if (names) *names = nav->tnames.data();
+	if (ms) *ms = nav->tms.data();
+	return (int) nav->tnames.size();
+}
+
+// ---- multi-GPU ----------------------------------------------------------------------------------
+// Particles are sharded contiguously: rank r owns global slots [r * P, (r + 1) * P). One step is
+//   phd_step_local_async                      predict / correct / prune / reweight of the shard
+//   <all-gather of phd_device_local_weights into phd_device_global_weights, RCCL, by the host>
+//   phd_step_global_async                     normalise + BestParticle + depletion test + systematic
+//                                             resampling over ALL particles, identical on every rank
+//   phd_migration_plan                        (host) who sends which particle to whom
+//   phd_migration_pack_async, <all-to-all of the send/recv buffers>, phd_migration_unpack_async
+int phd_step_local_async(phd_navigator* nav, uint8_t onlymapping)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->P < 1) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step_local: no particles");
+	hipSetDevice(nav->device);
+	StepBufs b = make_bufs(nav);
+	return launch_map(nav, b, !onlymapping);
+}
+
+void* phd_device_local_weights(phd_navigator* nav)
+{
+	if (!nav) return nullptr;
+	hipSetDevice(nav->device);
+	// un-normalised weights written by the local step live in the OUT bank of the current roles
+	if (sync_state(nav)) return nullptr;
+	return nav->bank[nav->h_sel[SEL_OUT]].weights;
+}
+
+void* phd_device_global_weights(phd_navigator* nav, int world_particles)
+{
+	if (!nav || world_particles < 1) return nullptr;
+	hipSetDevice(nav->device);
+	if (ensure_gw(nav, world_particles)) return nullptr;
+	return nav->d_gw;
+}
+
+int phd_step_global_async(phd_navigator* nav, int rank, int world_size, double u_resample)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (world_size < 1 || rank < 0 || rank >= world_size) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step_global: bad rank/world");
+	hipSetDevice(nav->device);
+	const int Pg = nav->P * world_size;
+	nav->last_world_particles = Pg;
+	int rc = ensure_gw(nav, Pg);
+	if (rc) return rc;
+	StepBufs b = make_bufs(nav);
+	timer_begin(nav, T_NR);
+	hipLaunchKernelGGL(k_normalise_resample, dim3(1), dim3(1024), 0, nav->stream, b, nav->d_gw, Pg, nav->dp.min_eff,
+	                   u_resample, 0, 0, nav->d_plan, nav->d_info);
+	timer_end(nav, T_NR);
+	HC(hipGetLastError());
+	hipLaunchKernelGGL(k_scatter_weights, dim3((nav->P + 255) / 256), dim3(256), 0, nav->stream, b, nav->d_gw, rank * nav->P);
+	HC(hipGetLastError());
+	return PHD_OK;
+}
+
+int phd_migration_plan(phd_navigator* nav, int rank, int world_size, int32_t* send_counts, int32_t* recv_counts)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (world_size < 1 || rank < 0 || rank >= world_size || !send_counts || !recv_counts) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_plan: bad arguments");
+	hipSetDevice(nav->device);
+	int rc = sync_state(nav);
+	if (rc) return rc;
+	const int Pl = nav->P, Pg = Pl * world_size, first = rank * Pl;
+	for (int r = 0; r < world_size; r++) send_counts[r] = recv_counts[r] = 0;
+	nav->nsend = nav->nrecv = 0;
+	nav->h_plan_send.clear();
+	nav->h_plan_recv.assign(Pl, 0);
+	std::vector<int> gsrc(Pg);
+	HC(hipMemcpy(gsrc.data(), nav->d_plan, (size_t) Pg * 4, hipMemcpyDeviceToHost));
+	nav->h_src.assign(gsrc.begin() + first, gsrc.begin() + first + Pl);   // global source of each local slot
+	if (!nav->h_info[1]) {
+		for (int i = 0; i < Pl; i++) nav->h_plan_recv[i] = i;
+		return PHD_OK;
+	}
+	// what I send: every destination slot g on another rank whose source I own, ordered by (dest rank, g)
+	for (int r = 0; r < world_size; r++) {
+		if (r == rank) continue;
+		for (int g = r * Pl; g < (r + 1) * Pl; g++) {
+			int s = gsrc[g];
+			if (s >= first && s < first + Pl) {
+				nav->h_plan_send.push_back(s - first);
+				send_counts[r]++;
+			}
+		}
+	}
+	// what I receive: my slots whose source is remote, ordered by (source rank, slot) — the sender's order
+	int slot = 0;
+	std::vector<int> code(Pl);
+	for (int i = 0; i < Pl; i++) {
+		int s = gsrc[first + i];
+		if (s >= first && s < first + Pl) code[i] = s - first;
+	}
+	for (int r = 0; r < world_size; r++) {
+		if (r == rank) continue;
+		for (int i = 0; i < Pl; i++) {
+			int s = gsrc[first + i];
+			if (s >= r * Pl && s < (r + 1) * Pl) {
+				code[i] = -(slot + 1);
+				slot++;
+				recv_counts[r]++;
+			}
+		}
+	}
+	nav->h_plan_recv = code;
+	nav->nsend = (int) nav->h_plan_send.size();
+	nav->nrecv = slot;
+	size_t rec = (size_t) 8 + (size_t) 10 * nav->cap;
+	int need = std::max(nav->nsend, nav->nrecv);
+	if (need > nav->migcap) {
+		hipFree(nav->d_send); hipFree(nav->d_recv);
+		nav->d_send = nav->d_recv = nullptr;
+		HC(hipMalloc((void**) &nav->d_send, (size_t) need * rec * 8));
+		HC(hipMalloc((void**) &nav->d_recv, (size_t) need * rec * 8));
+		nav->migcap = need;
+	}
+	return PHD_OK;
+}
+
+void* phd_migration_send_buffer(phd_navigator* nav, int64_t* bytes_per_particle)
+{
+	if (!nav) return nullptr;
+	if (bytes_per_particle) *bytes_per_particle = (int64_t) ((size_t) 8 + (size_t) 10 * nav->cap) * 8;
+	return nav->d_send;
+}
+
+void* phd_migration_recv_buffer(phd_navigator* nav) { return nav ? nav->d_recv : nullptr; }
+
+int phd_migration_pack_async(phd_navigator* nav)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	hipSetDevice(nav->device);
+	if (nav->nsend == 0) return PHD_OK;
+	// the plan ints live behind the global source vector in d_plan? no: a dedicated upload area
+	int* d_list = nullptr;
+	HC(hipMalloc((void**) &d_list, (size_t) nav->nsend * 4));
+	HC(hipMemcpy(d_list, nav->h_plan_send.data(), (size_t) nav->nsend * 4, hipMemcpyHostToDevice));
+	StepBufs b = make_bufs(nav);
+	hipLaunchKernelGGL(k_pack_particles, dim3(nav->nsend), dim3(256), 0, nav->stream, b, d_list, nav->d_send);
+	hipError_t e = hipStreamSynchronize(nav->stream);
+	hipFree(d_list);
+	if (e != hipSuccess) return nav->fail(PHD_ERR_DEVICE, hipGetErrorString(e));
+	return PHD_OK;
+}
+
+int phd_migration_unpack_async(phd_navigator* nav)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	hipSetDevice(nav->device);
+	StepBufs b = make_bufs(nav);
+	int* sel_next = nav->d_sel + (nav->parity ^ 1) * 4;
+	if (!nav->h_info[1]) {
+		// no resampling: only rotate the bank roles
+		timer_begin(nav, T_GR);
+		hipLaunchKernelGGL(k_gather_rotate, dim3(1), dim3(256), 0, nav->stream, b, nav->d_src, nav->d_info, 0, sel_next, nav->frozen ? 1 : 0);
+		timer_end(nav, T_GR);
+		HC(hipGetLastError());
+	}
+	else {
+		int* d_code = nullptr;
+		HC(hipMalloc((void**) &d_code, (size_t) nav->P * 4));
+		HC(hipMemcpy(d_code, nav->h_plan_recv.data(), (size_t) nav->P * 4, hipMemcpyHostToDevice));
+		timer_begin(nav, T_GR);
+		hipLaunchKernelGGL(k_unpack_gather, dim3(nav->P), dim3(256), 0, nav->stream, b, d_code, nav->d_recv,
+		                   1.0 / (double) nav->last_world_particles, sel_next, nav->frozen ? 1 : 0);
+		timer_end(nav, T_GR);
+		hipError_t e = hipStreamSynchronize(nav->stream);
+		hipFree(d_code);
+		if (e != hipSuccess) return nav->fail(PHD_ERR_DEVICE, hipGetErrorString(e));
+	}
+	nav->parity ^= 1;
+	nav->stage_valid = false;
+	return PHD_OK;
+}
+
+}  // extern "C"

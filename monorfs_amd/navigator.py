@@ -1,0 +1,245 @@
+"""Python host-side mirror of the reference's solver interface for the PHD path.
+
+`PHDNavigator` here keeps the member names of
+    class PHDNavigator<MeasurerT, PoseT, MeasurementT> : Navigator<...>
+    (mono-rfs-lib/SLAM/Navigators/PHDNavigator.cs:52-983, Navigator.cs:47-396)
+and forwards every one of them to libphdhip.so through the C-ABI of include/phdhip.h — it is what
+tests/ and bench.py drive; the C++ twin for native hosts is monorfs_amd/host/PHDNavigator.hpp and the
+C# adapter a maintainer would add is bindings/csharp/HipPHDNavigator.cs.
+
+No compute happens in this file: it marshals arrays and raises on a non-zero status."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .abi import (PHD_ERR_ASSOCIATION, PHD_STAGE_CORRECTED, PHD_STAGE_PREDICTED, PHD_STAGE_PRUNED, PhdParams,
+                  prm3d_defaults)
+
+dp = _lib.dp
+ip = _lib.ip
+
+
+class PHDError(RuntimeError):
+    """≙ the InvalidOperationException with Data["module"] that Simulation.Update catches
+    (Simulation.cs:655-670); `module` is "association" for PHD_ERR_ASSOCIATION."""
+
+    def __init__(self, status, message):
+        super().__init__("libphdhip status %d: %s" % (status, message))
+        self.status = status
+        self.module = "association" if status == PHD_ERR_ASSOCIATION else "phdhip"
+
+
+def _ptr(a):
+    return a.ctypes.data_as(dp)
+
+
+class PHDNavigator:
+    def __init__(self, params: PhdParams = None, particlecount=1, onlymapping=False, device=0,
+                 pose=(0, 0, 0, 1, 0, 0, 0)):
+        """≙ new PHDNavigator(vehicle, particlecount, onlymapping) (PHDNavigator.cs:192-208)."""
+        self._lib = _lib.load()
+        self.params = params if params is not None else prm3d_defaults(max_particles=max(1, particlecount))
+        self._h = self._lib.phd_create(C.byref(self.params), device)
+        if not self._h:
+            raise PHDError(-1, self._lib.phd_create_error().decode())
+        self.ParticleCount = particlecount
+        self.OnlyMapping = bool(onlymapping)
+        n = 1 if onlymapping else particlecount   # :201-203
+        self.reset(np.asarray(pose, float), (np.zeros(0), np.zeros((0, 3)), np.zeros((0, 3, 3))), n)
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc):
+        if rc != 0:
+            raise PHDError(rc, self._lib.phd_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.phd_destroy(self._h)
+            self._h = None
+
+    Dispose = close   # Navigator.Dispose (Navigator.cs:395)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ state
+    def reset(self, pose, model, particlecount):
+        """≙ PHDNavigator.reset (:245-266)."""
+        w, m, c = (np.ascontiguousarray(x, np.float64) for x in model)
+        pose = np.ascontiguousarray(pose, np.float64)
+        self._check(self._lib.phd_reset(self._h, int(particlecount), _ptr(pose), _ptr(w), _ptr(m), _ptr(c), len(w)))
+
+    def CollapseParticles(self, particlecount):
+        """≙ :233-236: every particle becomes a copy of the best one."""
+        best = self.BestParticle
+        pose = self.poses()[best]
+        self.reset(pose, self.MapModel(best), particlecount)
+
+    def ResetMapModel(self):
+        """≙ :271-276."""
+        empty = (np.zeros(0), np.zeros((0, 3)), np.zeros((0, 3, 3)))
+        poses, weights = self.poses().copy(), self.VehicleWeights.copy()
+        for i in range(self.particle_count):
+            self.set_map(i, empty)
+        self.set_poses(poses)
+        self.set_weights(weights)
+
+    @property
+    def particle_count(self):
+        return self._lib.phd_particle_count(self._h)
+
+    def set_poses(self, poses):
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+        self._check(self._lib.phd_set_poses(self._h, _ptr(poses), len(poses)))
+
+    def set_weights(self, weights):
+        weights = np.ascontiguousarray(weights, np.float64)
+        self._check(self._lib.phd_set_weights(self._h, _ptr(weights), len(weights)))
+
+    def set_map(self, particle, model):
+        w, m, c = (np.ascontiguousarray(x, np.float64) for x in model)
+        self._check(self._lib.phd_set_map(self._h, int(particle), _ptr(w), _ptr(m), _ptr(c), len(w)))
+
+    def upload_state(self, planes, counts, poses, weights):
+        """planes: [10][P][stride] float64 in the device layout (w, mean xyz, cov xx xy xz yy yz zz)."""
+        planes = np.ascontiguousarray(planes, np.float64)
+        counts = np.ascontiguousarray(counts, np.int32)
+        poses = np.ascontiguousarray(poses, np.float64)
+        weights = np.ascontiguousarray(weights, np.float64)
+        _, P, stride = planes.shape
+        self._check(self._lib.phd_upload_state_soa(self._h, P, stride, _ptr(planes), counts.ctypes.data_as(ip),
+                                                   _ptr(poses), _ptr(weights)))
+
+    def download_state(self, stride):
+        P = self.particle_count
+        planes = np.zeros((10, P, stride))
+        counts = np.zeros(P, np.int32)
+        poses = np.zeros((P, 7))
+        weights = np.zeros(P)
+        self._check(self._lib.phd_download_state_soa(self._h, stride, _ptr(planes), counts.ctypes.data_as(ip),
+                                                     _ptr(poses), _ptr(weights)))
+        return planes, counts, poses, weights
+
+    def poses(self):
+        n = C.c_int32(0)
+        ptr = self._lib.phd_poses(self._h, C.byref(n))
+        if not ptr:
+            raise PHDError(-1, self._lib.phd_last_error(self._h).decode())
+        return np.ctypeslib.as_array(ptr, shape=(n.value,)).reshape(-1, 7).copy()
+
+    # ------------------------------------------------------------------ Navigator interface
+    def Update(self, time, poses):
+        """≙ PHDNavigator.Update (:295-314). The motion model and its RNG stay on the host
+        (TrackVehicle.UpdateNoisy): the caller hands over the propagated particle poses."""
+        self.set_poses(poses)
+
+    def SlamUpdate(self, time, measurements, u_resample=0.5):
+        """≙ PHDNavigator.SlamUpdate (:323-362)."""
+        z = np.ascontiguousarray(measurements, np.float64).reshape(-1, 3)
+        self._check(self._lib.phd_slam_update(self._h, _ptr(z), len(z), int(self.OnlyMapping), float(u_resample)))
+
+    @property
+    def VehicleWeights(self):
+        n = C.c_int32(0)
+        ptr = self._lib.phd_weights(self._h, C.byref(n))
+        if not ptr:
+            raise PHDError(-1, self._lib.phd_last_error(self._h).decode())
+        return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+
+    @property
+    def BestParticle(self):
+        return self._lib.phd_best_particle(self._h)
+
+    def _map_from(self, fn, *args):
+        n = C.c_int32(0)
+        w, m, c = dp(), dp(), dp()
+        self._check(fn(self._h, *args, C.byref(n), C.byref(w), C.byref(m), C.byref(c)))
+        k = n.value
+        if k == 0:
+            return np.zeros(0), np.zeros((0, 3)), np.zeros((0, 3, 3))
+        return (np.ctypeslib.as_array(w, shape=(k,)).copy(), np.ctypeslib.as_array(m, shape=(k * 3,)).reshape(k, 3).copy(),
+                np.ctypeslib.as_array(c, shape=(k * 9,)).reshape(k, 3, 3).copy())
+
+    def MapModel(self, particle):
+        """≙ MapModels[particle] (:134)."""
+        return self._map_from(self._lib.phd_map, int(particle))
+
+    @property
+    def BestMapModel(self):
+        """≙ :155-161."""
+        return self.MapModel(self.BestParticle)
+
+    @property
+    def BestEstimate(self):
+        """≙ :144-150 — the pose of the best particle."""
+        return self.poses()[self.BestParticle]
+
+    def resample_sources(self):
+        n = C.c_int32(0)
+        r = C.c_uint8(0)
+        ptr = self._lib.phd_resample_sources(self._h, C.byref(n), C.byref(r))
+        return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy(), bool(r.value)
+
+    def ResampleParticles(self, weights, u):
+        """≙ :724-760 on caller-supplied weights; returns (sources, best slot)."""
+        weights = np.ascontiguousarray(weights, np.float64)
+        src = np.zeros(len(weights), np.int32)
+        best = C.c_int32(0)
+        self._check(self._lib.phd_resample(self._h, _ptr(weights), len(weights), float(u), src.ctypes.data_as(ip), C.byref(best)))
+        return src, best.value
+
+    def ParticleDepleted(self, weights):
+        """≙ :768-777."""
+        weights = np.ascontiguousarray(weights, np.float64)
+        d = C.c_uint8(0)
+        self._check(self._lib.phd_particle_depleted(self._h, _ptr(weights), len(weights), C.byref(d)))
+        return bool(d.value)
+
+    # ------------------------------------------------------------------ stage-level (unit KAT surface)
+    def run_stages(self, measurements, with_alpha=True):
+        z = np.ascontiguousarray(measurements, np.float64).reshape(-1, 3)
+        self._check(self._lib.phd_stage_run(self._h, _ptr(z), len(z), int(with_alpha)))
+
+    def PredictConditional(self, particle=0):
+        return self._map_from(self._lib.phd_stage_map, PHD_STAGE_PREDICTED, int(particle))
+
+    def CorrectConditional(self, particle=0):
+        """Corrected components with weight >= MinWeight (the rest cannot survive PruneModel), unsorted."""
+        return self._map_from(self._lib.phd_stage_map, PHD_STAGE_CORRECTED, int(particle))
+
+    def PruneModel(self, particle=0):
+        return self._map_from(self._lib.phd_stage_map, PHD_STAGE_PRUNED, int(particle))
+
+    def WeightAlpha(self):
+        n = C.c_int32(0)
+        ptr = self._lib.phd_stage_alpha(self._h, C.byref(n))
+        return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+
+    def SetLogLikelihood(self):
+        n = C.c_int32(0)
+        ptr = self._lib.phd_stage_setloglik(self._h, C.byref(n))
+        return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
+
+    # ------------------------------------------------------------------ benchmark surface
+    def set_measurements(self, measurements):
+        z = np.ascontiguousarray(measurements, np.float64).reshape(-1, 3)
+        self._check(self._lib.phd_set_measurements(self._h, _ptr(z), len(z)))
+
+    def step_async(self, u_resample=0.5):
+        self._check(self._lib.phd_step_async(self._h, int(self.OnlyMapping), float(u_resample)))
+
+    def sync(self):
+        self._check(self._lib.phd_sync(self._h))
+
+    def set_frozen(self, frozen):
+        self._check(self._lib.phd_set_frozen(self._h, int(bool(frozen))))
+
+    def last_timings(self):
+        names = C.POINTER(C.c_char_p)()
+        ms = dp()
+        n = self._lib.phd_last_timings(self._h, C.byref(names), C.byref(ms))
+        return {names[i].decode(): ms[i] for i in range(n)}

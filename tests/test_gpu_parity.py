@@ -1,0 +1,221 @@
+"""Parity of the HIP path (through the C-ABI of libphdhip.so) with the CPU oracle, on seeded synthetic
+frames at sizes the oracle finishes in seconds. FP64 everywhere; tolerances as stated in SURVEY §8d:
+  predict / correct : rel 1e-9 + abs 1e-12        prune / merge : rel 1e-7 (order-dependent sums)
+  particle weights  : rel 1e-6                    resample indices, BestParticle : exact
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import orc
+from monorfs_amd.abi import PHD_GATE_DISABLED, PHD_GATE_EUCLIDEAN, prm3d_defaults
+from monorfs_amd.synth import Frame
+
+
+@pytest.fixture(scope="module")
+def nav_mod():
+    from monorfs_amd import navigator
+    return navigator
+
+
+def make_nav(navigator, frame, maxq=600, **over):
+    p = prm3d_defaults(max_particles=frame.P, max_components=max(maxq, frame.C), max_measurements=max(frame.M, 1))
+    p.max_quantity = maxq
+    for k, v in over.items():
+        setattr(p, k, v)
+    nav = navigator.PHDNavigator(p, particlecount=frame.P)
+    nav.upload_state(frame.planes(), frame.counts, frame.poses, frame.weights)
+    return nav, p
+
+
+def close(a, b, rtol, atol=1e-12):
+    return np.allclose(a, b, rtol=rtol, atol=atol)
+
+
+def assert_mix_close(got, exp, rtol, what):
+    gw, gm, gc = got
+    ew, em, ec = exp
+    assert len(gw) == len(ew), "%s: %d components, oracle has %d" % (what, len(gw), len(ew))
+    assert close(gw, ew, rtol), "%s: weights differ (max rel %g)" % (what, np.max(np.abs(gw - ew) / np.maximum(np.abs(ew), 1e-300)))
+    assert close(gm, em, rtol, 1e-11), "%s: means differ" % what
+    # the device keeps the upper triangle of the (un-symmetrised) reference covariance
+    iu = np.triu_indices(3)
+    assert close(gc[:, iu[0], iu[1]], ec[:, iu[0], iu[1]], rtol, 1e-13), "%s: covariances differ" % what
+
+
+def match_unordered(got, exp, rtol):
+    """every oracle component is found exactly once in the device set"""
+    gw, gm, gc = got
+    ew, em, ec = exp
+    assert len(gw) == len(ew), "%d emitted, oracle keeps %d" % (len(gw), len(ew))
+    key_g = np.concatenate([gw[:, None], gm], axis=1)
+    key_e = np.concatenate([ew[:, None], em], axis=1)
+    used = np.zeros(len(gw), bool)
+    iu = np.triu_indices(3)
+    for i in range(len(ew)):
+        d = np.max(np.abs(key_g - key_e[i]) / (np.abs(key_e[i]) + 1e-9), axis=1)
+        d[used] = np.inf
+        j = int(np.argmin(d))
+        assert d[j] < 1e-8, "oracle component %d (w=%g) has no device twin (best %g)" % (i, ew[i], d[j])
+        assert close(gc[j][iu], ec[i][iu], rtol, 1e-13)
+        used[j] = True
+
+
+CASES = [
+    # P, C, M, seed, profile, overrides
+    (6, 40, 12, 11, "steady", {}),
+    (5, 130, 32, 12, "survey", {}),
+    (4, 300, 70, 13, "steady", {}),                      # two measurement blocks, two component tiles
+    (3, 64, 130, 14, "steady", {}),                      # four measurement blocks
+    (4, 90, 24, 15, "steady", {"gate_metric": PHD_GATE_EUCLIDEAN}),
+    (3, 50, 10, 16, "steady", {"gate_metric": PHD_GATE_DISABLED}),
+    (3, 0, 9, 17, "steady", {}),                         # empty map: every measurement is born
+    (3, 33, 0, 18, "steady", {}),                        # no measurements
+]
+
+
+@pytest.mark.parametrize("P,C,M,seed,profile,over", CASES)
+def test_stage_parity(nav_mod, P, C, M, seed, profile, over):
+    f = Frame(P, C, M, seed, weight_profile=profile) if C > 0 else Frame(P, 1, M, seed, weight_profile="survey")
+    if C == 0:
+        f.counts[:] = 0
+    nav, p = make_nav(nav_mod, f, **over)
+    nav.run_stages(f.z, with_alpha=True)
+    alpha = nav.WeightAlpha()
+    setll = nav.SetLogLikelihood()
+    for i in range(P):
+        prior = f.map(i) if C > 0 else (np.zeros(0), np.zeros((0, 3)), np.zeros((0, 3, 3)))
+        pred = orc.predict(p, f.poses[i], f.z, prior)
+        assert_mix_close(nav.PredictConditional(i), pred, 1e-9, "predict[%d]" % i)
+        cor = orc.correct(p, f.poses[i], f.z, pred)
+        keep = ~(cor[0] < p.min_weight)
+        match_unordered(nav.CorrectConditional(i), tuple(x[keep] for x in cor), 1e-9)
+        pr = orc.prune(p, cor)
+        assert_mix_close(nav.PruneModel(i), pr, 1e-7, "prune[%d]" % i)
+        a, sll = orc.weight_alpha(p, f.poses[i], f.z, pred, pr)
+        assert np.isclose(setll[i], sll, rtol=1e-9, atol=1e-9), "set log-likelihood[%d]: %r vs %r" % (i, setll[i], sll)
+        assert np.isclose(alpha[i], a, rtol=1e-6, atol=0), "alpha[%d]: %r vs %r" % (i, alpha[i], a)
+    nav.close()
+
+
+def test_merge_heavy_prune(nav_mod):
+    # many near-duplicate components so that the greedy merge absorbs most of them
+    rng = np.random.default_rng(3)
+    f = Frame(4, 200, 16, 21, weight_profile="steady")
+    f.mean = np.array(f.mean)
+    centres = f.mean[:, :20]
+    f.mean[:, :] = np.repeat(centres, 10, axis=1) + rng.normal(size=f.mean.shape) * 2e-3
+    nav, p = make_nav(nav_mod, f)
+    nav.run_stages(f.z, with_alpha=False)
+    for i in range(f.P):
+        pred = orc.predict(p, f.poses[i], f.z, f.map(i))
+        pr = orc.prune(p, orc.correct(p, f.poses[i], f.z, pred))
+        got = nav.PruneModel(i)
+        assert len(pr[0]) < 150
+        assert_mix_close(got, pr, 1e-7, "prune[%d]" % i)
+    nav.close()
+
+
+def test_max_quantity_cap(nav_mod):
+    f = Frame(3, 256, 32, 22, weight_profile="survey")
+    nav, p = make_nav(nav_mod, f, maxq=100)
+    nav.run_stages(f.z, with_alpha=True)
+    for i in range(f.P):
+        pred = orc.predict(p, f.poses[i], f.z, f.map(i))
+        pr = orc.prune(p, orc.correct(p, f.poses[i], f.z, pred))
+        assert len(pr[0]) <= 100
+        assert_mix_close(nav.PruneModel(i), pr, 1e-7, "prune[%d]" % i)
+    nav.close()
+
+
+@pytest.mark.parametrize("P,C,M,seed", [(16, 48, 12, 31), (64, 100, 24, 32)])
+def test_slam_update_sequence(nav_mod, P, C, M, seed):
+    """three full steps (predict, correct, prune, reweight, normalise, resample) against the oracle"""
+    f = Frame(P, C, M, seed, weight_profile="steady")
+    nav, p = make_nav(nav_mod, f)
+    st = orc.State(P, 700)
+    st.poses[:] = f.poses
+    st.w[:, :C], st.mean[:, :C], st.cov[:, :C], st.n[:] = f.w, f.mean, f.cov, C
+    rng = np.random.default_rng(seed)
+    nres = 0
+    for step in range(3):
+        z = f.z + rng.normal(size=f.z.shape) * np.sqrt([2.0, 2.0, 1e-3]) * 0.3
+        u = float(rng.uniform(0.05, 0.95))
+        best, src, res, _ = orc.slam_update(p, st, z, u=u, threads=4)
+        nav.SlamUpdate(None, z, u_resample=u)
+        gsrc, gres = nav.resample_sources()
+        assert gres == res, "step %d: resampled %r vs oracle %r" % (step, gres, res)
+        assert np.array_equal(gsrc, src), "step %d: resample sources differ" % step
+        assert nav.BestParticle == best
+        assert close(nav.VehicleWeights, st.weights, 1e-6, 1e-300), "step %d: particle weights" % step
+        assert close(nav.poses(), st.poses, 1e-15)
+        for i in (0, P // 2, P - 1):
+            assert_mix_close(nav.MapModel(i), st.map(i), 1e-7, "step %d map[%d]" % (step, i))
+        nres += res
+    assert nres > 0, "the sequence never resampled: the gather path was not exercised"
+    nav.close()
+
+
+def test_only_mapping(nav_mod):
+    f = Frame(1, 60, 14, 41, weight_profile="steady")
+    p = prm3d_defaults(max_particles=1, max_components=600, max_measurements=f.M)
+    nav = nav_mod.PHDNavigator(p, particlecount=20, onlymapping=True)
+    assert nav.particle_count == 1
+    nav.reset(f.poses[0], f.map(0), 1)
+    st = orc.State(1, 700)
+    st.poses[:] = f.poses
+    st.w[:, :f.C], st.mean[:, :f.C], st.cov[:, :f.C], st.n[:] = f.w, f.mean, f.cov, f.C
+    for _ in range(2):
+        orc.slam_update(p, st, f.z, onlymapping=True)
+        nav.SlamUpdate(None, f.z)
+    assert_mix_close(nav.BestMapModel, st.map(0), 1e-7, "mapping")
+    assert np.allclose(nav.VehicleWeights, [1.0])
+    nav.close()
+
+
+def test_reset_replicates_and_collapse(nav_mod):
+    f = Frame(1, 30, 8, 42, weight_profile="steady")
+    p = prm3d_defaults(max_particles=9, max_components=600, max_measurements=8)
+    nav = nav_mod.PHDNavigator(p, particlecount=9)
+    nav.reset(f.poses[0], f.map(0), 9)
+    assert np.allclose(nav.VehicleWeights, 1.0 / 9)
+    for i in (0, 4, 8):
+        assert_mix_close(nav.MapModel(i), f.map(0), 1e-15, "reset[%d]" % i)
+    assert np.allclose(nav.poses(), np.repeat((f.poses[0] if True else None)[None], 9, 0))
+    nav.CollapseParticles(3)
+    assert nav.particle_count == 3
+    assert_mix_close(nav.MapModel(2), f.map(0), 1e-15, "collapse")
+    nav.close()
+
+
+def test_resample_bit_exact(nav_mod):
+    p = prm3d_defaults(max_particles=4, max_components=600, max_measurements=8)
+    nav = nav_mod.PHDNavigator(p, particlecount=4)
+    rng = np.random.default_rng(5)
+    for P in (5, 257, 2048):
+        w = rng.random(P) ** 8
+        w /= w.sum()
+        for u in (1e-12, 0.25, 0.5, 0.999999):
+            src, best = nav.ResampleParticles(w, u)
+            osrc, obest = orc.resample(w, u)
+            assert np.array_equal(src, osrc) and best == obest
+        assert nav.ParticleDepleted(w) == orc.particle_depleted(p, w)
+    kat = [0.11, 0.28, 0.31, 0.01, 0.29]   # SimulationTest.cs:225-270
+    for u in np.linspace(0.001, 0.999, 97):
+        src, best = nav.ResampleParticles(kat, float(u))
+        assert src[best] == 2 and {1, 2, 4} <= set(src.tolist())
+    nav.close()
+
+
+def test_capacity_error_is_loud(nav_mod):
+    f = Frame(2, 200, 32, 51, weight_profile="survey")
+    p = prm3d_defaults(max_particles=2, max_components=600, max_measurements=32)
+    p.emit_capacity = 64
+    p.max_quantity = 64
+    nav = nav_mod.PHDNavigator(p, particlecount=2)
+    nav.upload_state(f.planes(), f.counts, f.poses, f.weights)
+    with pytest.raises(nav_mod.PHDError) as e:
+        nav.SlamUpdate(None, f.z)
+    assert e.value.status == 2
+    nav.close()
