@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""PHD-updates/s benchmark of the RB-PHD-SLAM inner loop on MI355X (BASELINE.json's metric).
+
+A step = one PHDNavigator.SlamUpdate (predict, correct, prune, reweight, normalise, depletion test,
+resample + particle copy when depleted) over one synthetic frame; the state and the measurements are
+resident in HBM before the timed region. N = 1 runs BASELINE config B (2048 particles x 512
+components x 64 measurements); N > 1 keeps 2048 particles per GPU (weak scaling, config C8 at N = 8):
+one process per GPU, RCCL all-gather of the particle weights, all-to-all of migrating particles.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="B", help="BASELINE config name: A, B, S (per-GPU shard of C8 = B)")
+    ap.add_argument("--weights", default="steady", choices=["steady", "survey"],
+                    help="prior weight profile of the synthetic frame (monorfs_amd/synth.py)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="particles in the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP events")
+    return ap.parse_args()
+
+
+class DevArray:
+    """__cuda_array_interface__ view of a device pointer owned by libphdhip (for torch.distributed)."""
+
+    def __init__(self, ptr, n, typestr="<f8"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def cpu_baseline(frame, params, sample, threads):
+    """The CPU oracle (C++ restatement of the C# algorithm) timed on the host cores, on a bounded sample of
+    the same workload. A reported baseline: it only times the checker, nothing of it is shipped."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+    P = min(sample, frame.P)
+    cap = max(700, frame.C + 128)
+
+    def state(n):
+        st = orc.State(n, cap)
+        st.poses[:] = frame.poses[:n]
+        st.w[:, :frame.C], st.mean[:, :frame.C], st.cov[:, :frame.C] = frame.w[:n], frame.mean[:n], frame.cov[:n]
+        st.n[:] = frame.C
+        return st
+
+    orc.slam_update(params, state(min(P, threads)), frame.z, u=0.5, threads=threads)   # warm-up
+    st = state(P)
+    stages = np.zeros(4)
+    t0 = time.perf_counter()
+    orc.slam_update(params, st, frame.z, u=0.5, threads=threads, stage_times=stages)
+    dt = time.perf_counter() - t0
+    return {"value": P * frame.C * frame.M / dt, "unit": "PHD updates/s", "cores": threads, "kind": "port",
+            "sample": "1 step of %d of the %d particles (C=%d, M=%d), oracle/phd_oracle.cpp with OpenMP over particles, %.2f s"
+                      % (P, frame.P, frame.C, frame.M, dt),
+            "stage_share": {k: float(v / stages.sum()) for k, v in zip(("predict", "correct", "prune", "reweight"), stages)}}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the PHD path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from monorfs_amd import navigator
+    from monorfs_amd.abi import prm3d_defaults
+    from monorfs_amd.synth import CONFIGS, Frame
+
+    P, Cc, M, seed = CONFIGS[args.config]
+    frame = Frame(P, Cc, M, seed, weight_profile=args.weights, shard=rank)   # same map + frame, own particles
+    maxq = max(600, Cc)
+    params = prm3d_defaults(max_particles=P, max_components=maxq, max_measurements=M)
+    params.max_quantity = maxq   # MaxQuantity = max(600, C)
+    nav = navigator.PHDNavigator(params, particlecount=P, device=local_rank)
+    nav.upload_state(frame.planes(), frame.counts, frame.poses, frame.weights)
+    nav.set_measurements(frame.z)
+    nav.set_frozen(True)     # steady state: every step sees the same P x C x M input
+    lib, h = nav._lib, nav._h
+
+    if world > 1:
+        Pg = P * world
+        gw = torch.as_tensor(DevArray(lib.phd_device_global_weights(h, Pg), Pg), device="cuda")
+        scounts = np.zeros(world, np.int32)
+        rcounts = np.zeros(world, np.int32)
+        ip = C.POINTER(C.c_int32)
+
+    def step(u=0.5):
+        if world == 1:
+            nav.step_async(u)
+            return
+        nav._check(lib.phd_step_local_async(h, 0))
+        lw = torch.as_tensor(DevArray(lib.phd_device_local_weights(h), P), device="cuda")   # syncs the handle's stream
+        dist.all_gather_into_tensor(gw, lw)
+        torch.cuda.current_stream().synchronize()
+        nav._check(lib.phd_step_global_async(h, rank, world, u))
+        nav._check(lib.phd_migration_plan(h, rank, world, scounts.ctypes.data_as(ip), rcounts.ctypes.data_as(ip)))
+        if True:
+            nav._check(lib.phd_migration_pack_async(h))
+            bpp = C.c_int64(0)
+            sptr = lib.phd_migration_send_buffer(h, C.byref(bpp))
+            rptr = lib.phd_migration_recv_buffer(h)
+            rec = bpp.value // 8
+            ns, nr = int(scounts.sum()), int(rcounts.sum())
+            send = torch.as_tensor(DevArray(sptr, max(ns, 1) * rec), device="cuda")[:ns * rec] if sptr else torch.empty(0, dtype=torch.float64, device="cuda")
+            recv = torch.as_tensor(DevArray(rptr, max(nr, 1) * rec), device="cuda")[:nr * rec] if rptr else torch.empty(0, dtype=torch.float64, device="cuda")
+            dist.all_to_all_single(recv, send, (rcounts * rec).tolist(), (scounts * rec).tolist())
+            torch.cuda.current_stream().synchronize()
+        nav._check(lib.phd_migration_unpack_async(h))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        nav.sync()
+
+    nav.timing_reset(False)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    nav.timing_reset(not args.no_events)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernels = nav.last_timings()
+
+    if rank == 0:
+        units = P * world * Cc * M * args.steps
+        ms = elapsed / args.steps * 1e3
+        out = {"metric": "PHD updates/sec (particles x components x measurements)", "value": units / elapsed,
+               "unit": "PHD updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic",
+               "config": {"workload": "RB-PHD-SLAM SlamUpdate, BASELINE config %s: %d particles/GPU x %d components x %d measurements, "
+                                      "PRM3D pixel-range model, prior weights '%s', state resident in HBM"
+                                      % (args.config, P, Cc, M, args.weights),
+                          "particles_per_gpu": P, "components": Cc, "measurements": M, "max_quantity": maxq,
+                          "parallelism": "particles sharded x%d" % world}}
+        if kernels:
+            dom = max(kernels, key=kernels.get)
+            alg_bytes = 160.0 * P * Cc          # 80 B/component read + 80 B written, per particle
+            achieved = alg_bytes / (kernels[dom] * 1e-3) / 1e9
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+            if os.path.exists(tfile):
+                try:
+                    traffic = json.load(open(tfile)).get(args.config, {}).get(dom)
+                except Exception:
+                    traffic = None
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernels[dom]}
+            out["kernel_ms"] = kernels
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(os.cpu_count() or 1, 16)
+            sample = args.cpu_sample or max(threads, min(P, 16 * threads))
+            out["cpu_baseline"] = cpu_baseline(frame, params, sample, threads)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    nav.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -190,9 +190,19 @@ int   phd_migration_pack_async(phd_navigator* nav);
 int   phd_migration_unpack_async(phd_navigator* nav);
 void* phd_stream(phd_navigator* nav);                               /* hipStream_t of the handle   */
 
-/* per-kernel device time of the last completed step in milliseconds (HIP events on the handle's
- * stream): names[i] -> ms[i]; returns the number of entries.                                     */
+/* Per-kernel device time in milliseconds, from HIP events recorded around every launch on the
+ * handle's stream: the mean over the launches since the last phd_timing_reset; names[i] -> ms[i];
+ * returns the number of entries. phd_timing_reset(nav, 0) switches the events off.               */
+int phd_timing_reset(phd_navigator* nav, uint8_t enabled);
 int phd_last_timings(phd_navigator* nav, const char*** names, const double** ms);
+
+/* Bulk upload / download of the whole particle set in the device layout (benchmark and tests):
+ * planes[10][nparticles][stride] = w, mean x y z, covariance xx xy xz yy yz zz; counts[nparticles];
+ * poses7[nparticles][7]; weights[nparticles]. The upload sets the particle count.               */
+int phd_upload_state_soa(phd_navigator* nav, int nparticles, int stride, const double* planes,
+                         const int32_t* counts, const double* poses7, const double* weights);
+int phd_download_state_soa(phd_navigator* nav, int stride, double* planes, int32_t* counts,
+                           double* poses7, double* weights);
 
 #ifdef __cplusplus
 }

@@ -17,10 +17,9 @@ namespace {
 
 thread_local std::string g_create_error;
 
-struct Timer {
+struct Timer {          // one record per kernel launch since the last phd_timing_reset
 	const char* name;
 	hipEvent_t  t0, t1;
-	bool        used;
 };
 
 }  // namespace
@@ -44,6 +43,7 @@ struct phd_navigator {
 	int*    d_born_count = nullptr; int* d_born_k = nullptr; double* d_born_mean = nullptr;
 	double* d_alpha = nullptr; double* d_setll = nullptr;
 	int*    d_flags = nullptr; int* d_src = nullptr; int* d_info = nullptr;
+	MurtyNodes* d_murty = nullptr;
 	double* d_gw = nullptr; int gwcap = 0;           // gathered weights of all ranks
 	double* d_stage = nullptr;                       // staging for uploads
 	// migration (multi-GPU resampling)
@@ -58,9 +58,12 @@ struct phd_navigator {
 	int  h_flags = 0;
 	bool stage_valid = false;
 
-	std::vector<Timer>       timers;
+	std::vector<Timer>       timers;    // event pool; [0, ntimers) are live records
+	size_t                   ntimers = 0;
+	bool                     timing = true;
 	std::vector<const char*> tnames;
 	std::vector<double>      tms;
+	std::vector<int>         tcounts;
 	std::string err;
 
 	int fail(int code, const std::string& what)
@@ -143,7 +146,7 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.z = nav->d_z;
 	b.emit_w = nav->d_emit_w; b.emit_idx = nav->d_emit_idx; b.emit_rec = nav->d_emit_rec; b.emit_count = nav->d_emit_count;
 	b.born_count = nav->d_born_count; b.born_k = nav->d_born_k; b.born_mean = nav->d_born_mean;
-	b.alpha = nav->d_alpha; b.setll = nav->d_setll; b.flags = nav->d_flags;
+	b.alpha = nav->d_alpha; b.setll = nav->d_setll; b.flags = nav->d_flags; b.murty = nav->d_murty;
 	return b;
 }
 
@@ -157,29 +160,27 @@ size_t lds_predict_correct(int ZB)
 
 size_t lds_prune(int ecap, int cutcap) { return (size_t) (ecap + 10 * cutcap) * 8 + (size_t) ecap * 4; }
 
+// HIP events around every kernel launch, on the stream the kernel is launched on
 void timer_begin(phd_navigator* nav, const char* name)
 {
-	for (Timer& t : nav->timers) {
-		if (t.name == name) {
-			hipEventRecord(t.t0, nav->stream);
-			t.used = true;
-			return;
-		}
+	if (!nav->timing) return;
+	if (nav->ntimers == nav->timers.size()) {
+		if (nav->timers.size() >= 65536) { nav->timing = false; return; }
+		Timer t;
+		t.name = name;
+		if (hipEventCreate(&t.t0) != hipSuccess || hipEventCreate(&t.t1) != hipSuccess) { nav->timing = false; return; }
+		nav->timers.push_back(t);
 	}
-	Timer t;
+	Timer& t = nav->timers[nav->ntimers];
 	t.name = name;
-	hipEventCreate(&t.t0);
-	hipEventCreate(&t.t1);
-	t.used = true;
 	hipEventRecord(t.t0, nav->stream);
-	nav->timers.push_back(t);
 }
 
 void timer_end(phd_navigator* nav, const char* name)
 {
-	for (Timer& t : nav->timers) {
-		if (t.name == name) hipEventRecord(t.t1, nav->stream);
-	}
+	if (!nav->timing || nav->ntimers >= nav->timers.size()) return;
+	hipEventRecord(nav->timers[nav->ntimers].t1, nav->stream);
+	nav->ntimers++;
 }
 
 const char* T_PC = "k_predict_correct";
@@ -235,7 +236,7 @@ int check_flags(phd_navigator* nav)
 		return nav->fail(PHD_ERR_CAPACITY, "map estimate larger than the landmark scratch (" + std::to_string(nav->Jcap) + ")");
 	}
 	if (f & PHD_FLAG_BIG_CLUSTER) {
-		return nav->fail(PHD_ERR_ASSOCIATION, "data-association cluster with more than 5 rows: beyond the on-device solver");
+		return nav->fail(PHD_ERR_ASSOCIATION, "data-association cluster with more than " + std::to_string(MURTY_NMAX) + " rows: beyond the on-device solver");
 	}
 	return PHD_OK;
 }
@@ -396,6 +397,7 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	ok = ok && dalloc((void**) &nav->d_alpha, (size_t) nav->Pcap * 8) && dalloc((void**) &nav->d_setll, (size_t) nav->Pcap * 8);
 	ok = ok && dalloc((void**) &nav->d_flags, 4) && dalloc((void**) &nav->d_info, 8);
 	ok = ok && dalloc((void**) &nav->d_src, (size_t) nav->Pcap * 4);
+	ok = ok && dalloc((void**) &nav->d_murty, (size_t) nav->Pcap * sizeof(MurtyNodes));
 	if (!ok) {
 		g_create_error = std::string("device allocation failed: ") + hipGetErrorString(hipGetLastError());
 		phd_destroy(nav);
@@ -421,7 +423,7 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_sel); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
-	hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
+	hipFree(nav->d_murty); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
 	if (nav->stream) hipStreamDestroy(nav->stream);
 	delete nav;
@@ -816,6 +818,16 @@ int phd_particle_depleted(phd_navigator* nav, const double* weights, int npartic
 
 void* phd_stream(phd_navigator* nav) { return nav ? (void*) nav->stream : nullptr; }
 
+int phd_timing_reset(phd_navigator* nav, uint8_t enabled)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	hipSetDevice(nav->device);
+	hipStreamSynchronize(nav->stream);
+	nav->ntimers = 0;
+	nav->timing = enabled != 0;
+	return PHD_OK;
+}
+
 int phd_last_timings(phd_navigator* nav, const char*** names, const double** ms)
 {
 	if (!nav) return 0;
@@ -823,14 +835,20 @@ int phd_last_timings(phd_navigator* nav, const char*** names, const double** ms)
 	hipStreamSynchronize(nav->stream);
 	nav->tnames.clear();
 	nav->tms.clear();
-	for (Timer& t : nav->timers) {
-		if (!t.used) continue;
+	nav->tcounts.clear();
+	for (size_t r = 0; r < nav->ntimers; r++) {
+		Timer& t = nav->timers[r];
 		float f = 0;
-		if (hipEventElapsedTime(&f, t.t0, t.t1) == hipSuccess) {
-			nav->tnames.push_back(t.name);
-			nav->tms.push_back((double) f);
+		if (hipEventElapsedTime(&f, t.t0, t.t1) != hipSuccess) continue;
+		size_t k = 0;
+		for (; k < nav->tnames.size(); k++) {
+			if (nav->tnames[k] == t.name) break;
 		}
+		if (k == nav->tnames.size()) { nav->tnames.push_back(t.name); nav->tms.push_back(0); nav->tcounts.push_back(0); }
+		nav->tms[k] += (double) f;
+		nav->tcounts[k]++;
 	}
+	for (size_t k = 0; k < nav->tms.size(); k++) nav->tms[k] /= std::max(nav->tcounts[k], 1);
 	if (names) *names = nav->tnames.data();
 	if (ms) *ms = nav->tms.data();
 	return (int) nav->tnames.size();

@@ -238,6 +238,9 @@ class PHDNavigator:
     def set_frozen(self, frozen):
         self._check(self._lib.phd_set_frozen(self._h, int(bool(frozen))))
 
+    def timing_reset(self, enabled=True):
+        self._check(self._lib.phd_timing_reset(self._h, int(bool(enabled))))
+
     def last_timings(self):
         names = C.POINTER(C.c_char_p)()
         ms = dp()

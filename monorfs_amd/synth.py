@@ -32,17 +32,18 @@ def measure_perfect_identity(m):
 class Frame:
     """One synthetic frame: P particle poses, a C-component prior mixture per particle and M measurements."""
 
-    def __init__(self, P, C, M, seed, detect_fraction=0.9, mean_jitter=1e-2, weight_profile="survey"):
+    def __init__(self, P, C, M, seed, detect_fraction=0.9, mean_jitter=1e-2, weight_profile="survey", shard=0):
         """weight_profile: "survey" = w ~ U(0.05, 1.2) for every component (the expected map size
         then exceeds the detections several times over and every WeightAlpha underflows to 0);
         "steady" = detected components U(0.6, 1.2), the others U(0.002, 0.06): a map consistent with the
         frame, finite particle weights, depletion and resampling."""
         rng = np.random.default_rng(seed)
+        prng = np.random.default_rng([seed, shard]) if shard else rng   # per-particle draws of this shard (rank)
         self.P, self.C, self.M = P, C, M
         # particle poses: base (identity) + one 30 Hz odometry-noise step, Q = diag(5e-3 x3, 2e-4 x3) (Config.cs:244-249)
         dt = 1.0 / 30
-        dloc = rng.normal(size=(P, 3)) * np.sqrt(5e-3) * dt
-        drot = rng.normal(size=(P, 3)) * np.sqrt(2e-4) * dt
+        dloc = prng.normal(size=(P, 3)) * np.sqrt(5e-3) * dt
+        drot = prng.normal(size=(P, 3)) * np.sqrt(2e-4) * dt
         q = np.concatenate([np.ones((P, 1)), 0.5 * drot], axis=1)
         q /= np.linalg.norm(q, axis=1, keepdims=True)
         self.poses = np.concatenate([dloc, q], axis=1)
@@ -52,7 +53,7 @@ class Frame:
         A = rng.uniform(-0.05, 0.05, size=(C, 3, 3))
         cov = A @ np.transpose(A, (0, 2, 1)) + 1e-4 * np.eye(3)
         w = rng.uniform(0.05, 1.2, C)
-        self.mean = base[None] + rng.normal(size=(P, C, 3)) * mean_jitter
+        self.mean = base[None] + prng.normal(size=(P, C, 3)) * mean_jitter
         self.cov = np.broadcast_to(cov, (P, C, 3, 3))
         self.w = np.broadcast_to(w, (P, C))
         self.counts = np.full(P, C, np.int32)

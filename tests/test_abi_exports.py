@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported():
     assert len(names) >= 30
     for n in names:
         assert hasattr(lib, n), "libphdhip.so does not export %s" % n
-    assert set(names) <= set(_lib.EXPORTS) | {"phd_upload_state_soa", "phd_download_state_soa"}
+    assert set(names) == set(_lib.EXPORTS)
 
 
 def test_params_struct_matches_c_defaults():

@@ -219,3 +219,50 @@ def test_capacity_error_is_loud(nav_mod):
         nav.SlamUpdate(None, f.z)
     assert e.value.status == 2
     nav.close()
+
+
+def clustered_frame(seed, groups, per_group, M_per_group, spread_px=4.0):
+    """landmarks packed a few pixels apart so that the association graph has clusters of more than 5 rows"""
+    from monorfs_amd.synth import measure_to_map_identity
+    rng = np.random.default_rng(seed)
+    zc, zs = [], []
+    for _ in range(groups):
+        c = np.array([rng.uniform(-250, 250), rng.uniform(-180, 180), rng.uniform(0.5, 1.5)])
+        for _ in range(per_group):
+            zc.append(c + rng.normal(size=3) * [spread_px, spread_px, 0.02])
+        for _ in range(M_per_group):
+            zs.append(c + rng.normal(size=3) * [spread_px, spread_px, 0.02])
+    zc, zs = np.array(zc), np.array(zs)
+    C = len(zc)
+    f = Frame(3, C, len(zs), seed, weight_profile="steady")
+    base = measure_to_map_identity(zc)
+    f.mean = base[None] + rng.normal(size=(f.P, C, 3)) * 1e-3
+    cov = np.diag([2e-4, 2e-4, 4e-4])
+    f.cov = np.broadcast_to(cov, (f.P, C, 3, 3))
+    f.w = np.broadcast_to(rng.uniform(0.9, 1.1, C), (f.P, C))
+    f.z = zs
+    f.M = len(zs)
+    return f
+
+
+@pytest.mark.parametrize("seed,groups,per_group,mpg", [(61, 2, 3, 3), (62, 3, 4, 3), (63, 1, 6, 7), (64, 4, 2, 4), (65, 2, 5, 5)])
+def test_big_association_clusters(nav_mod, seed, groups, per_group, mpg):
+    """clusters with more than 5 rows go through Murty's ranked assignments on the device, including
+    the reference's early exit on the stale logcomp entry (PHDNavigator.cs:503)"""
+    f = clustered_frame(seed, groups, per_group, mpg)
+    nav, p = make_nav(nav_mod, f, merge_threshold=1e-3)
+    nav.run_stages(f.z, with_alpha=True)
+    setll, alpha = nav.SetLogLikelihood(), nav.WeightAlpha()
+    biggest = 0
+    for i in range(f.P):
+        pred = orc.predict(p, f.poses[i], f.z, f.map(i))
+        pr = orc.prune(p, orc.correct(p, f.poses[i], f.z, pred))
+        assert_mix_close(nav.PruneModel(i), pr, 1e-7, "prune[%d]" % i)
+        lm, _ = orc.best_map_estimate(pr)
+        v, ncl, mx = orc.set_log_likelihood(p, f.poses[i], lm, f.z)
+        biggest = max(biggest, mx)
+        assert np.isclose(setll[i], v, rtol=1e-9, atol=1e-9), "set log-likelihood[%d]: %r vs %r (largest cluster %d)" % (i, setll[i], v, mx)
+        a, _ = orc.weight_alpha(p, f.poses[i], f.z, pred, pr)
+        assert np.isclose(alpha[i], a, rtol=1e-6, atol=0)
+    assert biggest > 5, "the frame did not produce a cluster with more than 5 rows (largest %d)" % biggest
+    nav.close()
