@@ -144,6 +144,7 @@ __global__ __launch_bounds__(256) void k_predict_correct(const DevParams prm, co
 		double acc[ZB];
 #pragma unroll
 		for (int b = 0; b < ZB; b++) acc[b] = 0;
+		bool wavedone = false;
 		for (int c0 = 0; c0 < n; c0 += TILE) {
 			int c = c0 + tid;
 			if (c < n) {
@@ -161,12 +162,13 @@ __global__ __launch_bounds__(256) void k_predict_correct(const DevParams prm, co
 			}
 			__syncthreads();
 			int cend = min(TILE, n - c0);
-			for (int cc = wv; cc < cend; cc += 4) {
+			for (int cc = wv; cc < cend && !wavedone; cc += 4) {
 				double m0 = tile[cc], m1 = tile[TILE + cc], m2 = tile[2 * TILE + cc];
 				double Pi[6];
 #pragma unroll
 				for (int t = 0; t < 6; t++) Pi[t] = tile[(3 + t) * TILE + cc];
 				double w = tile[9 * TILE + cc], mult = tile[10 * TILE + cc];
+				bool open = false;
 #pragma unroll
 				for (int b = 0; b < ZB; b++) {
 					double d0 = wx[b] - m0, d1 = wy[b] - m1, d2 = wz[b] - m2;
@@ -174,9 +176,13 @@ __global__ __launch_bounds__(256) void k_predict_correct(const DevParams prm, co
 					if (zv[b] && gate_near(prm.gate_metric, sq, prm.r_explore)) {
 						acc[b] += w * (mult * exp(-0.5 * quad_sym(Pi, d0, d1, d2)));   // Map.cs:216
 					}
+					open |= zv[b] && !(acc[b] >= prm.expl_thr);
 				}
+				// every term is >= 0: once this wave's partial sum of a measurement reaches the threshold the
+				// full sum does too, so a wave whose measurements are all explored can stop (NaNs keep it going)
+				wavedone = __ballot(open) == 0;
 			}
-			__syncthreads();
+			if (__syncthreads_and(wavedone)) break;
 		}
 #pragma unroll
 		for (int b = 0; b < ZB; b++) part[wv * MP + b * 64 + lane] = acc[b];
@@ -354,159 +360,7 @@ __global__ __launch_bounds__(256) void k_predict_correct(const DevParams prm, co
 	}
 }
 
-// =================================================================================================
-// k_prune_merge — PruneModel (PHDNavigator.cs:913-948)
-//
-// One wave per particle: the greedy merge is sequential in weight order (candidate i absorbs every
-// later close component), so the loop over candidates runs wave-synchronously with the later
-// components spread over the lanes; no workgroup barrier sits inside it.
-//   1. rank every emitted component by (weight desc, canonical index asc)  == stable descending sort
-//   2. keep ranks < min(MaxQuantity, count) (all weights are already >= MinWeight) -> LDS, sorted
-//   3. for each still-unassigned i in order: close(k) = (m_i - m_k)^T P_i^-1 (m_i - m_k) < T^2 for k > i
-//      (Gaussian.AreClose uses the candidate's covariance only, Gaussian.cs:243-246); moment-match the
-//      set (Gaussian.Merge, Gaussian.cs:329-346) and write it over slot `nout` (nout <= i).
-// =================================================================================================
-__global__ __launch_bounds__(64) void k_prune_merge(const DevParams prm, const StepBufs a, int cutcap)
-{
-	extern __shared__ __align__(16) double smem[];
-	double* keyw = smem;                     // [ecap]
-	double* sw   = keyw + a.ecap;            // [cutcap] sorted weight
-	double* sm   = sw + cutcap;              // [3][cutcap]
-	double* sP   = sm + 3 * cutcap;          // [6][cutcap]
-	int*    keyi = (int*) (sP + 6 * cutcap); // [ecap]
-
-	const int p = blockIdx.x, lane = threadIdx.x;
-	const MixView vout = bank_view(a, SEL_OUT);
-	const int ne = a.emit_count[p];
-	const size_t eb = (size_t) p * a.ecap;
-	for (int e = lane; e < ne; e += 64) {
-		keyw[e] = a.emit_w[eb + e];
-		keyi[e] = a.emit_idx[eb + e];
-	}
-	__syncthreads();
-	const int cut = min(min(prm.maxq, ne), cutcap);
-
-	// 1+2: counting rank, four elements per lane per sweep so each broadcast key is used four times
-	for (int e0 = 0; e0 < ne; e0 += 256) {
-		double we[4];
-		int    ie[4], rank[4];
-#pragma unroll
-		for (int u = 0; u < 4; u++) {
-			int e = e0 + u * 64 + lane;
-			we[u] = (e < ne) ? keyw[e] : 0.0;
-			ie[u] = (e < ne) ? keyi[e] : 0x7fffffff;
-			rank[u] = 0;
-		}
-		for (int j = 0; j < ne; j++) {
-			double wj = keyw[j];
-			int    ij = keyi[j];
-#pragma unroll
-			for (int u = 0; u < 4; u++) {
-				rank[u] += (wj > we[u]) || (wj == we[u] && ij < ie[u]);
-			}
-		}
-#pragma unroll
-		for (int u = 0; u < 4; u++) {
-			int e = e0 + u * 64 + lane;
-			if (e < ne && rank[u] < cut) {
-				int r = rank[u];
-				const double* rec = a.emit_rec + (eb + e) * 9;
-				sw[r] = we[u];
-#pragma unroll
-				for (int t = 0; t < 3; t++) sm[t * cutcap + r] = rec[t];
-#pragma unroll
-				for (int t = 0; t < 6; t++) sP[t * cutcap + r] = rec[3 + t];
-			}
-		}
-	}
-	__syncthreads();
-
-	// 3: greedy merge. assigned: bit s of a lane <-> element s*64 + lane
-	unsigned int assigned = 0;
-	const int nslots = (cut + 63) >> 6;
-	int nout = 0;
-	for (int i = 0; i < cut; i++) {
-		unsigned int om = __builtin_amdgcn_readlane(assigned, i & 63);
-		if ((om >> (i >> 6)) & 1u) continue;
-		double lw = sw[i];
-		double lm[3] = {sm[i], sm[cutcap + i], sm[2 * cutcap + i]};
-		double lP[6], Pi[6], det;
-#pragma unroll
-		for (int t = 0; t < 6; t++) lP[t] = sP[t * cutcap + i];
-		inv_sym3(lP, Pi, det);
-
-		double aw = 0, am[3] = {0, 0, 0}, aP[6] = {0, 0, 0, 0, 0, 0};
-		bool any = false;
-		for (int s = i >> 6; s < nslots; s++) {
-			int k = s * 64 + lane;
-			bool ok = (k > i) && (k < cut) && !((assigned >> s) & 1u);
-			if (ok) {
-				double k0 = sm[k], k1 = sm[cutcap + k], k2 = sm[2 * cutcap + k];
-				double d2 = quad_sym(Pi, lm[0] - k0, lm[1] - k1, lm[2] - k2);   // Gaussian.SquareMahalanobis
-				if (d2 < prm.merge_thr2) {
-					assigned |= 1u << s;
-					any = true;
-					double w = sw[k];
-					aw += w;
-					am[0] += w * k0; am[1] += w * k1; am[2] += w * k2;
-					aP[0] += w * (sP[0 * cutcap + k] + k0 * k0);
-					aP[1] += w * (sP[1 * cutcap + k] + k0 * k1);
-					aP[2] += w * (sP[2 * cutcap + k] + k0 * k2);
-					aP[3] += w * (sP[3 * cutcap + k] + k1 * k1);
-					aP[4] += w * (sP[4 * cutcap + k] + k1 * k2);
-					aP[5] += w * (sP[5 * cutcap + k] + k2 * k2);
-				}
-			}
-		}
-		if (__ballot(any)) {
-			aw = wave_sum(aw);
-#pragma unroll
-			for (int t = 0; t < 3; t++) am[t] = wave_sum(am[t]);
-#pragma unroll
-			for (int t = 0; t < 6; t++) aP[t] = wave_sum(aP[t]);
-		}
-		// Gaussian.Merge: raw moments, leader first (Gaussian.cs:329-346)
-		double W = (0.0 + lw) + aw;
-		double Mv[3] = {(0.0 + lw * lm[0]) + am[0], (0.0 + lw * lm[1]) + am[1], (0.0 + lw * lm[2]) + am[2]};
-		double C[6] = {(0.0 + lw * (lP[0] + lm[0] * lm[0])) + aP[0], (0.0 + lw * (lP[1] + lm[0] * lm[1])) + aP[1],
-		               (0.0 + lw * (lP[2] + lm[0] * lm[2])) + aP[2], (0.0 + lw * (lP[3] + lm[1] * lm[1])) + aP[3],
-		               (0.0 + lw * (lP[4] + lm[1] * lm[2])) + aP[4], (0.0 + lw * (lP[5] + lm[2] * lm[2])) + aP[5]};
-		double ow, omn[3], oP[6];
-		if (W < 1e-15) {   // Gaussian.cs:339-341
-			ow = 0.0;
-			omn[0] = lm[0]; omn[1] = lm[1]; omn[2] = lm[2];
-			oP[0] = 1e12; oP[1] = 0; oP[2] = 0; oP[3] = 1e12; oP[4] = 0; oP[5] = 1e12;
-		}
-		else {
-			ow = W;
-			omn[0] = Mv[0] / W; omn[1] = Mv[1] / W; omn[2] = Mv[2] / W;
-			oP[0] = C[0] / W - omn[0] * omn[0];
-			oP[1] = C[1] / W - omn[0] * omn[1];
-			oP[2] = C[2] / W - omn[0] * omn[2];
-			oP[3] = C[3] / W - omn[1] * omn[1];
-			oP[4] = C[4] / W - omn[1] * omn[2];
-			oP[5] = C[5] / W - omn[2] * omn[2];
-		}
-		if (lane == 0) {   // nout <= i: the slot is never read again inside the loop
-			sw[nout] = ow;
-#pragma unroll
-			for (int t = 0; t < 3; t++) sm[t * cutcap + nout] = omn[t];
-#pragma unroll
-			for (int t = 0; t < 6; t++) sP[t * cutcap + nout] = oP[t];
-		}
-		nout++;
-	}
-	__syncthreads();
-	const size_t ob = (size_t) p * a.cap;
-	for (int o = lane; o < nout; o += 64) {
-		vout.w[ob + o] = sw[o];
-#pragma unroll
-		for (int t = 0; t < 3; t++) vout.m[t][ob + o] = sm[t * cutcap + o];
-#pragma unroll
-		for (int t = 0; t < 6; t++) vout.P[t][ob + o] = sP[t * cutcap + o];
-	}
-	if (lane == 0) vout.count[p] = nout;
-}
+#include "phd_prune.h"
 
 // =================================================================================================
 // k_weight_alpha — WeightAlpha (PHDNavigator.cs:373-393)
@@ -1292,17 +1146,35 @@ __global__ __launch_bounds__(256) void k_weight_alpha(const DevParams prm, const
 //   info   : [0] BestParticle, [1] resampled flag
 // =================================================================================================
 __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, double* gw, int P, double min_eff, double u,
-                                                             int force_resample, int skip_normalise,
+                                                             int force_resample, int skip_normalise, int use_lds,
                                                              int* src, int* info)
 {
+	extern __shared__ __align__(16) double lw[];   // [P] when use_lds: the sequential loops then run out of LDS
 	__shared__ double s_sum;
-	__shared__ int s_res;
+	__shared__ int s_res, s_best, s_best_resampled;
 	const int tid = threadIdx.x;
-	double* w = gw ? gw : a.bank[a.sel[SEL_OUT]].weights;
-	if (tid == 0) {
+	double* gwp = gw ? gw : a.bank[a.sel[SEL_OUT]].weights;
+	double* w = use_lds ? lw : gwp;
+	if (use_lds) {
+		for (int i = tid; i < P; i += 1024) lw[i] = gwp[i];
+		__syncthreads();
+	}
+	// The three sequential passes run wave-uniformly: 64 weights are fetched by one LDS/global read into
+	// the lanes and then consumed one by one through v_readlane, so the running sums keep the
+	// reference's order without a dependent memory access per element.
+	const int lane = tid & 63, wv = tid >> 6;
+	auto rl = [](double v, int l) {
+		int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+		return __hiloint2double(hi, lo);
+	};
+	if (wv == 0) {
 		double sum = 0;
-		for (int i = 0; i < P; i++) sum += w[i];   // Accord Sum(): sequential
-		s_sum = (sum == 0) ? 1 : sum;               // :344
+		for (int b = 0; b < P; b += 64) {
+			double v = (b + lane < P) ? w[b + lane] : 0.0;
+			int cnt = min(64, P - b);
+			for (int j = 0; j < cnt; j++) sum += rl(v, j);   // Accord Sum(): sequential
+		}
+		if (lane == 0) s_sum = (sum == 0) ? 1 : sum;         // :344
 	}
 	__syncthreads();
 	if (!skip_normalise) {
@@ -1311,39 +1183,62 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 	}
 	__threadfence_block();
 	__syncthreads();
-	if (tid == 0) {
+	if (wv == 0) {
 		double maxweight = 0, cum = 0;
 		int best = 0;
-		for (int i = 0; i < P; i++) {
-			double wi = w[i];
-			if (wi > maxweight) { maxweight = wi; best = i; }   // :349-354
-			cum += wi * wi;                                     // :772-774
+		for (int b = 0; b < P; b += 64) {
+			double v = (b + lane < P) ? w[b + lane] : 0.0;
+			int cnt = min(64, P - b);
+			for (int j = 0; j < cnt; j++) {
+				double wi = rl(v, j);
+				if (wi > maxweight) { maxweight = wi; best = b + j; }   // :349-354
+				cum += wi * wi;                                         // :772-774
+			}
 		}
 		bool depleted = (1.0 / cum < min_eff * P);              // :776
 		if (force_resample > 0) depleted = true;
 		if (force_resample < 0) depleted = false;
-		s_res = depleted;
-		if (depleted) {   // ResampleParticles, :727-749
-			double random = u / P;
-			maxweight = 0;
-			int k = 0;
-			for (int i = 0; i < P; i++) {
-				for (; random > 0 && k < P; k++) random -= w[k];
-				int s = (k - 1 < 0) ? 0 : k - 1;   // u == 0 would index -1 in the reference: clamped
-				src[i] = s;
-				random += 1.0 / P;
-				if (w[s] > maxweight) { maxweight = w[s]; best = i; }
+		if (lane == 0) { s_res = depleted; s_best = best; }
+	}
+	else if (wv == 1 && force_resample >= 0) {
+		// ResampleParticles (:727-749), run by a second wave beside the depletion test: its recurrence
+		// does not depend on the outcome, only its use does
+		double random = u / P;
+		double maxweight = 0;
+		int k = 0, best = 0;
+		int cb = 0;                                              // chunk [cb, cb + 64) is in `cur`, the one before in `prev`
+		double cur = (lane < P) ? w[lane] : 0.0, prev = 0.0;
+		// every lane holds the same `random`; taking lane 0's comparison (readfirstlane) keeps k, i and the
+		// branches in scalar registers, so each step is one dependent v_add_f64 plus scalar bookkeeping
+		const double invP = 1.0 / P;
+		for (int i = 0; i < P; i++) {
+			while (k < P && __builtin_amdgcn_readfirstlane((int) (random > 0))) {
+				if (k >= cb + 64) { prev = cur; cb += 64; cur = (cb + lane < P) ? w[cb + lane] : 0.0; }
+				random -= rl(cur, k - cb);
+				k++;
 			}
+			int s = (k - 1 < 0) ? 0 : k - 1;   // u == 0 would index -1 in the reference: clamped
+			if (lane == 0) src[i] = s;
+			random += invP;
+			double ws = (s >= cb) ? rl(cur, s - cb) : rl(prev, s - (cb - 64));
+			if (__builtin_amdgcn_readfirstlane((int) (ws > maxweight))) { maxweight = ws; best = i; }
 		}
-		info[0] = best;
-		info[1] = depleted;
+		if (lane == 0) s_best_resampled = best;
 	}
 	__syncthreads();
-	if (s_res) {
-		for (int i = tid; i < P; i += 1024) w[i] = 1.0 / P;   // :742
+	const bool res = s_res != 0;
+	if (tid == 0) {
+		info[0] = res ? s_best_resampled : s_best;
+		info[1] = res;
+	}
+	if (res) {
+		for (int i = tid; i < P; i += 1024) gwp[i] = 1.0 / P;   // :742
 	}
 	else {
-		for (int i = tid; i < P; i += 1024) src[i] = i;
+		for (int i = tid; i < P; i += 1024) {
+			src[i] = i;
+			if (use_lds && !skip_normalise) gwp[i] = lw[i];
+		}
 	}
 }
 

@@ -158,7 +158,6 @@ size_t lds_predict_correct(int ZB)
 	return (size_t) (3 * MP + 3 * MP + 4 * MP + MP + 18 * TILE) * 8 + (size_t) (MP + 2) * 4;
 }
 
-size_t lds_prune(int ecap, int cutcap) { return (size_t) (ecap + 10 * cutcap) * 8 + (size_t) ecap * 4; }
 
 // HIP events around every kernel launch, on the stream the kernel is launched on
 void timer_begin(phd_navigator* nav, const char* name)
@@ -199,10 +198,10 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b, bool with_alpha)
 	timer_end(nav, T_PC);
 	HC(hipGetLastError());
 
-	size_t lp = lds_prune(nav->ecap, nav->cutcap);
+	size_t lp = (size_t) prune_lds(nav->cutcap).bytes;
 	HC(hipFuncSetAttribute((const void*) k_prune_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lp));
 	timer_begin(nav, T_PM);
-	hipLaunchKernelGGL(k_prune_merge, dim3(P), dim3(64), lp, nav->stream, nav->dp, b, nav->cutcap);
+	hipLaunchKernelGGL(k_prune_merge, dim3(P), dim3(256), lp, nav->stream, nav->dp, b, nav->cutcap);
 	timer_end(nav, T_PM);
 	HC(hipGetLastError());
 
@@ -224,6 +223,18 @@ int launch_map(phd_navigator* nav, const StepBufs& b, bool with_alpha)
 	case 2:  return launch_map_kernels<2>(nav, b, with_alpha);
 	default: return launch_map_kernels<4>(nav, b, with_alpha);
 	}
+}
+
+int launch_normalise(phd_navigator* nav, const StepBufs& b, double* gw, int P, double u, int force, int skipnorm, int* src, int* info)
+{
+	size_t lds = (size_t) P * 8;
+	int use_lds = lds <= 144 * 1024;
+	if (!use_lds) lds = 0;
+	HC(hipFuncSetAttribute((const void*) k_normalise_resample, hipFuncAttributeMaxDynamicSharedMemorySize, (int) std::max<size_t>(lds, 16)));
+	hipLaunchKernelGGL(k_normalise_resample, dim3(1), dim3(1024), lds, nav->stream, b, gw, P, nav->dp.min_eff, u, force, skipnorm,
+	                   use_lds, src, info);
+	HC(hipGetLastError());
+	return PHD_OK;
 }
 
 int check_flags(phd_navigator* nav)
@@ -565,10 +576,9 @@ int phd_step_async(phd_navigator* nav, uint8_t onlymapping, double u_resample)
 	int rc = launch_map(nav, b, !onlymapping);
 	if (rc) return rc;
 	timer_begin(nav, T_NR);
-	hipLaunchKernelGGL(k_normalise_resample, dim3(1), dim3(1024), 0, nav->stream, b, (double*) nullptr, nav->P,
-	                   nav->dp.min_eff, u_resample, onlymapping ? -1 : 0, onlymapping ? 1 : 0, nav->d_src, nav->d_info);
+	rc = launch_normalise(nav, b, nullptr, nav->P, u_resample, onlymapping ? -1 : 0, onlymapping ? 1 : 0, nav->d_src, nav->d_info);
 	timer_end(nav, T_NR);
-	HC(hipGetLastError());
+	if (rc) return rc;
 	int* sel_next = nav->d_sel + (nav->parity ^ 1) * 4;
 	timer_begin(nav, T_GR);
 	hipLaunchKernelGGL(k_gather_rotate, dim3(nav->P), dim3(256), 0, nav->stream, b, nav->d_src, nav->d_info, 0, sel_next,
@@ -781,8 +791,7 @@ int phd_resample(phd_navigator* nav, const double* weights, int nparticles, doub
 	StepBufs b = make_bufs(nav);
 	int* d_src2 = nullptr;
 	HC(hipMalloc((void**) &d_src2, (size_t) nparticles * 4 + 8));
-	hipLaunchKernelGGL(k_normalise_resample, dim3(1), dim3(1024), 0, nav->stream, b, nav->d_gw, nparticles, nav->dp.min_eff,
-	                   u_resample, 1, 1, d_src2 + 2, d_src2);
+	rc = launch_normalise(nav, b, nav->d_gw, nparticles, u_resample, 1, 1, d_src2 + 2, d_src2);
 	hipError_t e = hipStreamSynchronize(nav->stream);
 	int info[2] = {0, 0};
 	if (e == hipSuccess) e = hipMemcpy(sources, d_src2 + 2, (size_t) nparticles * 4, hipMemcpyDeviceToHost);
@@ -805,8 +814,7 @@ int phd_particle_depleted(phd_navigator* nav, const double* weights, int npartic
 	StepBufs b = make_bufs(nav);
 	int* d_tmp = nullptr;
 	HC(hipMalloc((void**) &d_tmp, (size_t) nparticles * 4 + 8));
-	hipLaunchKernelGGL(k_normalise_resample, dim3(1), dim3(1024), 0, nav->stream, b, nav->d_gw, nparticles, nav->dp.min_eff,
-	                   0.5, 0, 1, d_tmp + 2, d_tmp);
+	rc = launch_normalise(nav, b, nav->d_gw, nparticles, 0.5, 0, 1, d_tmp + 2, d_tmp);
 	hipError_t e = hipStreamSynchronize(nav->stream);
 	int info[2] = {0, 0};
 	if (e == hipSuccess) e = hipMemcpy(info, d_tmp, 8, hipMemcpyDeviceToHost);
@@ -899,10 +907,9 @@ int phd_step_global_async(phd_navigator* nav, int rank, int world_size, double u
 	if (rc) return rc;
 	StepBufs b = make_bufs(nav);
 	timer_begin(nav, T_NR);
-	hipLaunchKernelGGL(k_normalise_resample, dim3(1), dim3(1024), 0, nav->stream, b, nav->d_gw, Pg, nav->dp.min_eff,
-	                   u_resample, 0, 0, nav->d_plan, nav->d_info);
+	rc = launch_normalise(nav, b, nav->d_gw, Pg, u_resample, 0, 0, nav->d_plan, nav->d_info);
 	timer_end(nav, T_NR);
-	HC(hipGetLastError());
+	if (rc) return rc;
 	hipLaunchKernelGGL(k_scatter_weights, dim3((nav->P + 255) / 256), dim3(256), 0, nav->stream, b, nav->d_gw, rank * nav->P);
 	HC(hipGetLastError());
 	return PHD_OK;
