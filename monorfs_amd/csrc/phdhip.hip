@@ -915,6 +915,47 @@ int phd_step_global_async(phd_navigator* nav, int rank, int world_size, double u
 	return PHD_OK;
 }
 
+// Pure host logic (no handle, no device): from the global source vector of a resampling step, which of
+// this rank's particles go where and where each of its slots comes from. Both sides derive their lists
+// from the same vector, so the sender's order per destination equals the receiver's order per source.
+//   send_list : local indices to pack, grouped by destination rank (ascending), then by destination slot
+//   dst_code  : per local slot: >= 0 local source index, < 0 -(k + 1) = record k of the receive buffer
+// Returns the number of records received.
+int phd_plan_migration(const int32_t* gsrc, int Pl, int world_size, int rank, int32_t* send_counts, int32_t* recv_counts,
+                       int32_t* send_list, int32_t* dst_code)
+{
+	const int first = rank * Pl;
+	for (int r = 0; r < world_size; r++) send_counts[r] = recv_counts[r] = 0;
+	int ns = 0;
+	for (int r = 0; r < world_size; r++) {
+		if (r == rank) continue;
+		for (int g = r * Pl; g < (r + 1) * Pl; g++) {
+			int s = gsrc[g];
+			if (s >= first && s < first + Pl) {
+				send_list[ns++] = s - first;
+				send_counts[r]++;
+			}
+		}
+	}
+	for (int i = 0; i < Pl; i++) {
+		int s = gsrc[first + i];
+		if (s >= first && s < first + Pl) dst_code[i] = s - first;
+	}
+	int slot = 0;
+	for (int r = 0; r < world_size; r++) {
+		if (r == rank) continue;
+		for (int i = 0; i < Pl; i++) {
+			int s = gsrc[first + i];
+			if (s >= r * Pl && s < (r + 1) * Pl) {
+				dst_code[i] = -(slot + 1);
+				slot++;
+				recv_counts[r]++;
+			}
+		}
+	}
+	return slot;
+}
+
 int phd_migration_plan(phd_navigator* nav, int rank, int world_size, int32_t* send_counts, int32_t* recv_counts)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
@@ -934,35 +975,11 @@ int phd_migration_plan(phd_navigator* nav, int rank, int world_size, int32_t* se
 		for (int i = 0; i < Pl; i++) nav->h_plan_recv[i] = i;
 		return PHD_OK;
 	}
-	// what I send: every destination slot g on another rank whose source I own, ordered by (dest rank, g)
-	for (int r = 0; r < world_size; r++) {
-		if (r == rank) continue;
-		for (int g = r * Pl; g < (r + 1) * Pl; g++) {
-			int s = gsrc[g];
-			if (s >= first && s < first + Pl) {
-				nav->h_plan_send.push_back(s - first);
-				send_counts[r]++;
-			}
-		}
-	}
-	// what I receive: my slots whose source is remote, ordered by (source rank, slot) — the sender's order
-	int slot = 0;
-	std::vector<int> code(Pl);
-	for (int i = 0; i < Pl; i++) {
-		int s = gsrc[first + i];
-		if (s >= first && s < first + Pl) code[i] = s - first;
-	}
-	for (int r = 0; r < world_size; r++) {
-		if (r == rank) continue;
-		for (int i = 0; i < Pl; i++) {
-			int s = gsrc[first + i];
-			if (s >= r * Pl && s < (r + 1) * Pl) {
-				code[i] = -(slot + 1);
-				slot++;
-				recv_counts[r]++;
-			}
-		}
-	}
+	std::vector<int> code(Pl), sendlist(Pl * (size_t) std::max(world_size - 1, 1));
+	int slot = phd_plan_migration(gsrc.data(), Pl, world_size, rank, send_counts, recv_counts, sendlist.data(), code.data());
+	int ns = 0;
+	for (int r = 0; r < world_size; r++) ns += send_counts[r];
+	nav->h_plan_send.assign(sendlist.begin(), sendlist.begin() + ns);
 	nav->h_plan_recv = code;
 	nav->nsend = (int) nav->h_plan_send.size();
 	nav->nrecv = slot;
