@@ -1137,110 +1137,7 @@ __global__ __launch_bounds__(256) void k_weight_alpha(const DevParams prm, const
 	}
 }
 
-// =================================================================================================
-// k_normalise_resample — PHDNavigator.cs:343-358, 724-777 on the whole weight vector (all ranks'
-// particles when sharded). Sums and the systematic-resampling recurrence run in the reference's
-// sequential order on one lane, so the result is bit-identical for any number of GPUs.
-//   w      : [P] in: un-normalised weights, out: normalised weights, or 1/P after resampling
-//   src    : [P] source slot of each particle (identity when not resampled)
-//   info   : [0] BestParticle, [1] resampled flag
-// =================================================================================================
-__global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, double* gw, int P, double min_eff, double u,
-                                                             int force_resample, int skip_normalise, int use_lds,
-                                                             int* src, int* info)
-{
-	extern __shared__ __align__(16) double lw[];   // [P] when use_lds: the sequential loops then run out of LDS
-	__shared__ double s_sum;
-	__shared__ int s_res, s_best, s_best_resampled;
-	const int tid = threadIdx.x;
-	double* gwp = gw ? gw : a.bank[a.sel[SEL_OUT]].weights;
-	double* w = use_lds ? lw : gwp;
-	if (use_lds) {
-		for (int i = tid; i < P; i += 1024) lw[i] = gwp[i];
-		__syncthreads();
-	}
-	// The three sequential passes run wave-uniformly: 64 weights are fetched by one LDS/global read into
-	// the lanes and then consumed one by one through v_readlane, so the running sums keep the
-	// reference's order without a dependent memory access per element.
-	const int lane = tid & 63, wv = tid >> 6;
-	auto rl = [](double v, int l) {
-		int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-		return __hiloint2double(hi, lo);
-	};
-	if (wv == 0) {
-		double sum = 0;
-		for (int b = 0; b < P; b += 64) {
-			double v = (b + lane < P) ? w[b + lane] : 0.0;
-			int cnt = min(64, P - b);
-			for (int j = 0; j < cnt; j++) sum += rl(v, j);   // Accord Sum(): sequential
-		}
-		if (lane == 0) s_sum = (sum == 0) ? 1 : sum;         // :344
-	}
-	__syncthreads();
-	if (!skip_normalise) {
-		const double sum = s_sum;
-		for (int i = tid; i < P; i += 1024) w[i] = w[i] / sum;   // :345
-	}
-	__threadfence_block();
-	__syncthreads();
-	if (wv == 0) {
-		double maxweight = 0, cum = 0;
-		int best = 0;
-		for (int b = 0; b < P; b += 64) {
-			double v = (b + lane < P) ? w[b + lane] : 0.0;
-			int cnt = min(64, P - b);
-			for (int j = 0; j < cnt; j++) {
-				double wi = rl(v, j);
-				if (wi > maxweight) { maxweight = wi; best = b + j; }   // :349-354
-				cum += wi * wi;                                         // :772-774
-			}
-		}
-		bool depleted = (1.0 / cum < min_eff * P);              // :776
-		if (force_resample > 0) depleted = true;
-		if (force_resample < 0) depleted = false;
-		if (lane == 0) { s_res = depleted; s_best = best; }
-	}
-	else if (wv == 1 && force_resample >= 0) {
-		// ResampleParticles (:727-749), run by a second wave beside the depletion test: its recurrence
-		// does not depend on the outcome, only its use does
-		double random = u / P;
-		double maxweight = 0;
-		int k = 0, best = 0;
-		int cb = 0;                                              // chunk [cb, cb + 64) is in `cur`, the one before in `prev`
-		double cur = (lane < P) ? w[lane] : 0.0, prev = 0.0;
-		// every lane holds the same `random`; taking lane 0's comparison (readfirstlane) keeps k, i and the
-		// branches in scalar registers, so each step is one dependent v_add_f64 plus scalar bookkeeping
-		const double invP = 1.0 / P;
-		for (int i = 0; i < P; i++) {
-			while (k < P && __builtin_amdgcn_readfirstlane((int) (random > 0))) {
-				if (k >= cb + 64) { prev = cur; cb += 64; cur = (cb + lane < P) ? w[cb + lane] : 0.0; }
-				random -= rl(cur, k - cb);
-				k++;
-			}
-			int s = (k - 1 < 0) ? 0 : k - 1;   // u == 0 would index -1 in the reference: clamped
-			if (lane == 0) src[i] = s;
-			random += invP;
-			double ws = (s >= cb) ? rl(cur, s - cb) : rl(prev, s - (cb - 64));
-			if (__builtin_amdgcn_readfirstlane((int) (ws > maxweight))) { maxweight = ws; best = i; }
-		}
-		if (lane == 0) s_best_resampled = best;
-	}
-	__syncthreads();
-	const bool res = s_res != 0;
-	if (tid == 0) {
-		info[0] = res ? s_best_resampled : s_best;
-		info[1] = res;
-	}
-	if (res) {
-		for (int i = tid; i < P; i += 1024) gwp[i] = 1.0 / P;   // :742
-	}
-	else {
-		for (int i = tid; i < P; i += 1024) {
-			src[i] = i;
-			if (use_lds && !skip_normalise) gwp[i] = lw[i];
-		}
-	}
-}
+#include "phd_resample.h"
 
 // Deep copy of the resampled particles (PHDNavigator.cs:740-741) and rotation of the bank roles for the
 // next step, decided on the device from the resampling flag so the host never waits inside a step.

@@ -13,9 +13,9 @@ int main()
 	try {
 		monorfs::PHDNavigator nav(prm, pose, 8);
 		std::vector<monorfs::PixelRangeMeasurement> z = {{10, 20, 1.0}, {-50, 30, 0.8}, {100, -60, 1.4}};
-		nav.SlamUpdate(z, 0.5);   // three births per particle
+		nav.SlamUpdate(z, 0.5);   // three births per particle, corrected by their own measurements in the same frame
 		monorfs::Map m0 = nav.BestMapModel();
-		if (m0.size() != 3) { std::printf("expected 3 births, got %zu\n", m0.size()); return 1; }
+		if (m0.size() < 3 || m0.size() > 6) { std::printf("expected 3..6 components after the first frame, got %zu\n", m0.size()); return 1; }
 		nav.SlamUpdate(z, 0.5);   // now detected
 		monorfs::Map m1 = nav.BestMapModel();
 		double sumw = 0;
