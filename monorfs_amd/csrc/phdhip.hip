@@ -44,6 +44,7 @@ struct phd_navigator {
 	double* d_alpha = nullptr; double* d_setll = nullptr;
 	int*    d_flags = nullptr; int* d_src = nullptr; int* d_info = nullptr;
 	MurtyNodes* d_murty = nullptr;
+	double* d_jscratch = nullptr;
 	double* d_gw = nullptr; int gwcap = 0;           // gathered weights of all ranks
 	double* d_stage = nullptr;                       // staging for uploads
 	// migration (multi-GPU resampling)
@@ -146,7 +147,7 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.z = nav->d_z;
 	b.emit_w = nav->d_emit_w; b.emit_idx = nav->d_emit_idx; b.emit_rec = nav->d_emit_rec; b.emit_count = nav->d_emit_count;
 	b.born_count = nav->d_born_count; b.born_k = nav->d_born_k; b.born_mean = nav->d_born_mean;
-	b.alpha = nav->d_alpha; b.setll = nav->d_setll; b.flags = nav->d_flags; b.murty = nav->d_murty;
+	b.alpha = nav->d_alpha; b.setll = nav->d_setll; b.flags = nav->d_flags; b.murty = nav->d_murty; b.jscratch = nav->d_jscratch;
 	return b;
 }
 
@@ -206,7 +207,7 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b, bool with_alpha)
 	HC(hipGetLastError());
 
 	if (with_alpha) {
-		AlphaLds lay = alpha_lds(ZB * 64, nav->Jcap, nav->cutcap);
+		AlphaLds lay = alpha_lds(ZB * 64, nav->cutcap);
 		HC(hipFuncSetAttribute((const void*) k_weight_alpha<ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
 		timer_begin(nav, T_WA);
 		hipLaunchKernelGGL(k_weight_alpha<ZB>, dim3(P), dim3(256), lay.bytes, nav->stream, nav->dp, b, nav->cutcap);
@@ -380,7 +381,7 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	nav->cutcap = params->max_quantity;
 	int ecap = params->emit_capacity > 0 ? params->emit_capacity : 4 * (nav->cap + nav->Mcap);
 	nav->ecap = (std::max(ecap, nav->cutcap) + 63) & ~63;
-	nav->Jcap = std::min(512, (nav->cutcap + 63) & ~63);
+	nav->Jcap = std::min(1024, (nav->cutcap + 63) & ~63);
 	nav->P = 0;
 
 	auto dalloc = [&](void** ptr, size_t bytes) { return hipMalloc(ptr, std::max<size_t>(bytes, 16)) == hipSuccess; };
@@ -409,6 +410,7 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	ok = ok && dalloc((void**) &nav->d_flags, 4) && dalloc((void**) &nav->d_info, 8);
 	ok = ok && dalloc((void**) &nav->d_src, (size_t) nav->Pcap * 4);
 	ok = ok && dalloc((void**) &nav->d_murty, (size_t) nav->Pcap * sizeof(MurtyNodes));
+	ok = ok && dalloc((void**) &nav->d_jscratch, (size_t) nav->Pcap * alpha_jscratch_doubles(nav->Jcap) * 8);
 	if (!ok) {
 		g_create_error = std::string("device allocation failed: ") + hipGetErrorString(hipGetLastError());
 		phd_destroy(nav);
@@ -434,7 +436,7 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_sel); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
-	hipFree(nav->d_murty); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
+	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
 	if (nav->stream) hipStreamDestroy(nav->stream);
 	delete nav;
