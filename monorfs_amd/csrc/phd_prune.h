@@ -6,24 +6,28 @@
 // the set by its moment match (Gaussian.Merge, Gaussian.cs:297-347).
 //
 // Only the question "is i still present" is sequential. The kernel therefore splits the work:
-//   A. rank     : stable descending order by counting (every thread ranks its entries against LDS key tiles)
-//   B. pairs    : every closeness test close_i(k), k > i, in parallel — row i per thread, the candidate's
-//                 P_i^-1 in registers, the other means broadcast from LDS; a Euclidean bound
+//   A. sort     : bitonic sort in LDS on the weight's bit pattern (12-byte entries: key + emit slot), the
+//                 best half kept while further chunks stream in; runs of equal weights are then put in
+//                 canonical-index order, which makes the order the reference's sort made stable
+//   B. pairs    : every closeness test close_i(k), k > i, in parallel — two rows per thread, the other
+//                 means broadcast from LDS. A float32 Euclidean bound
 //                 |d|^2 > T^2 trace(P_i)  =>  d^T P_i^-1 d >= |d|^2 / lambda_max(P_i) > T^2
-//                 skips the quadratic form for far pairs. Each row keeps its first 7 close entries.
-//   C. resolve  : one wave walks the rows in weight order with the "absorbed" bits spread over its lanes
-//                 (integer work only); rows with more than 7 close entries are re-tested by the 64 lanes.
+//                 (radius inflated for the float32 rounding) rejects far pairs; the survivors take the
+//                 exact FP64 test. Each row keeps its first 7 close rows.
+//   C. resolve  : one wave walks the rows in weight order, 64 row records at a time held in its lanes and
+//                 the "absorbed" bits spread over its lanes (integer work only); rows with more than 7
+//                 close rows are re-tested by the 64 lanes.
 //   D. merge    : one thread per surviving row accumulates the raw moments of its set in list order
 //                 (leader first, members by rank — the reference's summation order) and writes the
 //                 result at its position among the survivors.
 #pragma once
 #include "phd_device.h"
 
-#define PRUNE_KEYTILE 1024
 #define PRUNE_NBR 7
 
 struct PruneLds {
 	int sw, sm, order, x, scan;   // offsets in doubles
+	int NS;                       // sort width (power of two >= 2 * cutcap)
 	int bytes;
 };
 
@@ -31,29 +35,61 @@ __host__ __device__ inline PruneLds prune_lds(int cutcap)
 {
 	PruneLds l;
 	int cc = (cutcap + 1) & ~1;
+	int NS = 512;
+	while (NS < 2 * cutcap) NS <<= 1;
+	l.NS    = NS;
 	l.sw    = 0;
 	l.sm    = l.sw + cc;
 	l.order = l.sm + 3 * cc;                 // int[cc]
-	l.x     = l.order + cc / 2;              // key tile (1024 doubles + 1024 ints)  |  nbr u64[2*cc] + owner int[cc]
-	int keytile = PRUNE_KEYTILE + PRUNE_KEYTILE / 2;
-	int rest    = 2 * cc + cc / 2;
-	l.scan  = l.x + (keytile > rest ? keytile : rest);
-	l.bytes = (l.scan + 132) * 8;            // int[264]
+	l.x     = l.order + cc / 2;              // sort keys u64[NS] + slots int[NS]  |  nbr u64[2*cc], owner int[cc], smf float[3*cc], absb int[64]
+	int sortd = NS + NS / 2;
+	int rest  = 2 * cc + cc / 2 + (3 * cc + 1) / 2 + 1 + 32;
+	l.scan  = l.x + (sortd > rest ? sortd : rest);
+	l.bytes = (l.scan + 136) * 8;            // int[264] + spare
 	return l;
+}
+
+// total order on doubles as unsigned integers (larger double <-> larger key); 0 is below every number
+__device__ __forceinline__ unsigned long long prune_key(double w)
+{
+	unsigned long long b = (unsigned long long) __double_as_longlong(w);
+	return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// bitonic sort of n (power of two) entries, largest key first
+__device__ __forceinline__ void prune_bitonic(unsigned long long* key, int* slot, int n, int tid)
+{
+	for (int k = 2; k <= n; k <<= 1) {
+		for (int j = k >> 1; j > 0; j >>= 1) {
+			for (int t = tid; t < (n >> 1); t += 256) {
+				int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+				int q = i | j;
+				unsigned long long a = key[i], b = key[q];
+				bool desc = (i & k) == 0;
+				if (desc ? (a < b) : (a > b)) {
+					key[i] = b; key[q] = a;
+					int s = slot[i]; slot[i] = slot[q]; slot[q] = s;
+				}
+			}
+			__syncthreads();
+		}
+	}
 }
 
 __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const StepBufs a, int cutcap)
 {
 	extern __shared__ __align__(16) double smem[];
 	const PruneLds lay = prune_lds(cutcap);
-	const int cc = (cutcap + 1) & ~1;
+	const int cc = (cutcap + 1) & ~1, NS = lay.NS;
 	double* sw    = smem + lay.sw;                         // [cut] sorted weights
 	double* sm    = smem + lay.sm;                         // [3][cc] sorted means
 	int*    order = (int*) (smem + lay.order);             // [cut] emit slot of rank r
-	double* kw    = smem + lay.x;                          // key tile: weights
-	int*    ki    = (int*) (kw + PRUNE_KEYTILE);           //           canonical indices
-	unsigned long long* nbr = (unsigned long long*) (smem + lay.x);   // [cut][2]: count + up to 7 close later rows
-	int*    owner = (int*) (nbr + 2 * cc);                 // [cut] row that absorbed k (k itself for a survivor)
+	unsigned long long* skey = (unsigned long long*) (smem + lay.x);   // [NS] sort keys
+	int*    sslot = (int*) (skey + NS);                    // [NS] emit slots
+	unsigned long long* nbr = (unsigned long long*) (smem + lay.x);    // [cut][2]: count + up to 7 close later rows
+	int*    owner = (int*) (nbr + 2 * cc);                 // [cut] row that absorbed k (-1: none)
+	float*  smf   = (float*) (owner + cc);                 // [3][cc] centred means, float32
+	int*    absb  = (int*) (smf + 3 * cc + (cc & 1));      // [64] absorbed bits as left by the resolving wave
 	int*    scan  = (int*) (smem + lay.scan);              // [264]
 
 	const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -62,39 +98,51 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	const size_t eb = (size_t) p * a.ecap;
 	const int cut = min(min(prm.maxq, ne), cutcap);   // weightcut: every emitted weight is already >= MinWeight
 
-	// ---- A. rank by (weight desc, canonical index asc) == the reference's sort made stable
-	for (int g0 = 0; g0 < ne; g0 += 1024) {           // this thread's entries g0 + u*256 + tid, u < 4
-		double we[4];
-		int    ie[4], rank[4];
-#pragma unroll
-		for (int u = 0; u < 4; u++) {
-			int e = g0 + u * 256 + tid;
-			we[u] = (e < ne) ? a.emit_w[eb + e] : 0.0;
-			ie[u] = (e < ne) ? a.emit_idx[eb + e] : 0x7fffffff;
-			rank[u] = 0;
-		}
-		for (int t0 = 0; t0 < ne; t0 += PRUNE_KEYTILE) {
+	// ---- A. order by (weight desc, canonical index asc)
+	{
+		int n = 2;
+		while (n < ne && n < NS) n <<= 1;                 // width of the first pass
+		int taken = 0;                                    // emitted entries consumed so far
+		bool first = true;
+		while (first || taken < ne) {
+			// first pass: fill [0, n); later passes (n == NS): refill the worse half [n/2, n)
+			const int from = first ? 0 : (n >> 1);
+			for (int t = from + tid; t < n; t += 256) {
+				int e = taken + (t - from);
+				bool in = e < ne;
+				skey[t]  = in ? prune_key(a.emit_w[eb + e]) : 0ull;
+				sslot[t] = in ? e : -1;
+			}
+			taken += n - from;
+			first = false;
 			__syncthreads();
-			for (int j = tid; j < PRUNE_KEYTILE && t0 + j < ne; j += 256) {
-				kw[j] = a.emit_w[eb + t0 + j];
-				ki[j] = a.emit_idx[eb + t0 + j];
-			}
-			__syncthreads();
-			int jend = min(PRUNE_KEYTILE, ne - t0);
-			for (int j = 0; j < jend; j++) {
-				double wj = kw[j];
-				int    ij = ki[j];
-#pragma unroll
-				for (int u = 0; u < 4; u++) rank[u] += (wj > we[u]) || (wj == we[u] && ij < ie[u]);
+			prune_bitonic(skey, sslot, n, tid);
+			// equal weights: the reference's list order decides (canonical index ascending)
+			int tie = 0;
+			for (int r = tid; r + 1 < n; r += 256) tie |= (skey[r] == skey[r + 1] && sslot[r] >= 0 && sslot[r + 1] >= 0);
+			if (__syncthreads_or(tie)) {
+				if (tid == 0) {
+					int r = 0;
+					while (r < n && sslot[r] >= 0) {
+						int e = r + 1;
+						while (e < n && sslot[e] >= 0 && skey[e] == skey[r]) e++;
+						for (int x = r + 1; x < e; x++) {   // insertion sort of the run by canonical index
+							int s = sslot[x];
+							int ix = a.emit_idx[eb + s];
+							int y = x - 1;
+							while (y >= r && a.emit_idx[eb + sslot[y]] > ix) { sslot[y + 1] = sslot[y]; y--; }
+							sslot[y + 1] = s;
+						}
+						r = e;
+					}
+				}
+				__syncthreads();
 			}
 		}
-#pragma unroll
-		for (int u = 0; u < 4; u++) {
-			int e = g0 + u * 256 + tid;
-			if (e < ne && rank[u] < cut) {
-				order[rank[u]] = e;
-				sw[rank[u]]    = we[u];
-			}
+		for (int r = tid; r < cut; r += 256) {
+			int s = sslot[r];
+			order[r] = s;
+			sw[r]    = a.emit_w[eb + s];
 		}
 	}
 	__syncthreads();
@@ -102,42 +150,78 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 		const double* rec = a.emit_rec + (eb + order[r]) * 9;
 		sm[r] = rec[0]; sm[cc + r] = rec[1]; sm[2 * cc + r] = rec[2];
 	}
-	__syncthreads();   // the key tile is dead from here on: nbr / owner take its place
-
-	// ---- B. all closeness tests, row per thread
-	for (int rb = 0; rb * 256 < cut; rb++) {
-		const int  i = rb * 256 + tid;
-		const bool valid = i < cut;
-		double Pi[6] = {1, 0, 0, 1, 0, 1}, m0 = 0, m1 = 0, m2 = 0, bound = -1.0;
-		if (valid) {
-			const double* rec = a.emit_rec + (eb + order[i]) * 9;
-			double P[6], det;
+	__syncthreads();   // the sort buffers are dead from here on: nbr / owner / smf take their place
+	// centre the means (any point will do) for the float32 copy; largest centred coordinate for its rounding bound
+	const double ctr0 = (cut > 0) ? sm[0] : 0, ctr1 = (cut > 0) ? sm[cc] : 0, ctr2 = (cut > 0) ? sm[2 * cc] : 0;
+	double cmax = 0;
+	for (int r = tid; r < cut; r += 256) {
+		double c0 = sm[r] - ctr0, c1 = sm[cc + r] - ctr1, c2 = sm[2 * cc + r] - ctr2;
+		smf[r] = (float) c0; smf[cc + r] = (float) c1; smf[2 * cc + r] = (float) c2;
+		cmax = fmax(cmax, fmax(fabs(c0), fmax(fabs(c1), fabs(c2))));
+		owner[r] = -1;
+	}
 #pragma unroll
-			for (int t = 0; t < 6; t++) P[t] = rec[3 + t];
-			inv_sym3(P, Pi, det);
-			m0 = sm[i]; m1 = sm[cc + i]; m2 = sm[2 * cc + i];
-			// Sylvester: only a positive definite P_i admits the Euclidean bound
-			bool pd = P[0] > 0 && (P[0] * P[3] - P[1] * P[1]) > 0 && det > 0;
-			bound = pd ? prm.merge_thr2 * (P[0] + P[3] + P[5]) * (1.0 + 1e-6) : INFINITY;
+	for (int o = 32; o > 0; o >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, o, 64));
+	if (lane == 0) { scan[wv] = __double2hiint(cmax); scan[4 + wv] = __double2loint(cmax); }
+	__syncthreads();
+	double Rmax = 0;
+	for (int q = 0; q < 4; q++) Rmax = fmax(Rmax, __hiloint2double(scan[q], scan[4 + q]));
+	__syncthreads();
+
+	// ---- B. all closeness tests, two rows per thread
+	for (int rb = 0; rb * 512 < cut; rb++) {
+		int    row[2];
+		bool   valid[2];
+		double Pi[2][6], md[2][3];
+		float  mf[2][3], boundf[2];
+		unsigned long long lo[2] = {0, 0}, hi[2] = {0, 0};
+		int cnt[2] = {0, 0};
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			row[h]   = rb * 512 + h * 256 + tid;
+			valid[h] = row[h] < cut;
+			boundf[h] = -1.0f;
+#pragma unroll
+			for (int t = 0; t < 6; t++) Pi[h][t] = 0;
+#pragma unroll
+			for (int t = 0; t < 3; t++) { md[h][t] = 0; mf[h][t] = 0; }
+			if (valid[h]) {
+				const double* rec = a.emit_rec + (eb + order[row[h]]) * 9;
+				double P[6], det;
+#pragma unroll
+				for (int t = 0; t < 6; t++) P[t] = rec[3 + t];
+				inv_sym3(P, Pi[h], det);
+#pragma unroll
+				for (int t = 0; t < 3; t++) { md[h][t] = sm[t * cc + row[h]]; mf[h][t] = smf[t * cc + row[h]]; }
+				// Sylvester: only a positive definite P_i admits the Euclidean bound
+				bool pd = P[0] > 0 && (P[0] * P[3] - P[1] * P[1]) > 0 && det > 0;
+				double rad = sqrt(prm.merge_thr2 * (P[0] + P[3] + P[5])) * 1.001 + 2e-6 * Rmax;   // + float32 rounding of both means
+				boundf[h] = pd ? (float) (rad * rad * 1.001) : INFINITY;
+			}
 		}
-		unsigned long long lo = 0, hi = 0;
-		int cnt = 0;
-		const int kstart = rb * 256 + wv * 64 + 1;   // rows of this wave are >= kstart - 1
+		const int kstart = rb * 512 + wv * 64 + 1;   // rows of this wave are >= kstart - 1
 		for (int k = kstart; k < cut; k++) {
-			double d0 = m0 - sm[k], d1 = m1 - sm[cc + k], d2 = m2 - sm[2 * cc + k];
-			double sq = d0 * d0 + d1 * d1 + d2 * d2;
-			if (valid && k > i && sq <= bound) {
-				if (quad_sym(Pi, d0, d1, d2) < prm.merge_thr2) {   // Gaussian.SquareMahalanobis(b.Mean) < threshold^2
-					if (cnt < 3) lo |= (unsigned long long) k << (16 * (cnt + 1));
-					else if (cnt < PRUNE_NBR) hi |= (unsigned long long) k << (16 * (cnt - 3));
-					cnt++;
+			float k0 = smf[k], k1 = smf[cc + k], k2 = smf[2 * cc + k];
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				float e0 = mf[h][0] - k0, e1 = mf[h][1] - k1, e2 = mf[h][2] - k2;
+				float sq = e0 * e0 + e1 * e1 + e2 * e2;
+				if (k > row[h] && sq <= boundf[h]) {
+					double d0 = md[h][0] - sm[k], d1 = md[h][1] - sm[cc + k], d2 = md[h][2] - sm[2 * cc + k];
+					if (quad_sym(Pi[h], d0, d1, d2) < prm.merge_thr2) {   // Gaussian.SquareMahalanobis(b.Mean) < threshold^2
+						if (cnt[h] < 3) lo[h] |= (unsigned long long) k << (16 * (cnt[h] + 1));
+						else if (cnt[h] < PRUNE_NBR) hi[h] |= (unsigned long long) k << (16 * (cnt[h] - 3));
+						cnt[h]++;
+					}
 				}
 			}
 		}
-		if (valid) {
-			nbr[2 * i]     = lo | (unsigned long long) min(cnt, 0xffff);
-			nbr[2 * i + 1] = hi;
-			owner[i]       = -1;
+#pragma unroll
+		for (int h = 0; h < 2; h++) {
+			if (valid[h]) {
+				nbr[2 * row[h]]     = lo[h] | (unsigned long long) min(cnt[h], 0xffff);
+				nbr[2 * row[h] + 1] = hi[h];
+			}
 		}
 	}
 	__syncthreads();
@@ -146,43 +230,55 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	if (wv == 0) {
 		unsigned int absorbed = 0;                  // bit s of lane l <-> row s*64 + l
 		const int nslots = (cut + 63) >> 6;
-		unsigned long long nlo = (cut > 0) ? nbr[0] : 0, nhi = (cut > 0) ? nbr[1] : 0;
-		for (int i = 0; i < cut; i++) {
-			const unsigned long long lo = nlo, hi = nhi;
-			if (i + 1 < cut) { nlo = nbr[2 * (i + 1)]; nhi = nbr[2 * (i + 1) + 1]; }   // independent of the state: prefetched
-			unsigned int om = (unsigned int) __builtin_amdgcn_readlane((int) absorbed, i & 63);
-			if ((om >> (i >> 6)) & 1u) continue;
-			if (lane == 0) owner[i] = i;
-			const int cnt = (int) (lo & 0xffff);
-			if (cnt <= PRUNE_NBR) {
-				for (int c = 0; c < cnt; c++) {
-					int k = (int) (((c < 3) ? (lo >> (16 * (c + 1))) : (hi >> (16 * (c - 3)))) & 0xffff);
-					unsigned int km = (unsigned int) __builtin_amdgcn_readlane((int) absorbed, k & 63);
-					if (!((km >> (k >> 6)) & 1u)) {
-						if (lane == (k & 63)) absorbed |= 1u << (k >> 6);
-						if (lane == 0) owner[k] = i;
+		for (int base = 0; base < cut; base += 64) {
+			const int s0 = base >> 6;
+			// this lane holds the record of row base + lane
+			unsigned long long vlo = 0, vhi = 0;
+			if (base + lane < cut) { vlo = nbr[2 * (base + lane)]; vhi = nbr[2 * (base + lane) + 1]; }
+			const int lolo = (int) (unsigned int) vlo, lohi = (int) (unsigned int) (vlo >> 32);
+			const int hilo = (int) (unsigned int) vhi, hihi = (int) (unsigned int) (vhi >> 32);
+			const int lend = min(64, cut - base);
+			for (int l = 0; l < lend; l++) {
+				const int i = base + l;
+				unsigned int om = (unsigned int) __builtin_amdgcn_readlane((int) absorbed, l);
+				if ((om >> s0) & 1u) continue;
+				const unsigned int w0 = (unsigned int) __builtin_amdgcn_readlane(lolo, l);
+				const int cnt = (int) (w0 & 0xffff);
+				if (cnt == 0) continue;
+				if (cnt <= PRUNE_NBR) {
+					const unsigned long long lo = ((unsigned long long) (unsigned int) __builtin_amdgcn_readlane(lohi, l) << 32) | w0;
+					const unsigned long long hi = ((unsigned long long) (unsigned int) __builtin_amdgcn_readlane(hihi, l) << 32) |
+					                              (unsigned int) __builtin_amdgcn_readlane(hilo, l);
+					for (int c = 0; c < cnt; c++) {
+						int k = (int) (((c < 3) ? (lo >> (16 * (c + 1))) : (hi >> (16 * (c - 3)))) & 0xffff);
+						unsigned int km = (unsigned int) __builtin_amdgcn_readlane((int) absorbed, k & 63);
+						if (!((km >> (k >> 6)) & 1u)) {
+							if (lane == (k & 63)) absorbed |= 1u << (k >> 6);
+							if (lane == 0) owner[k] = i;
+						}
 					}
 				}
-			}
-			else {
-				// more close rows than the list holds: re-test row i against every later row, 64 at a time
-				const double* rec = a.emit_rec + (eb + order[i]) * 9;
-				double P[6], Pi[6], det;
+				else {
+					// more close rows than the list holds: re-test row i against every later row, 64 at a time
+					const double* rec = a.emit_rec + (eb + order[i]) * 9;
+					double P[6], Pi[6], det;
 #pragma unroll
-				for (int t = 0; t < 6; t++) P[t] = rec[3 + t];
-				inv_sym3(P, Pi, det);
-				double m0 = sm[i], m1 = sm[cc + i], m2 = sm[2 * cc + i];
-				for (int s = i >> 6; s < nslots; s++) {
-					int k = s * 64 + lane;
-					if (k > i && k < cut && !((absorbed >> s) & 1u)) {
-						if (quad_sym(Pi, m0 - sm[k], m1 - sm[cc + k], m2 - sm[2 * cc + k]) < prm.merge_thr2) {
-							absorbed |= 1u << s;
-							owner[k] = i;
+					for (int t = 0; t < 6; t++) P[t] = rec[3 + t];
+					inv_sym3(P, Pi, det);
+					double m0 = sm[i], m1 = sm[cc + i], m2 = sm[2 * cc + i];
+					for (int s = i >> 6; s < nslots; s++) {
+						int k = s * 64 + lane;
+						if (k > i && k < cut && !((absorbed >> s) & 1u)) {
+							if (quad_sym(Pi, m0 - sm[k], m1 - sm[cc + k], m2 - sm[2 * cc + k]) < prm.merge_thr2) {
+								absorbed |= 1u << s;
+								owner[k] = i;
+							}
 						}
 					}
 				}
 			}
 		}
+		absb[lane] = (int) absorbed;
 	}
 	__syncthreads();
 
@@ -190,7 +286,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	int nsurv_before = 0;
 	for (int r0 = 0; r0 < cut; r0 += 256) {
 		const int  i = r0 + tid;
-		const bool surv = i < cut && owner[i] == i;
+		const bool surv = i < cut && !(((unsigned int) absb[i & 63] >> (i >> 6)) & 1u);
 		unsigned long long bal = __ballot(surv);
 		if (lane == 0) scan[wv] = __popcll(bal);
 		__syncthreads();
