@@ -9,7 +9,7 @@ from .abi import PhdParams
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO_PATH = os.path.join(CSRC, "libphdhip.so")
-SOURCES = ["phdhip.hip", "phd_kernels.h", "phd_prune.h", "phd_alpha.h", "phd_resample.h", "phd_device.h"]
+SOURCES = ["phdhip.hip", "phd_kernels.h", "phd_correct.h", "phd_prune.h", "phd_alpha.h", "phd_resample.h", "phd_device.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 
 dp = C.POINTER(C.c_double)

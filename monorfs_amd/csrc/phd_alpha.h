@@ -353,7 +353,7 @@ __host__ __device__ inline AlphaLds alpha_lds(int MP, int ncap)
 	AlphaLds l;
 	l.zs   = 0;
 	l.red  = l.zs + 3 * MP;
-	l.lm   = l.red + 256;
+	l.lm   = l.red + 256 + EXPTAB_N;   // red[256], exp table[32]
 	l.pick = l.lm + 3 * JL;
 	l.scr  = l.pick + JL / 2;
 	l.p1_keyw = l.scr;
@@ -362,7 +362,7 @@ __host__ __device__ inline AlphaLds alpha_lds(int MP, int ncap)
 	l.p1_sortsrc = l.p1_dw + JL;
 	int ph1 = l.p1_sortsrc + (ncap + JL + 1) / 2 - l.scr;
 	l.p2_tile = l.scr;
-	l.p2_part = l.p2_tile + 11 * TILE;
+	l.p2_part = l.p2_tile + 12 * TILE;
 	int ph2 = l.p2_part + (JL / 64) * 256 - l.scr;
 	l.p3_zh = l.scr;
 	l.p3_pdj = l.p3_zh + 3 * JL;
@@ -395,6 +395,7 @@ __global__ __launch_bounds__(256) void k_weight_alpha(const DevParams prm, const
 	const AlphaLds lay = alpha_lds(MP, ncap);
 	double* zs   = smem + lay.zs;          // [MP][3] measurements
 	double* red  = smem + lay.red;         // [256] reduction scratch
+	double* etab = red + 256;              // [32] 2^(j/32)
 	__shared__ int s_J, s_changed, s_nroots, s_big;
 	__shared__ double s_ccount, s_total;
 
@@ -409,6 +410,7 @@ __global__ __launch_bounds__(256) void k_weight_alpha(const DevParams prm, const
 	const PoseD pose = load_pose(bin.poses + (size_t) p * 7);
 
 	for (int k = tid; k < MP * 3; k += 256) zs[k] = (k < M * 3) ? a.z[k] : 0.0;
+	exp_tab_init(etab, tid);
 
 	// ---- phase 1: BestMapEstimate (Map.cs:119-142)
 	double* keyw    = smem + lay.p1_keyw;              // [ncap] weights in map order
@@ -494,7 +496,7 @@ __global__ __launch_bounds__(256) void k_weight_alpha(const DevParams prm, const
 	// landmarks and the 64 / LJ lane groups take different components, then the groups are summed.
 	double plog_part = 0, clog_part = 0, pcount_part = 0;
 	{
-		double* tile = smem + lay.p2_tile;   // [11][TILE]
+		double* tile = smem + lay.p2_tile;   // [TILE][12]: mean, inverse covariance, weight, multiplier
 		const int JB = (J + 63) >> 6;
 		for (int c = tid; c < n; c += 256) pcount_part += vin.w[sbi + c];
 		for (int src = 0; src < 2; src++) {
@@ -526,12 +528,13 @@ __global__ __launch_bounds__(256) void k_weight_alpha(const DevParams prm, const
 						for (int t = 0; t < 6; t++) P[t] = prm.birthP[t];
 					}
 					inv_sym3(P, Pi, det);
+					double* tt = tile + tid * 12;
 #pragma unroll
-					for (int t = 0; t < 3; t++) tile[t * TILE + tid] = m[t];
+					for (int t = 0; t < 3; t++) tt[t] = m[t];
 #pragma unroll
-					for (int t = 0; t < 6; t++) tile[(3 + t) * TILE + tid] = Pi[t];
-					tile[9 * TILE + tid]  = w;
-					tile[10 * TILE + tid] = PHD_INV_2PI / sqrt(fabs(det));
+					for (int t = 0; t < 6; t++) tt[3 + t] = Pi[t];
+					tt[9]  = w;
+					tt[10] = PHD_INV_2PI / sqrt(fabs(det));
 				}
 				__syncthreads();
 				const int cend = min(TILE, total - c0);
@@ -542,14 +545,24 @@ __global__ __launch_bounds__(256) void k_weight_alpha(const DevParams prm, const
 					const bool jv = jl < rem;
 					const int  j  = jb * 64 + jl;
 					const double x0 = jv ? lm[j] : 0, x1 = jv ? lm[JS + j] : 0, x2 = jv ? lm[2 * JS + j] : 0;
-					double acc = 0;
-					for (int cc = wv * G + g; cc < cend; cc += 4 * G) {
-						double d0 = x0 - tile[cc], d1 = x1 - tile[TILE + cc], d2 = x2 - tile[2 * TILE + cc];
+					// w * (mult * exp(-d^T Pinv d / 2)) of component cc at this lane's landmark (Map.cs:198)
+					auto dens = [&](int cc) {
+						const double* tt = tile + cc * 12;
+						double d0 = x0 - tt[0], d1 = x1 - tt[1], d2 = x2 - tt[2];
 						double Pi[6];
 #pragma unroll
-						for (int t = 0; t < 6; t++) Pi[t] = tile[(3 + t) * TILE + cc];
-						acc += tile[9 * TILE + cc] * (tile[10 * TILE + cc] * exp(-0.5 * quad_sym(Pi, d0, d1, d2)));
+						for (int t = 0; t < 6; t++) Pi[t] = tt[3 + t];
+						return tt[9] * (tt[10] * exp_neg(-0.5 * quad_sym(Pi, d0, d1, d2), etab));
+					};
+					double acc = 0, acc2 = 0;
+					int cc = wv * G + g;
+					const int step = 4 * G;
+					for (; cc + step < cend; cc += 2 * step) {   // two independent components per trip
+						acc  += dens(cc);
+						acc2 += dens(cc + step);
 					}
+					if (cc < cend) acc += dens(cc);
+					acc += acc2;
 					part[(jb * 4 + wv) * 64 + lane] += acc;   // own slot
 				}
 				__syncthreads();

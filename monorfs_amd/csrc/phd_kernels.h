@@ -5,7 +5,8 @@
 // (w, mean x/y/z, covariance xx/xy/xz/yy/yz/zz), each [particle][slot], so a wavefront reads 64
 // consecutive components of one particle as one 512-B line per plane.
 //
-//   k_predict_correct : PredictConditional + CorrectConditional (+ the MinWeight cut of PruneModel)
+//   k_explore, k_measure, k_correct, k_emit_finish (phd_correct.h) : PredictConditional + CorrectConditional
+//                       (+ the MinWeight cut of PruneModel)
 //   k_prune_merge     : PruneModel (sort by weight, MaxQuantity cap, greedy merge)
 //   k_weight_alpha    : WeightAlpha = BestMapEstimate + mixture densities + SetLogLikelihood
 //   k_normalise_resample, k_gather_particles : particle weights, BestParticle, systematic resampling
@@ -62,6 +63,14 @@ struct StepBufs {
 	int*    flags;       // [1]
 	struct MurtyNodes* murty;   // [P] workspace of the big-cluster solver
 	double* jscratch;    // [P] landmark-indexed arrays of k_weight_alpha when the map estimate outgrows LDS
+	// per-component measurement quantities of the predicted mixture: 18 planes of [Pcap][cmcap]
+	double* cm;
+	size_t  cmplane;     // doubles per plane = Pcap * cmcap
+	int     cmcap;       // cap + Mcap
+	// (component, measurement) pairs that reach MinWeight, queued for the Kalman update
+	int*    pair_ck;     // [P][ecap][2]
+	double* pair_w;      // [P][ecap]
+	int*    pair_count;  // [P]
 };
 
 __device__ __forceinline__ MixView bank_view(const StepBufs& a, int role)
@@ -79,287 +88,7 @@ __device__ __forceinline__ MixView bank_view(const StepBufs& a, int role)
 
 #define TILE 256   // components staged per LDS tile
 
-// =================================================================================================
-// k_predict_correct
-//
-// LDS: the measurement block (raw + mapped into world space), per-wave partial sums, and one tile
-// of per-component quantities that the "measurement-in-lanes" loops read as broadcasts.
-// Mapping: per-component work (Jacobian, innovation covariance and its inverse, detection
-// probability) is done component-per-lane; every (component, measurement) pair is then visited
-// measurement-per-lane with the component broadcast from LDS, so the per-measurement sums
-// (explored density, PHD weight sum) are private to a lane and need no cross-lane reduction inside
-// the loop; the four waves split the components of a tile and are combined once, in wave order.
-// =================================================================================================
-template <int ZB>
-__global__ __launch_bounds__(256) void k_predict_correct(const DevParams prm, const StepBufs a)
-{
-	constexpr int MP = ZB * 64;
-	extern __shared__ __align__(16) double smem[];
-	double* zs    = smem;              // [MP][3]
-	double* zmap  = zs + 3 * MP;       // [MP][3]
-	double* part  = zmap + 3 * MP;     // [4][MP]
-	double* denom = part + 4 * MP;     // [MP]
-	double* tile  = denom + MP;        // [18][TILE]
-	int*    born  = (int*) (tile + 18 * TILE);   // [MP] flags, then compacted list
-	int*    cnt   = born + MP;         // [0] births, [1] emitted
-
-	const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	const int M = a.M, cap = a.cap;
-	const MixView vin = bank_view(a, SEL_IN);
-	const Bank& bin  = a.bank[a.sel[SEL_IN]];
-	const Bank& bout = a.bank[a.sel[SEL_OUT]];
-	const int n = vin.count[p];
-	const size_t sb = (size_t) p * cap;
-	const PoseD pose = load_pose(bin.poses + (size_t) p * 7);
-	double rq[9];
-	conj_matrix(pose, rq);
-	// the particle keeps its pose and (until the reweight kernel runs) its weight in the output bank
-	if (tid < 7) bout.poses[(size_t) p * 7 + tid] = bin.poses[(size_t) p * 7 + tid];
-	if (tid == 7) bout.weights[p] = bin.weights[p];
-
-	for (int k = tid; k < MP; k += 256) {
-		double z[3] = {0, 0, 1}, x[3] = {0, 0, 0};
-		if (k < M) {
-			z[0] = a.z[k * 3]; z[1] = a.z[k * 3 + 1]; z[2] = a.z[k * 3 + 2];
-			measure_to_map(prm, pose, z, x);
-		}
-		zs[k * 3] = z[0]; zs[k * 3 + 1] = z[1]; zs[k * 3 + 2] = z[2];
-		zmap[k * 3] = x[0]; zmap[k * 3 + 1] = x[1]; zmap[k * 3 + 2] = x[2];
-	}
-	if (tid < 2) cnt[tid] = 0;
-	__syncthreads();
-
-	// the measurements this lane owns
-	double zx[ZB], zy[ZB], zr[ZB], wx[ZB], wy[ZB], wz[ZB];
-	bool   zv[ZB];
-#pragma unroll
-	for (int b = 0; b < ZB; b++) {
-		int k = b * 64 + lane;
-		zv[b] = k < M;
-		zx[b] = zs[k * 3]; zy[b] = zs[k * 3 + 1]; zr[b] = zs[k * 3 + 2];
-		wx[b] = zmap[k * 3]; wy[b] = zmap[k * 3 + 1]; wz[b] = zmap[k * 3 + 2];
-	}
-
-	// ---- PredictConditional: Explored(model, MeasureToMap(z)) on the PRIOR map (PHDNavigator.cs:806-811)
-	{
-		double acc[ZB];
-#pragma unroll
-		for (int b = 0; b < ZB; b++) acc[b] = 0;
-		bool wavedone = false;
-		for (int c0 = 0; c0 < n; c0 += TILE) {
-			int c = c0 + tid;
-			if (c < n) {
-				double P[6], Pi[6], det;
-#pragma unroll
-				for (int t = 0; t < 6; t++) P[t] = vin.P[t][sb + c];
-				inv_sym3(P, Pi, det);
-				tile[0 * TILE + tid] = vin.m[0][sb + c];
-				tile[1 * TILE + tid] = vin.m[1][sb + c];
-				tile[2 * TILE + tid] = vin.m[2][sb + c];
-#pragma unroll
-				for (int t = 0; t < 6; t++) tile[(3 + t) * TILE + tid] = Pi[t];
-				tile[9 * TILE + tid]  = vin.w[sb + c];
-				tile[10 * TILE + tid] = PHD_INV_2PI / sqrt(fabs(det));
-			}
-			__syncthreads();
-			int cend = min(TILE, n - c0);
-			for (int cc = wv; cc < cend && !wavedone; cc += 4) {
-				double m0 = tile[cc], m1 = tile[TILE + cc], m2 = tile[2 * TILE + cc];
-				double Pi[6];
-#pragma unroll
-				for (int t = 0; t < 6; t++) Pi[t] = tile[(3 + t) * TILE + cc];
-				double w = tile[9 * TILE + cc], mult = tile[10 * TILE + cc];
-				bool open = false;
-#pragma unroll
-				for (int b = 0; b < ZB; b++) {
-					double d0 = wx[b] - m0, d1 = wy[b] - m1, d2 = wz[b] - m2;
-					double sq = d0 * d0 + d1 * d1 + d2 * d2;
-					if (zv[b] && gate_near(prm.gate_metric, sq, prm.r_explore)) {
-						acc[b] += w * (mult * exp(-0.5 * quad_sym(Pi, d0, d1, d2)));   // Map.cs:216
-					}
-					open |= zv[b] && !(acc[b] >= prm.expl_thr);
-				}
-				// every term is >= 0: once this wave's partial sum of a measurement reaches the threshold the
-				// full sum does too, so a wave whose measurements are all explored can stop (NaNs keep it going)
-				wavedone = __ballot(open) == 0;
-			}
-			if (__syncthreads_and(wavedone)) break;
-		}
-#pragma unroll
-		for (int b = 0; b < ZB; b++) part[wv * MP + b * 64 + lane] = acc[b];
-		__syncthreads();
-		for (int k = tid; k < MP; k += 256) {
-			double dens = part[k] + part[MP + k] + part[2 * MP + k] + part[3 * MP + k];
-			born[k] = (k < M) && !(dens >= prm.expl_thr);
-		}
-		__syncthreads();
-		if (tid == 0) {   // births keep measurement order (PHDNavigator.cs:814-816)
-			int nb = 0;
-			for (int k = 0; k < M; k++) {
-				if (born[k]) {
-					born[nb] = k;   // nb <= k: in-place compaction
-					a.born_k[(size_t) p * a.Mcap + nb] = k;
-					a.born_mean[((size_t) p * a.Mcap + nb) * 3]     = zmap[k * 3];
-					a.born_mean[((size_t) p * a.Mcap + nb) * 3 + 1] = zmap[k * 3 + 1];
-					a.born_mean[((size_t) p * a.Mcap + nb) * 3 + 2] = zmap[k * 3 + 2];
-					nb++;
-				}
-			}
-			cnt[0] = nb;
-			a.born_count[p] = nb;
-		}
-		__syncthreads();
-	}
-	const int np = n + cnt[0];   // predicted = prior + births
-
-	// component c of the predicted mixture
-	auto load_comp = [&](int c, double& w, double m[3], double P[6]) {
-		if (c < n) {
-			w = vin.w[sb + c];
-#pragma unroll
-			for (int t = 0; t < 3; t++) m[t] = vin.m[t][sb + c];
-#pragma unroll
-			for (int t = 0; t < 6; t++) P[t] = vin.P[t][sb + c];
-		}
-		else {
-			int k = born[c - n];
-			w = prm.birthw;
-			m[0] = zmap[k * 3]; m[1] = zmap[k * 3 + 1]; m[2] = zmap[k * 3 + 2];
-#pragma unroll
-			for (int t = 0; t < 6; t++) P[t] = prm.birthP[t];
-		}
-	};
-
-	auto emit = [&](bool flag, double w, int idx, const double m[3], const double P[6]) {
-		unsigned long long bal = __ballot(flag);
-		if (bal == 0) return;
-		int base = 0;
-		int first = __ffsll((long long) bal) - 1;
-		if (lane == first) base = atomicAdd(&cnt[1], __popcll(bal));
-		base = __shfl(base, first, 64);
-		if (flag) {
-			int slot = base + __popcll(bal & lanemask_lt());
-			if (slot < a.ecap) {
-				size_t e = (size_t) p * a.ecap + slot;
-				a.emit_w[e]   = w;
-				a.emit_idx[e] = idx;
-				double* r = a.emit_rec + e * 9;
-				r[0] = m[0]; r[1] = m[1]; r[2] = m[2];
-#pragma unroll
-				for (int t = 0; t < 6; t++) r[3 + t] = P[t];
-			}
-		}
-	};
-
-	// ---- CorrectConditional, two sweeps over the predicted mixture
-	//   sweep 0: misdetection copies (:837-840) and weightsum[z] = sum over near components of PD w q(z) (:886-890)
-	//   sweep 1: emission of w' = PD w q / (kappa + weightsum) with m', P' (:892-902), for w' >= MinWeight
-	double wsum[ZB];
-#pragma unroll
-	for (int b = 0; b < ZB; b++) wsum[b] = 0;
-
-	for (int sweep = 0; sweep < 2; sweep++) {
-		for (int c0 = 0; c0 < np; c0 += TILE) {
-			int  c = c0 + tid;
-			bool valid = c < np;
-			bool mis = false;
-			double w = 0, m[3] = {0, 0, 0}, P[6] = {1, 0, 0, 1, 0, 1}, wm = 0;
-			if (valid) {
-				load_comp(c, w, m, P);
-				CompMeas cm;
-				comp_measure(prm, pose, rq, m, P, cm);
-#pragma unroll
-				for (int t = 0; t < 3; t++) tile[t * TILE + tid] = cm.zh[t];
-#pragma unroll
-				for (int t = 0; t < 9; t++) tile[(3 + t) * TILE + tid] = cm.Sinv[t];
-				double pdw = cm.pd * w;
-				tile[12 * TILE + tid] = cm.qmult;
-				tile[13 * TILE + tid] = pdw;
-#pragma unroll
-				for (int t = 0; t < 3; t++) tile[(14 + t) * TILE + tid] = m[t];
-				// no pair can reach MinWeight unless  PD w mult exp(-d2/2) >= MinWeight * kappa
-				double dc = 2.0 * (log(pdw * cm.qmult) - prm.emit_log_floor) + 1.0;
-				tile[17 * TILE + tid] = isinf(prm.emit_log_floor) ? INFINITY : dc;
-				wm  = (1 - cm.pd) * w;
-				mis = !(wm < prm.minw);
-			}
-			if (sweep == 0) emit(mis, wm, c, m, P);
-			__syncthreads();
-			int cend = min(TILE, np - c0);
-			for (int cc = wv; cc < cend; cc += 4) {
-				double zh0 = tile[cc], zh1 = tile[TILE + cc], zh2 = tile[2 * TILE + cc];
-				double Si[9];
-#pragma unroll
-				for (int t = 0; t < 9; t++) Si[t] = tile[(3 + t) * TILE + cc];
-				double qmult = tile[12 * TILE + cc], pdw = tile[13 * TILE + cc];
-				double m0 = tile[14 * TILE + cc], m1 = tile[15 * TILE + cc], m2 = tile[16 * TILE + cc];
-				double dc = tile[17 * TILE + cc];
-				if (sweep == 0) {
-#pragma unroll
-					for (int b = 0; b < ZB; b++) {
-						double e0 = wx[b] - m0, e1 = wy[b] - m1, e2 = wz[b] - m2;
-						double sq = e0 * e0 + e1 * e1 + e2 * e2;
-						double d2 = quad_gen(Si, zx[b] - zh0, zy[b] - zh1, zr[b] - zh2);
-						double q  = qmult * exp(-0.5 * d2);
-						if (zv[b] && gate_near(prm.gate_metric, sq, prm.r_correct)) {
-							wsum[b] += pdw * q;
-						}
-					}
-				}
-				else {
-#pragma unroll
-					for (int b = 0; b < ZB; b++) {
-						double e0 = wx[b] - m0, e1 = wy[b] - m1, e2 = wz[b] - m2;
-						double sq = e0 * e0 + e1 * e1 + e2 * e2;
-						double n0 = zx[b] - zh0, n1 = zy[b] - zh1, n2 = zr[b] - zh2;
-						double d2 = quad_gen(Si, n0, n1, n2);
-						bool cand = zv[b] && gate_near(prm.gate_metric, sq, prm.r_correct) && (d2 <= dc);
-						if (__ballot(cand)) {
-							double q   = qmult * exp(-0.5 * d2);
-							double wgt = pdw * q / denom[b * 64 + lane];   // PHDNavigator.cs:899
-							bool   em  = cand && !(wgt < prm.minw);
-							if (__ballot(em)) {
-								// the component is wave-uniform: every lane rebuilds its gain and posterior covariance
-								int cg = c0 + cc;
-								double cw, cmn[3], cP[6];
-								load_comp(cg, cw, cmn, cP);
-								CompMeas cm;
-								comp_measure(prm, pose, rq, cmn, cP, cm);
-								double K[9], Pn[6], mn[3];
-								kalman_gain(cm, K);
-								kalman_cov(cm, K, cP, Pn);
-#pragma unroll
-								for (int t = 0; t < 3; t++) {
-									mn[t] = cmn[t] + (K[t * 3] * n0 + K[t * 3 + 1] * n1 + K[t * 3 + 2] * n2);
-								}
-								int k = b * 64 + lane;
-								emit(em, wgt, np + k * np + cg, mn, Pn);
-							}
-						}
-					}
-				}
-			}
-			__syncthreads();
-		}
-		if (sweep == 0) {
-#pragma unroll
-			for (int b = 0; b < ZB; b++) part[wv * MP + b * 64 + lane] = wsum[b];
-			__syncthreads();
-			for (int k = tid; k < MP; k += 256) {
-				denom[k] = prm.kappa + (part[k] + part[MP + k] + part[2 * MP + k] + part[3 * MP + k]);
-			}
-			__syncthreads();
-		}
-	}
-	if (tid == 0) {
-		int ne = cnt[1];
-		if (ne > a.ecap) {
-			atomicOr(a.flags, PHD_FLAG_EMIT_OVERFLOW);
-			ne = a.ecap;
-		}
-		a.emit_count[p] = ne;
-	}
-}
+#include "phd_correct.h"
 
 #include "phd_prune.h"
 

@@ -45,6 +45,8 @@ struct phd_navigator {
 	int*    d_flags = nullptr; int* d_src = nullptr; int* d_info = nullptr;
 	MurtyNodes* d_murty = nullptr;
 	double* d_jscratch = nullptr;
+	double* d_cm = nullptr; int cmcap = 0;
+	int* d_pair_ck = nullptr; double* d_pair_w = nullptr; int* d_pair_count = nullptr;
 	double* d_gw = nullptr; int gwcap = 0;           // gathered weights of all ranks
 	double* d_stage = nullptr;                       // staging for uploads
 	// migration (multi-GPU resampling)
@@ -126,8 +128,11 @@ DevParams make_dev_params(const phd_params& p)
 	d.birthw     = p.birth_weight;
 	d.minw       = p.min_weight;
 	d.expl_thr   = p.exploration_threshold;
-	d.r_correct  = p.density_distance_threshold;
-	d.r_explore  = 3 * p.density_distance_threshold;
+	// Map.Near / Map.Evaluate(x, radius): Accord's KDTree compares its distance with the radius; with the
+	// squared-Euclidean metric that is |x-m|^2 <= radius, with the Euclidean one |x-m| <= radius
+	const double rc = p.density_distance_threshold, re = 3 * p.density_distance_threshold;
+	d.g2_correct = (p.gate_metric == PHD_GATE_DISABLED) ? INFINITY : (p.gate_metric == PHD_GATE_SQUARED_EUCLIDEAN ? rc : rc * rc);
+	d.g2_explore = (p.gate_metric == PHD_GATE_DISABLED) ? INFINITY : (p.gate_metric == PHD_GATE_SQUARED_EUCLIDEAN ? re : re * re);
 	d.merge_thr2 = p.merge_threshold * p.merge_threshold;
 	d.min_eff    = p.min_effective_particle;
 	double floor = p.min_weight * p.clutter_density;
@@ -148,16 +153,12 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.emit_w = nav->d_emit_w; b.emit_idx = nav->d_emit_idx; b.emit_rec = nav->d_emit_rec; b.emit_count = nav->d_emit_count;
 	b.born_count = nav->d_born_count; b.born_k = nav->d_born_k; b.born_mean = nav->d_born_mean;
 	b.alpha = nav->d_alpha; b.setll = nav->d_setll; b.flags = nav->d_flags; b.murty = nav->d_murty; b.jscratch = nav->d_jscratch;
+	b.cm = nav->d_cm; b.cmcap = nav->cmcap; b.cmplane = (size_t) nav->Pcap * nav->cmcap;
+	b.pair_ck = nav->d_pair_ck; b.pair_w = nav->d_pair_w; b.pair_count = nav->d_pair_count;
 	return b;
 }
 
 int zb_of(int M) { return M <= 64 ? 1 : (M <= 128 ? 2 : 4); }
-
-size_t lds_predict_correct(int ZB)
-{
-	int MP = ZB * 64;
-	return (size_t) (3 * MP + 3 * MP + 4 * MP + MP + 18 * TILE) * 8 + (size_t) (MP + 2) * 4;
-}
 
 
 // HIP events around every kernel launch, on the stream the kernel is launched on
@@ -183,7 +184,10 @@ void timer_end(phd_navigator* nav, const char* name)
 	nav->ntimers++;
 }
 
-const char* T_PC = "k_predict_correct";
+const char* T_EX = "k_explore";
+const char* T_ME = "k_measure";
+const char* T_CO = "k_correct";
+const char* T_EF = "k_emit_finish";
 const char* T_PM = "k_prune_merge";
 const char* T_WA = "k_weight_alpha";
 const char* T_NR = "k_normalise_resample";
@@ -193,10 +197,18 @@ template <int ZB>
 int launch_map_kernels(phd_navigator* nav, const StepBufs& b, bool with_alpha)
 {
 	const int P = nav->P;
-	HC(hipFuncSetAttribute((const void*) k_predict_correct<ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_predict_correct(ZB)));
-	timer_begin(nav, T_PC);
-	hipLaunchKernelGGL(k_predict_correct<ZB>, dim3(P), dim3(256), lds_predict_correct(ZB), nav->stream, nav->dp, b);
-	timer_end(nav, T_PC);
+	timer_begin(nav, T_EX);
+	hipLaunchKernelGGL(k_explore<ZB>, dim3(P), dim3(256), 0, nav->stream, nav->dp, b);
+	timer_end(nav, T_EX);
+	timer_begin(nav, T_ME);
+	hipLaunchKernelGGL(k_measure, dim3(P), dim3(256), 0, nav->stream, nav->dp, b);
+	timer_end(nav, T_ME);
+	timer_begin(nav, T_CO);
+	hipLaunchKernelGGL(k_correct<ZB>, dim3(P), dim3(256), 0, nav->stream, nav->dp, b);
+	timer_end(nav, T_CO);
+	timer_begin(nav, T_EF);
+	hipLaunchKernelGGL(k_emit_finish, dim3(P), dim3(256), 0, nav->stream, nav->dp, b);
+	timer_end(nav, T_EF);
 	HC(hipGetLastError());
 
 	size_t lp = (size_t) prune_lds(nav->cutcap).bytes;
@@ -410,6 +422,10 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	ok = ok && dalloc((void**) &nav->d_flags, 4) && dalloc((void**) &nav->d_info, 8);
 	ok = ok && dalloc((void**) &nav->d_src, (size_t) nav->Pcap * 4);
 	ok = ok && dalloc((void**) &nav->d_murty, (size_t) nav->Pcap * sizeof(MurtyNodes));
+	nav->cmcap = nav->cap + nav->Mcap;
+	ok = ok && dalloc((void**) &nav->d_cm, (size_t) CM_PLANES * nav->Pcap * nav->cmcap * 8);
+	ok = ok && dalloc((void**) &nav->d_pair_ck, E * 8) && dalloc((void**) &nav->d_pair_w, E * 8);
+	ok = ok && dalloc((void**) &nav->d_pair_count, (size_t) nav->Pcap * 4);
 	ok = ok && dalloc((void**) &nav->d_jscratch, (size_t) nav->Pcap * alpha_jscratch_doubles(nav->Jcap) * 8);
 	if (!ok) {
 		g_create_error = std::string("device allocation failed: ") + hipGetErrorString(hipGetLastError());
@@ -436,7 +452,7 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_sel); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
-	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
+	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_cm); hipFree(nav->d_pair_ck); hipFree(nav->d_pair_w); hipFree(nav->d_pair_count); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
 	if (nav->stream) hipStreamDestroy(nav->stream);
 	delete nav;
