@@ -362,8 +362,8 @@ __host__ __device__ inline AlphaLds alpha_lds(int MP, int ncap)
 	l.p1_sortsrc = l.p1_dw + JL;
 	int ph1 = l.p1_sortsrc + (ncap + JL + 1) / 2 - l.scr;
 	l.p2_tile = l.scr;
-	l.p2_part = l.p2_tile + 12 * TILE;
-	int ph2 = l.p2_part + (JL / 64) * 256 - l.scr;
+	l.p2_part = l.scr;
+	int ph2 = 0;
 	l.p3_zh = l.scr;
 	l.p3_pdj = l.p3_zh + 3 * JL;
 	l.p3_res = l.p3_pdj + JL;
@@ -386,7 +386,7 @@ __host__ __device__ inline size_t alpha_jscratch_doubles(int Jcap)
 }
 
 template <int ZB>
-__global__ __launch_bounds__(256) void k_weight_alpha(const DevParams prm, const StepBufs a, int ncap)
+__global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const StepBufs a, int ncap)
 {
 	constexpr int MP = ZB * 64;
 	constexpr int MW = ZB;   // 64-bit adjacency words per landmark
@@ -410,7 +410,6 @@ __global__ __launch_bounds__(256) void k_weight_alpha(const DevParams prm, const
 	const PoseD pose = load_pose(bin.poses + (size_t) p * 7);
 
 	for (int k = tid; k < MP * 3; k += 256) zs[k] = (k < M * 3) ? a.z[k] : 0.0;
-	exp_tab_init(etab, tid);
 
 	// ---- phase 1: BestMapEstimate (Map.cs:119-142)
 	double* keyw    = smem + lay.p1_keyw;              // [ncap] weights in map order
@@ -453,7 +452,6 @@ __global__ __launch_bounds__(256) void k_weight_alpha(const DevParams prm, const
 	double* pdj  = inlds ? smem + lay.p3_pdj : gj + 7 * (size_t) JS;     // [JS] detection probability of landmark j
 	double* res  = inlds ? smem + lay.p3_res : gj + 8 * (size_t) JS;     // [JS] per-cluster log-sum-exp, in cluster order
 	unsigned long long* adj = (unsigned long long*) (inlds ? smem + lay.p3_adj : gj + 9 * (size_t) JS);   // [JS][MW]
-	double* part = inlds ? smem + lay.p2_part : gj + 13 * (size_t) JS;   // [JB][4][64] partial densities
 	int* gi      = (int*) (gj + 17 * (size_t) JS);
 	int* pick    = inlds ? (int*) (smem + lay.pick) : gi;                // [JS] component picked for landmark j
 	int* dsrc    = inlds ? sortsrc + ncap : gi + JS;                     // [JS]
@@ -485,121 +483,13 @@ __global__ __launch_bounds__(256) void k_weight_alpha(const DevParams prm, const
 	__syncthreads();
 	for (int j = tid; j < J; j += 256) {
 		int c = pick[j];
-		lm[j] = vout.m[0][sbo + c]; lm[JS + j] = vout.m[1][sbo + c]; lm[2 * JS + j] = vout.m[2][sbo + c];
+		double l0 = vout.m[0][sbo + c], l1 = vout.m[1][sbo + c], l2 = vout.m[2][sbo + c];
+		lm[j] = l0; lm[JS + j] = l1; lm[2 * JS + j] = l2;
+		double* glm = a.alm + (size_t) p * 3 * a.Jcap;   // for k_alpha_density
+		glm[j] = l0; glm[a.Jcap + j] = l1; glm[2 * a.Jcap + j] = l2;
 	}
 	__threadfence_block();
 	__syncthreads();
-
-	// ---- phase 2: sum_j log v_pred(m_j), sum_j log v_corr(m_j) with v = full ungated mixture density (Map.cs:192-202)
-	// Component tiles are staged once and swept for every block of 64 landmarks (landmark per lane, the
-	// component broadcast from LDS). A last block with few landmarks is packed: LJ = 2^k lanes carry the
-	// landmarks and the 64 / LJ lane groups take different components, then the groups are summed.
-	double plog_part = 0, clog_part = 0, pcount_part = 0;
-	{
-		double* tile = smem + lay.p2_tile;   // [TILE][12]: mean, inverse covariance, weight, multiplier
-		const int JB = (J + 63) >> 6;
-		for (int c = tid; c < n; c += 256) pcount_part += vin.w[sbi + c];
-		for (int src = 0; src < 2; src++) {
-			const int total = (src == 0) ? np : no;
-			for (int i = tid; i < JB * 256; i += 256) part[i] = 0;
-			for (int c0 = 0; c0 < total; c0 += TILE) {
-				int c = c0 + tid;
-				if (c < total) {
-					double w, m[3], P[6], Pi[6], det;
-					if (src == 1) {
-						w = vout.w[sbo + c];
-#pragma unroll
-						for (int t = 0; t < 3; t++) m[t] = vout.m[t][sbo + c];
-#pragma unroll
-						for (int t = 0; t < 6; t++) P[t] = vout.P[t][sbo + c];
-					}
-					else if (c < n) {
-						w = vin.w[sbi + c];
-#pragma unroll
-						for (int t = 0; t < 3; t++) m[t] = vin.m[t][sbi + c];
-#pragma unroll
-						for (int t = 0; t < 6; t++) P[t] = vin.P[t][sbi + c];
-					}
-					else {
-						const double* bm = a.born_mean + ((size_t) p * a.Mcap + (c - n)) * 3;
-						w = prm.birthw;
-						m[0] = bm[0]; m[1] = bm[1]; m[2] = bm[2];
-#pragma unroll
-						for (int t = 0; t < 6; t++) P[t] = prm.birthP[t];
-					}
-					inv_sym3(P, Pi, det);
-					double* tt = tile + tid * 12;
-#pragma unroll
-					for (int t = 0; t < 3; t++) tt[t] = m[t];
-#pragma unroll
-					for (int t = 0; t < 6; t++) tt[3 + t] = Pi[t];
-					tt[9]  = w;
-					tt[10] = PHD_INV_2PI / sqrt(fabs(det));
-				}
-				__syncthreads();
-				const int cend = min(TILE, total - c0);
-				for (int jb = 0; jb < JB; jb++) {
-					const int rem = min(64, J - jb * 64);
-					const int LJ  = (rem > 32) ? 64 : ((rem <= 1) ? 1 : (1 << (32 - __clz(rem - 1))));
-					const int G   = 64 / LJ, g = lane / LJ, jl = lane & (LJ - 1);
-					const bool jv = jl < rem;
-					const int  j  = jb * 64 + jl;
-					const double x0 = jv ? lm[j] : 0, x1 = jv ? lm[JS + j] : 0, x2 = jv ? lm[2 * JS + j] : 0;
-					// w * (mult * exp(-d^T Pinv d / 2)) of component cc at this lane's landmark (Map.cs:198)
-					auto dens = [&](int cc) {
-						const double* tt = tile + cc * 12;
-						double d0 = x0 - tt[0], d1 = x1 - tt[1], d2 = x2 - tt[2];
-						double Pi[6];
-#pragma unroll
-						for (int t = 0; t < 6; t++) Pi[t] = tt[3 + t];
-						return tt[9] * (tt[10] * exp_neg(-0.5 * quad_sym(Pi, d0, d1, d2), etab));
-					};
-					double acc = 0, acc2 = 0;
-					int cc = wv * G + g;
-					const int step = 4 * G;
-					for (; cc + step < cend; cc += 2 * step) {   // two independent components per trip
-						acc  += dens(cc);
-						acc2 += dens(cc + step);
-					}
-					if (cc < cend) acc += dens(cc);
-					acc += acc2;
-					part[(jb * 4 + wv) * 64 + lane] += acc;   // own slot
-				}
-				__syncthreads();
-			}
-			__threadfence_block();
-			__syncthreads();
-			for (int jb = wv; jb < JB; jb += 4) {
-				const int rem = min(64, J - jb * 64);
-				const int LJ  = (rem > 32) ? 64 : ((rem <= 1) ? 1 : (1 << (32 - __clz(rem - 1))));
-				const int jl = lane & (LJ - 1);
-				double v = part[(jb * 4 + 0) * 64 + lane] + part[(jb * 4 + 1) * 64 + lane] + part[(jb * 4 + 2) * 64 + lane] +
-				           part[(jb * 4 + 3) * 64 + lane];
-				for (int o = LJ; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
-				if (lane < LJ && jl < rem) {
-					if (src == 0) plog_part += log(v);
-					else          clog_part += log(v);
-				}
-			}
-			__syncthreads();
-		}
-	}
-	// block reductions (fixed order)
-	auto block_sum = [&](double v) {
-		red[tid] = v;
-		__syncthreads();
-		for (int s = 128; s > 0; s >>= 1) {
-			if (tid < s) red[tid] += red[tid + s];
-			__syncthreads();
-		}
-		double r = red[0];
-		__syncthreads();
-		return r;
-	};
-	const double plog = block_sum(plog_part);
-	const double clog = block_sum(clog_part);
-	const double pcount = block_sum(pcount_part) + nb * prm.birthw;
-	const double ccount = s_ccount;
 
 	// ---- phase 3: SetLogLikelihood (PHDNavigator.cs:462-515) on the matrix of SetLogLikeMatrix (:415-453)
 	{
@@ -826,11 +716,155 @@ __global__ __launch_bounds__(256) void k_weight_alpha(const DevParams prm, const
 		__syncthreads();
 	}
 	if (tid == 0) {
-		double setll = s_total;
+		a.setll[p]   = s_total;
+		a.aJ[p]      = J;
+		a.account[p] = s_ccount;
+	}
+}
+
+// =================================================================================================
+// k_alpha_density — the two mixture-density sums of WeightAlpha (PHDNavigator.cs:381-384) and its last line:
+//   alpha = exp( L(Z | map estimate, pose) + [sum_j log v_pred(m_j) - sum w_pred] - [sum_j log v_corr(m_j) - sum w_corr] )
+// with v(.) the full, ungated mixture density (Map.Evaluate(point), Map.cs:192-202) and m_j the landmarks of
+// the map estimate left in HBM by k_alpha_assoc. Landmark per lane, component tiles broadcast from LDS.
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_alpha_density(const DevParams prm, const StepBufs a)
+{
+	constexpr int JL = ALPHA_JL;
+	__shared__ double tile[TILE * 12];          // [TILE][12]: mean, inverse covariance, weight, multiplier
+	__shared__ double partl[(JL / 64) * 256];   // [JB][4][64] partial densities (HBM slab when J > JL)
+	__shared__ double red[256];
+	__shared__ double etab[EXPTAB_N];
+
+	const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int cap = a.cap;
+	const MixView vin = bank_view(a, SEL_IN), vout = bank_view(a, SEL_OUT);
+	const Bank& bin  = a.bank[a.sel[SEL_IN]];
+	const Bank& bout = a.bank[a.sel[SEL_OUT]];
+	const int n = vin.count[p], nb = a.born_count[p], no = vout.count[p];
+	const int np = n + nb;
+	const size_t sbi = (size_t) p * cap, sbo = (size_t) p * cap;
+	const int J = a.aJ[p];
+	const int JS = a.Jcap;
+	const double* lm = a.alm + (size_t) p * 3 * JS;   // [3][Jcap]
+	double* gj = a.jscratch + (size_t) p * alpha_jscratch_doubles(a.Jcap);
+	double* part = (J <= JL) ? partl : gj + 13 * (size_t) JS;
+	exp_tab_init(etab, tid);
+	__syncthreads();
+
+	// ---- phase 2: sum_j log v_pred(m_j), sum_j log v_corr(m_j) with v = full ungated mixture density (Map.cs:192-202)
+	// Component tiles are staged once and swept for every block of 64 landmarks (landmark per lane, the
+	// component broadcast from LDS). A last block with few landmarks is packed: LJ = 2^k lanes carry the
+	// landmarks and the 64 / LJ lane groups take different components, then the groups are summed.
+	double plog_part = 0, clog_part = 0, pcount_part = 0;
+	{
+		const int JB = (J + 63) >> 6;
+		for (int c = tid; c < n; c += 256) pcount_part += vin.w[sbi + c];
+		for (int src = 0; src < 2; src++) {
+			const int total = (src == 0) ? np : no;
+			for (int i = tid; i < JB * 256; i += 256) part[i] = 0;
+			for (int c0 = 0; c0 < total; c0 += TILE) {
+				int c = c0 + tid;
+				if (c < total) {
+					double w, m[3], P[6], Pi[6], det;
+					if (src == 1) {
+						w = vout.w[sbo + c];
+#pragma unroll
+						for (int t = 0; t < 3; t++) m[t] = vout.m[t][sbo + c];
+#pragma unroll
+						for (int t = 0; t < 6; t++) P[t] = vout.P[t][sbo + c];
+					}
+					else if (c < n) {
+						w = vin.w[sbi + c];
+#pragma unroll
+						for (int t = 0; t < 3; t++) m[t] = vin.m[t][sbi + c];
+#pragma unroll
+						for (int t = 0; t < 6; t++) P[t] = vin.P[t][sbi + c];
+					}
+					else {
+						const double* bm = a.born_mean + ((size_t) p * a.Mcap + (c - n)) * 3;
+						w = prm.birthw;
+						m[0] = bm[0]; m[1] = bm[1]; m[2] = bm[2];
+#pragma unroll
+						for (int t = 0; t < 6; t++) P[t] = prm.birthP[t];
+					}
+					inv_sym3(P, Pi, det);
+					double* tt = tile + tid * 12;
+#pragma unroll
+					for (int t = 0; t < 3; t++) tt[t] = m[t];
+#pragma unroll
+					for (int t = 0; t < 6; t++) tt[3 + t] = Pi[t];
+					tt[9]  = w;
+					tt[10] = PHD_INV_2PI / sqrt(fabs(det));
+				}
+				__syncthreads();
+				const int cend = min(TILE, total - c0);
+				for (int jb = 0; jb < JB; jb++) {
+					const int rem = min(64, J - jb * 64);
+					const int LJ  = (rem > 32) ? 64 : ((rem <= 1) ? 1 : (1 << (32 - __clz(rem - 1))));
+					const int G   = 64 / LJ, g = lane / LJ, jl = lane & (LJ - 1);
+					const bool jv = jl < rem;
+					const int  j  = jb * 64 + jl;
+					const double x0 = jv ? lm[j] : 0, x1 = jv ? lm[JS + j] : 0, x2 = jv ? lm[2 * JS + j] : 0;
+					// w * (mult * exp(-d^T Pinv d / 2)) of component cc at this lane's landmark (Map.cs:198)
+					auto dens = [&](int cc) {
+						const double* tt = tile + cc * 12;
+						double d0 = x0 - tt[0], d1 = x1 - tt[1], d2 = x2 - tt[2];
+						double Pi[6];
+#pragma unroll
+						for (int t = 0; t < 6; t++) Pi[t] = tt[3 + t];
+						return tt[9] * (tt[10] * exp_neg(-0.5 * quad_sym(Pi, d0, d1, d2), etab));
+					};
+					double acc = 0, acc2 = 0;
+					int cc = wv * G + g;
+					const int step = 4 * G;
+					for (; cc + step < cend; cc += 2 * step) {   // two independent components per trip
+						acc  += dens(cc);
+						acc2 += dens(cc + step);
+					}
+					if (cc < cend) acc += dens(cc);
+					acc += acc2;
+					part[(jb * 4 + wv) * 64 + lane] += acc;   // own slot
+				}
+				__syncthreads();
+			}
+			__threadfence_block();
+			__syncthreads();
+			for (int jb = wv; jb < JB; jb += 4) {
+				const int rem = min(64, J - jb * 64);
+				const int LJ  = (rem > 32) ? 64 : ((rem <= 1) ? 1 : (1 << (32 - __clz(rem - 1))));
+				const int jl = lane & (LJ - 1);
+				double v = part[(jb * 4 + 0) * 64 + lane] + part[(jb * 4 + 1) * 64 + lane] + part[(jb * 4 + 2) * 64 + lane] +
+				           part[(jb * 4 + 3) * 64 + lane];
+				for (int o = LJ; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+				if (lane < LJ && jl < rem) {
+					if (src == 0) plog_part += log(v);
+					else          clog_part += log(v);
+				}
+			}
+			__syncthreads();
+		}
+	}
+	// block reductions (fixed order)
+	auto block_sum = [&](double v) {
+		red[tid] = v;
+		__syncthreads();
+		for (int s = 128; s > 0; s >>= 1) {
+			if (tid < s) red[tid] += red[tid + s];
+			__syncthreads();
+		}
+		double r = red[0];
+		__syncthreads();
+		return r;
+	};
+	const double plog = block_sum(plog_part);
+	const double clog = block_sum(clog_part);
+	const double pcount = block_sum(pcount_part) + nb * prm.birthw;
+	if (tid == 0) {
+		const double ccount = a.account[p];
 		double ratio = (plog - pcount) - (clog - ccount);   // :390
-		double alpha = exp(setll + ratio);                  // :392
-		a.setll[p] = setll;
+		double alpha = exp(a.setll[p] + ratio);             // :392
 		a.alpha[p] = alpha;
-		bout.weights[p] = bin.weights[p] * alpha;         // :335
+		bout.weights[p] = bin.weights[p] * alpha;           // :335
 	}
 }

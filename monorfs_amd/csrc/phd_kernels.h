@@ -71,6 +71,10 @@ struct StepBufs {
 	int*    pair_ck;     // [P][ecap][2]
 	double* pair_w;      // [P][ecap]
 	int*    pair_count;  // [P]
+	// map estimate handed from k_alpha_assoc to k_alpha_density
+	double* alm;         // [P][3][Jcap] landmark means
+	int*    aJ;          // [P] landmarks
+	double* account;     // [P] expected size of the corrected map
 };
 
 __device__ __forceinline__ MixView bank_view(const StepBufs& a, int role)

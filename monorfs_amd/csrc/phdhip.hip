@@ -47,6 +47,7 @@ struct phd_navigator {
 	double* d_jscratch = nullptr;
 	double* d_cm = nullptr; int cmcap = 0;
 	int* d_pair_ck = nullptr; double* d_pair_w = nullptr; int* d_pair_count = nullptr;
+	double* d_alm = nullptr; int* d_aJ = nullptr; double* d_account = nullptr;
 	double* d_gw = nullptr; int gwcap = 0;           // gathered weights of all ranks
 	double* d_stage = nullptr;                       // staging for uploads
 	// migration (multi-GPU resampling)
@@ -155,6 +156,7 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.alpha = nav->d_alpha; b.setll = nav->d_setll; b.flags = nav->d_flags; b.murty = nav->d_murty; b.jscratch = nav->d_jscratch;
 	b.cm = nav->d_cm; b.cmcap = nav->cmcap; b.cmplane = (size_t) nav->Pcap * nav->cmcap;
 	b.pair_ck = nav->d_pair_ck; b.pair_w = nav->d_pair_w; b.pair_count = nav->d_pair_count;
+	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account;
 	return b;
 }
 
@@ -189,7 +191,8 @@ const char* T_ME = "k_measure";
 const char* T_CO = "k_correct";
 const char* T_EF = "k_emit_finish";
 const char* T_PM = "k_prune_merge";
-const char* T_WA = "k_weight_alpha";
+const char* T_WA = "k_alpha_assoc";
+const char* T_WD = "k_alpha_density";
 const char* T_NR = "k_normalise_resample";
 const char* T_GR = "k_gather_rotate";
 
@@ -220,10 +223,13 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b, bool with_alpha)
 
 	if (with_alpha) {
 		AlphaLds lay = alpha_lds(ZB * 64, nav->cutcap);
-		HC(hipFuncSetAttribute((const void*) k_weight_alpha<ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
+		HC(hipFuncSetAttribute((const void*) k_alpha_assoc<ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
 		timer_begin(nav, T_WA);
-		hipLaunchKernelGGL(k_weight_alpha<ZB>, dim3(P), dim3(256), lay.bytes, nav->stream, nav->dp, b, nav->cutcap);
+		hipLaunchKernelGGL(k_alpha_assoc<ZB>, dim3(P), dim3(256), lay.bytes, nav->stream, nav->dp, b, nav->cutcap);
 		timer_end(nav, T_WA);
+		timer_begin(nav, T_WD);
+		hipLaunchKernelGGL(k_alpha_density, dim3(P), dim3(256), 0, nav->stream, nav->dp, b);
+		timer_end(nav, T_WD);
 		HC(hipGetLastError());
 	}
 	return PHD_OK;
@@ -426,6 +432,8 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	ok = ok && dalloc((void**) &nav->d_cm, (size_t) CM_PLANES * nav->Pcap * nav->cmcap * 8);
 	ok = ok && dalloc((void**) &nav->d_pair_ck, E * 8) && dalloc((void**) &nav->d_pair_w, E * 8);
 	ok = ok && dalloc((void**) &nav->d_pair_count, (size_t) nav->Pcap * 4);
+	ok = ok && dalloc((void**) &nav->d_alm, (size_t) nav->Pcap * 3 * nav->Jcap * 8);
+	ok = ok && dalloc((void**) &nav->d_aJ, (size_t) nav->Pcap * 4) && dalloc((void**) &nav->d_account, (size_t) nav->Pcap * 8);
 	ok = ok && dalloc((void**) &nav->d_jscratch, (size_t) nav->Pcap * alpha_jscratch_doubles(nav->Jcap) * 8);
 	if (!ok) {
 		g_create_error = std::string("device allocation failed: ") + hipGetErrorString(hipGetLastError());
@@ -452,7 +460,7 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_sel); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
-	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_cm); hipFree(nav->d_pair_ck); hipFree(nav->d_pair_w); hipFree(nav->d_pair_count); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
+	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cm); hipFree(nav->d_pair_ck); hipFree(nav->d_pair_w); hipFree(nav->d_pair_count); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
 	if (nav->stream) hipStreamDestroy(nav->stream);
 	delete nav;
