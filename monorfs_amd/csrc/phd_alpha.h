@@ -341,7 +341,7 @@ __device__ __noinline__ int wave_murty(const MurtyLds& ws, MurtyNodes* nodes, in
 
 struct AlphaLds {
 	int zs, red, lm, pick, scr;                 // persistent, offsets in doubles
-	int p1_keyw, p1_sortw, p1_dw, p1_sortsrc;   // phase 1 (ints follow: sortsrc[ncap], dsrc[JL])
+	int p1_keyw, p1_sortw, p1_dw, p1_sortsrc, ns;   // phase 1 (ints follow: sortsrc[ns], dsrc[JL])
 	int p2_tile, p2_part;                       // phase 2
 	int p3_zh, p3_pdj, p3_res, p3_adj, p3_int, p3_x;   // phase 3 (ints: labl[JL], roots[JL], labz[MP]); x = mats | murty
 	int bytes;
@@ -356,11 +356,14 @@ __host__ __device__ inline AlphaLds alpha_lds(int MP, int ncap)
 	l.lm   = l.red + 256 + EXPTAB_N;   // red[256], exp table[32]
 	l.pick = l.lm + 3 * JL;
 	l.scr  = l.pick + JL / 2;
+	int ns = 2;
+	while (ns < ncap) ns <<= 1;                 // width of the bitonic sort
+	l.ns = ns;
 	l.p1_keyw = l.scr;
 	l.p1_sortw = l.p1_keyw + ncap;
-	l.p1_dw = l.p1_sortw + ncap;
+	l.p1_dw = l.p1_sortw + ns;
 	l.p1_sortsrc = l.p1_dw + JL;
-	int ph1 = l.p1_sortsrc + (ncap + JL + 1) / 2 - l.scr;
+	int ph1 = l.p1_sortsrc + (ns + JL + 1) / 2 - l.scr;
 	l.p2_tile = l.scr;
 	l.p2_part = l.scr;
 	int ph2 = 0;
@@ -415,32 +418,82 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 	double* keyw    = smem + lay.p1_keyw;              // [ncap] weights in map order
 	double* sortw   = smem + lay.p1_sortw;             // [ncap] weights, stable descending
 	int*    sortsrc = (int*) (smem + lay.p1_sortsrc);  // [ncap]
-	for (int c = tid; c < no; c += 256) keyw[c] = vout.w[sbo + c];
-	__syncthreads();
-	if (tid == 0) {   // ExpectedSize, summed in map order (Map.cs:61-71); size = (int) ExpectedSize (:126)
-		double e = 0;
-		for (int c = 0; c < no; c++) e += keyw[c];
-		s_ccount = e;
-		int J = (int) e;
-		if (J < 0) J = 0;
-		if (J > a.Jcap) {
-			atomicOr(a.flags, PHD_FLAG_J_OVERFLOW);
-			J = a.Jcap;
+	// block-wide sum in a fixed order (thread partials, then a tree)
+	auto block_sum = [&](double v) {
+		red[tid] = v;
+		__syncthreads();
+		for (int s = 128; s > 0; s >>= 1) {
+			if (tid < s) red[tid] += red[tid + s];
+			__syncthreads();
 		}
-		s_J = J;
-	}
-	// stable descending order by counting rank (mlist.Sort, :129)
+		double r = red[0];
+		__syncthreads();
+		return r;
+	};
+	double wpart = 0;
 	for (int c = tid; c < no; c += 256) {
-		double wc = keyw[c];
-		int rank = 0;
-		for (int j = 0; j < no; j++) {
-			double wj = keyw[j];
-			rank += (wj > wc) || (wj == wc && j < c);
-		}
-		sortw[rank]   = wc;
-		sortsrc[rank] = c;
+		double wc = vout.w[sbo + c];
+		keyw[c] = wc;
+		wpart += wc;
 	}
-	__syncthreads();
+	// ExpectedSize (Map.cs:61-71) and size = (int) ExpectedSize (:126). The reference adds the weights one by
+	// one; the tree sum differs from that by a few ulp, which can only change the integer part when the sum
+	// sits within that distance of an integer: then, and only then, the weights are re-added in map order.
+	{
+		double e = block_sum(wpart);
+		if (fabs(e - rint(e)) <= 1e-9 * fmax(1.0, fabs(e))) {
+			if (tid == 0) {
+				double q = 0;
+				for (int c = 0; c < no; c++) q += keyw[c];
+				s_ccount = q;
+			}
+			__syncthreads();
+			e = s_ccount;
+		}
+		if (tid == 0) {
+			s_ccount = e;
+			int J = (int) e;
+			if (J < 0) J = 0;
+			if (J > a.Jcap) {
+				atomicOr(a.flags, PHD_FLAG_J_OVERFLOW);
+				J = a.Jcap;
+			}
+			s_J = J;
+		}
+	}
+	// stable descending order (mlist.Sort, :129): bitonic sort on the weight's bit pattern, then runs of
+	// equal weights put back in map order
+	{
+		unsigned long long* skey = (unsigned long long*) sortw;   // [NS] keys, then overwritten by the sorted weights
+		int NS = 2;
+		while (NS < no) NS <<= 1;
+		for (int t = tid; t < NS; t += 256) {
+			skey[t]    = (t < no) ? prune_key(keyw[t]) : 0ull;
+			sortsrc[t] = (t < no) ? t : -1;
+		}
+		__syncthreads();
+		prune_bitonic(skey, sortsrc, NS, tid);
+		int tie = 0;
+		for (int r = tid; r + 1 < no; r += 256) tie |= (skey[r] == skey[r + 1]);
+		if (__syncthreads_or(tie)) {
+			if (tid == 0) {
+				int r = 0;
+				while (r < no) {
+					int e = r + 1;
+					while (e < no && skey[e] == skey[r]) e++;
+					for (int x = r + 1; x < e; x++) {
+						int sx = sortsrc[x], y = x - 1;
+						while (y >= r && sortsrc[y] > sx) { sortsrc[y + 1] = sortsrc[y]; y--; }
+						sortsrc[y + 1] = sx;
+					}
+					r = e;
+				}
+			}
+			__syncthreads();
+		}
+		for (int r = tid; r < no; r += 256) sortw[r] = keyw[sortsrc[r]];   // same bytes as skey[r]: each thread rewrites its own slots
+		__syncthreads();
+	}
 	const int J = s_J;
 	// landmark-indexed arrays: LDS, or the HBM slab of this particle when the estimate is large
 	const bool inlds = J <= JL;
@@ -454,7 +507,7 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 	unsigned long long* adj = (unsigned long long*) (inlds ? smem + lay.p3_adj : gj + 9 * (size_t) JS);   // [JS][MW]
 	int* gi      = (int*) (gj + 17 * (size_t) JS);
 	int* pick    = inlds ? (int*) (smem + lay.pick) : gi;                // [JS] component picked for landmark j
-	int* dsrc    = inlds ? sortsrc + ncap : gi + JS;                     // [JS]
+	int* dsrc    = inlds ? sortsrc + lay.ns : gi + JS;                   // [JS]
 	int* labl    = inlds ? (int*) (smem + lay.p3_int) : gi + 2 * JS;     // [JS]
 	int* roots   = inlds ? labl + JL : gi + 3 * JS;                      // [JS]
 	int* labz    = (int*) (smem + lay.p3_int) + 2 * JL;                  // [MP]
@@ -546,14 +599,22 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 			if (!s_changed) break;
 			__syncthreads();
 		}
-		if (tid == 0) {
+		if (wv == 0) {   // clusters that hold a detection entry, in ascending order of their first landmark
 			int nr = 0;
-			for (int j = 0; j < J; j++) {
-				bool has = false;
-				for (int b = 0; b < MW; b++) has |= adj[(size_t) j * MW + b] != 0;
-				if (labl[j] == j && has) roots[nr++] = j;
+			for (int j0 = 0; j0 < J; j0 += 64) {
+				const int j = j0 + lane;
+				bool isroot = false;
+				if (j < J) {
+					bool has = false;
+#pragma unroll
+					for (int b = 0; b < MW; b++) has |= adj[(size_t) j * MW + b] != 0;
+					isroot = has && labl[j] == j;
+				}
+				unsigned long long bal = __ballot(isroot);
+				if (isroot) roots[nr + __popcll(bal & lanemask_lt())] = j;
+				nr += __popcll(bal);
 			}
-			s_nroots = nr;
+			if (lane == 0) s_nroots = nr;
 		}
 		__syncthreads();
 		const int nroots = s_nroots;
@@ -698,20 +759,24 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 			}
 			__syncthreads();
 		}
-		if (tid == 0) {
-			// total in the reference's component order: clusters holding detections (ascending first
-			// landmark), then the lone landmarks (misdetection only), then the lone measurements (clutter)
-			double total = 0;
-			for (int r = 0; r < nroots; r++) total += res[r];
-			for (int j = 0; j < J; j++) {
+		// total over the components: clusters holding detections, the lone landmarks (misdetection only,
+		// log(1 - PD_j)) and the lone measurements (clutter, log kappa). The reference adds them in that order one
+		// by one; here every thread adds its share and the shares are summed in a fixed tree.
+		{
+			double tpart = 0;
+			for (int r = tid; r < nroots; r += 256) tpart += res[r];
+			for (int j = tid; j < J; j += 256) {
 				bool has = false;
+#pragma unroll
 				for (int b = 0; b < MW; b++) has |= adj[(size_t) j * MW + b] != 0;
-				if (!has) total += log(1 - pdj[j]);
+				if (!has) tpart += log(1 - pdj[j]);
 			}
-			for (int k = 0; k < M; k++) {
-				if (labz[k] == J + k) total += prm.logkappa;
+			for (int k = tid; k < M; k += 256) {
+				if (labz[k] == J + k) tpart += prm.logkappa;
 			}
-			s_total = total;
+			__syncthreads();
+			double total = block_sum(tpart);
+			if (tid == 0) s_total = total;
 		}
 		__syncthreads();
 	}
