@@ -6,64 +6,74 @@
 // k_weight_alpha — WeightAlpha (PHDNavigator.cs:373-393)
 // =================================================================================================
 
-// next permutation of LexicographicalPairing (GraphCombinatorics.cs:306-332) on n <= 5 entries
-__device__ __forceinline__ bool lex_last(const int* perm, int n)
+// Permutations of LexicographicalPairing (GraphCombinatorics.cs:280-334) on n <= 5 entries, held as 4-bit
+// fields of one register (entry i in bits [4i, 4i+4)) so that nothing is indexed dynamically in memory.
+__device__ __forceinline__ int pk_get(unsigned int perm, int i) { return (int) ((perm >> (4 * i)) & 15u); }
+
+__device__ __forceinline__ unsigned int pk_set(unsigned int perm, int i, int v)
+{
+	return (perm & ~(15u << (4 * i))) | ((unsigned int) v << (4 * i));
+}
+
+__device__ __forceinline__ unsigned int pk_reverse(unsigned int perm, int from, int to)   // Array.Reverse on [from, to)
+{
+	for (int i = from, j = to - 1; i < j; i++, j--) {
+		int vi = pk_get(perm, i), vj = pk_get(perm, j);
+		perm = pk_set(pk_set(perm, i, vj), j, vi);
+	}
+	return perm;
+}
+
+__device__ __forceinline__ bool pk_last(unsigned int perm, int n)   // lastpermutation, :341-350
 {
 	for (int i = 1; i < n; i++) {
-		if (perm[i - 1] < perm[i]) return false;
+		if (pk_get(perm, i - 1) < pk_get(perm, i)) return false;
 	}
 	return true;
 }
 
-__device__ __forceinline__ void lex_reverse(int* perm, int from, int to)   // [from, to)
-{
-	for (int i = from, j = to - 1; i < j; i++, j--) {
-		int t = perm[i]; perm[i] = perm[j]; perm[j] = t;
-	}
-}
-
-__device__ __forceinline__ void lex_next(int* perm, int n, int measurestart)
+__device__ __forceinline__ unsigned int pk_next(unsigned int perm, int n, int measurestart)   // :306-331
 {
 	int x, y;
 	for (x = n - 2; x > 0; x--) {
-		if (perm[x] < perm[x + 1]) break;
+		if (pk_get(perm, x) < pk_get(perm, x + 1)) break;
 	}
 	for (y = n - 1; y > x; y--) {
-		if (perm[x] < perm[y]) break;
+		if (pk_get(perm, x) < pk_get(perm, y)) break;
 	}
-	int t = perm[x]; perm[x] = perm[y]; perm[y] = t;
-	lex_reverse(perm, x + 1, n);
-	lex_reverse(perm, measurestart, n);
+	int vx = pk_get(perm, x), vy = pk_get(perm, y);
+	perm = pk_set(pk_set(perm, x, vy), y, vx);
+	perm = pk_reverse(perm, x + 1, n);
+	return pk_reverse(perm, measurestart, n);
 }
 
 // log-sum-exp over every pairing of a cluster with n <= 5 rows, enumerated exactly like
 // LexicographicalPairing(component, map.Count) (`modelsize` is compared with COMPACTED row indices,
 // PHDNavigator.cs:493 / GraphCombinatorics.cs:293-299). mat: n x n, row stride 5, stride `ms` between entries.
-__device__ __noinline__ double cluster_enumerate(const double* mat, int ms, int n, int modelsize, double* rec = nullptr)
+__device__ double cluster_enumerate(const double* mat, int ms, int n, int modelsize, double* rec = nullptr)
 {
-	int perm[5], first[5];
 	int measurestart = n;
 	for (int i = 0; i < n; i++) {
 		if (i >= modelsize) { measurestart = i; break; }
 	}
-	for (int i = 0; i < n; i++) first[i] = i;
-	lex_reverse(first, measurestart, n);
+	unsigned int first = 0x43210u;   // row keys, sorted
+	first = pk_reverse(first, measurestart, n);
 
 	double mx = -INFINITY, value = 0;
 	for (int pass = 0; pass < 2; pass++) {
-		for (int i = 0; i < n; i++) perm[i] = first[i];
+		unsigned int perm = first;
 		int m = 0;
 		for (;;) {
 			double v = 0;
-			for (int i = 0; i < n; i++) v += mat[(i * 5 + perm[i]) * ms];   // AssignmentValue
+			for (int i = 0; i < n; i++) v += mat[(i * 5 + pk_get(perm, i)) * ms];   // AssignmentValue
 			if (pass == 0) {
 				mx = fmax(mx, v);
 				if (rec) rec[m] = v;   // logcomp[m] = assignment.Item2 (PHDNavigator.cs:507)
 			}
 			else value += exp(v - mx);
 			m++;
-			if (lex_last(perm, n)) break;
-			lex_next(perm, n, measurestart);
+			if (pk_last(perm, n)) break;
+			perm = pk_next(perm, n, measurestart);
 		}
 		if (pass == 0 && isinf(mx) && mx < 0) return -INFINITY;   // LogSumExp, MatrixExtensions.cs:379-381
 	}
@@ -626,12 +636,14 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 				int ri = r0 + lane;
 				if (ri < nroots) {
 					int root = roots[ri];
-					int L[5], Z[5], nl = 0, nz = 0, nrow = 0;
+					// members, ascending: up to 5 landmarks / measurements as 12-bit fields of a register
+					unsigned long long Lp = 0, Zp = 0;
+					int nl = 0, nz = 0, nrow = 0;
 					for (int j = root; j < J; j++) {
-						if (labl[j] == root) { if (nl < 5) L[nl] = j; nl++; }
+						if (labl[j] == root) { if (nl < 5) Lp |= (unsigned long long) j << (12 * nl); nl++; }
 					}
 					for (int k = 0; k < M; k++) {
-						if (labz[k] == root) { if (nz < 5) Z[nz] = k; nz++; }
+						if (labz[k] == root) { if (nz < 5) Zp |= (unsigned long long) k << (12 * nz); nz++; }
 					}
 					nrow = nl + nz;
 					if (nrow > 5) {
@@ -642,9 +654,9 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 						double* mat = mats + lane;   // entry e at mat[e * 64]
 						for (int e = 0; e < 25; e++) mat[e * 64] = -INFINITY;
 						for (int x = 0; x < nl; x++) {
-							int j = L[x];
+							int j = (int) ((Lp >> (12 * x)) & 4095);
 							for (int y = 0; y < nz; y++) {
-								int k = Z[y];
+								int k = (int) ((Zp >> (12 * y)) & 4095);
 								if ((adj[(size_t) j * MW + (k >> 6)] >> (k & 63)) & 1ull) {
 									double dist = sqrt(quad_gen(prm.Rinv, zh[j] - zs[k * 3], zh[JS + j] - zs[k * 3 + 1],
 									                            zh[2 * JS + j] - zs[k * 3 + 2]));
