@@ -353,7 +353,7 @@ struct AlphaLds {
 	int zs, red, lm, pick, scr;                 // persistent, offsets in doubles
 	int p1_keyw, p1_sortw, p1_dw, p1_sortsrc, ns;   // phase 1 (ints follow: sortsrc[ns], dsrc[JL])
 	int p2_tile, p2_part;                       // phase 2
-	int p3_zh, p3_pdj, p3_res, p3_adj, p3_int, p3_x;   // phase 3 (ints: labl[JL], roots[JL], labz[MP]); x = mats | murty
+	int p3_zh, p3_pdj, p3_res, p3_adj, p3_adjT, p3_int, p3_x;   // phase 3 (ints: labl[JL], roots[JL], labz[MP]); x = mats | murty
 	int bytes;
 };
 
@@ -381,7 +381,8 @@ __host__ __device__ inline AlphaLds alpha_lds(int MP, int ncap)
 	l.p3_pdj = l.p3_zh + 3 * JL;
 	l.p3_res = l.p3_pdj + JL;
 	l.p3_adj = l.p3_res + JL;
-	l.p3_int = l.p3_adj + JL * MW;
+	l.p3_adjT = l.p3_adj + JL * MW;
+	l.p3_int = l.p3_adjT + MP * (JL / 64);
 	l.p3_x   = l.p3_int + (2 * JL + MP + 1) / 2;
 	int xs = 25 * 64 > MURTY_LDS_DOUBLES ? 25 * 64 : MURTY_LDS_DOUBLES;
 	int ph3 = l.p3_x + xs + 2 - l.scr;
@@ -522,7 +523,13 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 	int* roots   = inlds ? labl + JL : gi + 3 * JS;                      // [JS]
 	int* labz    = (int*) (smem + lay.p3_int) + 2 * JL;                  // [MP]
 	double* xreg = smem + lay.p3_x;                                      // mats [25][64]  |  Murty scratch
-	if (tid == 0) {
+	// When the largest weight minus one does not exceed the J-th largest weight no appended entry can be
+	// picked among the first J: the estimate is simply the J heaviest components, in order.
+	const bool straight = J <= no && (J == 0 || !(sortw[0] - 1 > sortw[J - 1]));
+	if (straight) {
+		for (int j = tid; j < J; j += 256) pick[j] = sortsrc[j];
+	}
+	else if (tid == 0) {
 		// "take the i-th entry, append a copy with w - 1, sort again" (:131-138) is a two-way merge:
 		// every appended weight is <= the one it came from, so the appended entries are produced in
 		// non-increasing order and form a FIFO merged with the original sorted list; on a tie the
@@ -558,24 +565,32 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 	{
 		double* mats = xreg;   // [25][64] one 5x5 matrix per lane (dead before the Murty path reuses the region)
 
+		constexpr int JW = JL / 64;                                   // words of a transposed adjacency row (LDS case)
+		unsigned long long* adjT = (unsigned long long*) (smem + lay.p3_adjT);   // [MP][JW] landmarks gated with measurement k
 		for (int j = tid; j < J; j += 256) {
 			double m[3] = {lm[j], lm[JS + j], lm[2 * JS + j]}, z[3], l[3];
 			measure_perfect(prm, pose, m, z, l);
 			zh[j] = z[0]; zh[JS + j] = z[1]; zh[2 * JS + j] = z[2];
 			pdj[j] = detection_probability_m(prm, z);
-			unsigned long long bits[MW];
 #pragma unroll
-			for (int b = 0; b < MW; b++) bits[b] = 0;
-			for (int k = 0; k < M; k++) {
-				double dist = sqrt(quad_gen(prm.Rinv, z[0] - zs[k * 3], z[1] - zs[k * 3 + 1], z[2] - zs[k * 3 + 2]));
-				if (dist < 5) bits[k >> 6] |= 1ull << (k & 63);   // :436
-			}
-#pragma unroll
-			for (int b = 0; b < MW; b++) adj[(size_t) j * MW + b] = bits[b];
+			for (int b = 0; b < MW; b++) adj[(size_t) j * MW + b] = 0;
 			labl[j] = j;
 		}
 		for (int k = tid; k < M; k += 256) labz[k] = J + k;
+		for (int t = tid; t < MP * JW; t += 256) adjT[t] = 0;
 		if (tid == 0) { s_nroots = 0; s_big = 0; }
+		__threadfence_block();
+		__syncthreads();
+		// detection block: defined iff Mahalanobis(z_k; h(m_j), R) < 5 (:433-442), every pair in parallel
+		for (int e = tid; e < J * M; e += 256) {
+			const int j = e / M, k = e - j * M;
+			double dist = sqrt(quad_gen(prm.Rinv, zh[j] - zs[k * 3], zh[JS + j] - zs[k * 3 + 1], zh[2 * JS + j] - zs[k * 3 + 2]));
+			if (dist < 5) {   // :436
+				atomicOr(&adj[(size_t) j * MW + (k >> 6)], 1ull << (k & 63));
+				if (inlds) atomicOr(&adjT[(size_t) k * JW + (j >> 6)], 1ull << (j & 63));
+			}
+		}
+		__threadfence_block();
 		__syncthreads();
 
 		// connected components of the bipartite (landmark, measurement) graph by min-label propagation;
@@ -597,14 +612,29 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 				}
 				if (l < labl[j]) { labl[j] = l; s_changed = 1; }
 			}
+			__threadfence_block();
 			__syncthreads();
 			for (int k = tid; k < M; k += 256) {
 				int l = labz[k];
-				for (int j = 0; j < J; j++) {
-					if ((adj[(size_t) j * MW + (k >> 6)] >> (k & 63)) & 1ull) l = min(l, labl[j]);
+				if (inlds) {
+#pragma unroll
+					for (int b = 0; b < JW; b++) {
+						unsigned long long bits = adjT[(size_t) k * JW + b];
+						while (bits) {
+							int j = b * 64 + __ffsll((long long) bits) - 1;
+							bits &= bits - 1;
+							l = min(l, labl[j]);
+						}
+					}
+				}
+				else {
+					for (int j = 0; j < J; j++) {
+						if ((adj[(size_t) j * MW + (k >> 6)] >> (k & 63)) & 1ull) l = min(l, labl[j]);
+					}
 				}
 				if (l < labz[k]) { labz[k] = l; s_changed = 1; }
 			}
+			__threadfence_block();
 			__syncthreads();
 			if (!s_changed) break;
 			__syncthreads();
