@@ -6,6 +6,19 @@
 
 #define PHD_WAVE 64
 
+// In-kernel stamps for a separate DIAGNOSTIC build only (hipcc -DPHD_STAMPS -> libphdhip_stamps.so, see
+// scripts/stamps.py): thread 0 of every workgroup records the shader clock at phase boundaries and leaves the
+// differences in a debug slab that no kernel reads. The product build compiles them to nothing.
+#ifdef PHD_STAMPS
+#define PHD_STAMP_DECL long long stamp_[12]; for (int s_ = 0; s_ < 12; s_++) stamp_[s_] = 0
+#define PHD_STAMP(i) stamp_[i] = clock64()
+#define PHD_STAMP_FLUSH(n) if (threadIdx.x == 0 && a.stamps) { for (int s_ = 0; s_ + 1 < (n); s_++) a.stamps[(size_t) blockIdx.x * 16 + s_] = (double) (stamp_[s_ + 1] - stamp_[s_]); }
+#else
+#define PHD_STAMP_DECL
+#define PHD_STAMP(i)
+#define PHD_STAMP_FLUSH(n)
+#endif
+
 // Parameters as the kernels consume them (built once on the host from phd_params).
 struct DevParams {
 	// PRM3DMeasurer (PRM3DMeasurer.cs:55-73): focal, float32 range clip, integer film rectangle

@@ -75,6 +75,7 @@ struct StepBufs {
 	double* alm;         // [P][3][Jcap] landmark means
 	int*    aJ;          // [P] landmarks
 	double* account;     // [P] expected size of the corrected map
+	double* stamps;      // [P][16] phase stamps of the diagnostic build (NULL otherwise)
 };
 
 __device__ __forceinline__ MixView bank_view(const StepBufs& a, int role)

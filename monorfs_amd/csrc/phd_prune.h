@@ -93,11 +93,13 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	int*    scan  = (int*) (smem + lay.scan);              // [264]
 
 	const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	PHD_STAMP_DECL;
 	const MixView vout = bank_view(a, SEL_OUT);
 	const int ne = a.emit_count[p];
 	const size_t eb = (size_t) p * a.ecap;
 	const int cut = min(min(prm.maxq, ne), cutcap);   // weightcut: every emitted weight is already >= MinWeight
 
+	PHD_STAMP(0);
 	// ---- A. order by (weight desc, canonical index asc)
 	{
 		int n = 2;
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 		}
 	}
 	__syncthreads();
+	PHD_STAMP(1);
 	for (int r = tid; r < cut; r += 256) {
 		const double* rec = a.emit_rec + (eb + order[r]) * 9;
 		sm[r] = rec[0]; sm[cc + r] = rec[1]; sm[2 * cc + r] = rec[2];
@@ -168,6 +171,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	for (int q = 0; q < 4; q++) Rmax = fmax(Rmax, __hiloint2double(scan[q], scan[4 + q]));
 	__syncthreads();
 
+	PHD_STAMP(2);
 	// ---- B. all closeness tests, two rows per thread
 	for (int rb = 0; rb * 512 < cut; rb++) {
 		int    row[2];
@@ -226,6 +230,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	}
 	__syncthreads();
 
+	PHD_STAMP(3);
 	// ---- C. who survives: sequential in rank order, one wave, absorbed bits in registers
 	if (wv == 0) {
 		unsigned int absorbed = 0;                  // bit s of lane l <-> row s*64 + l
@@ -282,6 +287,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	}
 	__syncthreads();
 
+	PHD_STAMP(4);
 	// ---- D. output position of every survivor (exclusive scan of the survivor flags) and the merges
 	int nsurv_before = 0;
 	for (int r0 = 0; r0 < cut; r0 += 256) {
@@ -342,5 +348,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 		}
 		nsurv_before += total;
 	}
+	PHD_STAMP(5);
 	if (tid == 0) vout.count[p] = nsurv_before;
+	PHD_STAMP_FLUSH(6);
 }

@@ -48,6 +48,7 @@ struct phd_navigator {
 	double* d_cm = nullptr; int cmcap = 0;
 	int* d_pair_ck = nullptr; double* d_pair_w = nullptr; int* d_pair_count = nullptr;
 	double* d_alm = nullptr; int* d_aJ = nullptr; double* d_account = nullptr;
+	double* d_stamps = nullptr;
 	double* d_gw = nullptr; int gwcap = 0;           // gathered weights of all ranks
 	double* d_stage = nullptr;                       // staging for uploads
 	// migration (multi-GPU resampling)
@@ -156,7 +157,7 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.alpha = nav->d_alpha; b.setll = nav->d_setll; b.flags = nav->d_flags; b.murty = nav->d_murty; b.jscratch = nav->d_jscratch;
 	b.cm = nav->d_cm; b.cmcap = nav->cmcap; b.cmplane = (size_t) nav->Pcap * nav->cmcap;
 	b.pair_ck = nav->d_pair_ck; b.pair_w = nav->d_pair_w; b.pair_count = nav->d_pair_count;
-	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account;
+	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account; b.stamps = nav->d_stamps;
 	return b;
 }
 
@@ -432,6 +433,9 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	ok = ok && dalloc((void**) &nav->d_cm, (size_t) CM_PLANES * nav->Pcap * nav->cmcap * 8);
 	ok = ok && dalloc((void**) &nav->d_pair_ck, E * 8) && dalloc((void**) &nav->d_pair_w, E * 8);
 	ok = ok && dalloc((void**) &nav->d_pair_count, (size_t) nav->Pcap * 4);
+#ifdef PHD_STAMPS
+	ok = ok && dalloc((void**) &nav->d_stamps, (size_t) nav->Pcap * 16 * 8);
+#endif
 	ok = ok && dalloc((void**) &nav->d_alm, (size_t) nav->Pcap * 3 * nav->Jcap * 8);
 	ok = ok && dalloc((void**) &nav->d_aJ, (size_t) nav->Pcap * 4) && dalloc((void**) &nav->d_account, (size_t) nav->Pcap * 8);
 	ok = ok && dalloc((void**) &nav->d_jscratch, (size_t) nav->Pcap * alpha_jscratch_doubles(nav->Jcap) * 8);
@@ -460,7 +464,7 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_sel); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
-	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cm); hipFree(nav->d_pair_ck); hipFree(nav->d_pair_w); hipFree(nav->d_pair_count); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
+	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cm); hipFree(nav->d_pair_ck); hipFree(nav->d_pair_w); hipFree(nav->d_pair_count); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
 	if (nav->stream) hipStreamDestroy(nav->stream);
 	delete nav;
@@ -849,6 +853,15 @@ int phd_particle_depleted(phd_navigator* nav, const double* weights, int npartic
 	*depleted = info[1] ? 1 : 0;
 	return PHD_OK;
 }
+
+#ifdef PHD_STAMPS
+// diagnostic build only: per-workgroup phase stamps of the last stamped kernel, [P][16] doubles
+int phd_debug_stamps(phd_navigator* nav, double* out)
+{
+	hipStreamSynchronize(nav->stream);
+	return hipMemcpy(out, nav->d_stamps, (size_t) nav->P * 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
 
 void* phd_stream(phd_navigator* nav) { return nav ? (void*) nav->stream : nullptr; }
 
