@@ -24,6 +24,7 @@
 #include "phd_device.h"
 
 #define PRUNE_NBR 7
+#define PRUNE_NB 1024   // buckets of the spatial hash
 
 struct PruneLds {
 	int sw, sm, order, x, scan;   // offsets in doubles
@@ -41,9 +42,10 @@ __host__ __device__ inline PruneLds prune_lds(int cutcap)
 	l.sw    = 0;
 	l.sm    = l.sw + cc;
 	l.order = l.sm + 3 * cc;                 // int[cc]
-	l.x     = l.order + cc / 2;              // sort keys u64[NS] + slots int[NS]  |  nbr u64[2*cc], owner int[cc], smf float[3*cc], absb int[64]
+	l.x     = l.order + cc / 2;              // sort keys u64[NS] + slots int[NS]  |  nbr, rad2, owner, cell lists (see `rest`)
 	int sortd = NS + NS / 2;
-	int rest  = 2 * cc + cc / 2 + (3 * cc + 1) / 2 + 1 + 32;
+	// nbr u64[2*cc], rad2 double[cc], owner/cellid/cperm int[cc] each, cstart int[NB+2], cfill int[NB], bred double[28], absb int[64]
+	int rest  = 2 * cc + cc + (3 * cc) / 2 + (PRUNE_NB + 2) / 2 + PRUNE_NB / 2 + 28 + 32 + 4;
 	l.scan  = l.x + (sortd > rest ? sortd : rest);
 	l.bytes = (l.scan + 136) * 8;            // int[264] + spare
 	return l;
@@ -87,9 +89,14 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	unsigned long long* skey = (unsigned long long*) (smem + lay.x);   // [NS] sort keys
 	int*    sslot = (int*) (skey + NS);                    // [NS] emit slots
 	unsigned long long* nbr = (unsigned long long*) (smem + lay.x);    // [cut][2]: count + up to 7 close later rows
-	int*    owner = (int*) (nbr + 2 * cc);                 // [cut] row that absorbed k (-1: none)
-	float*  smf   = (float*) (owner + cc);                 // [3][cc] centred means, float32
-	int*    absb  = (int*) (smf + 3 * cc + (cc & 1));      // [64] absorbed bits as left by the resolving wave
+	double* rad2  = (double*) (nbr + 2 * cc);              // [cut] squared Euclidean bound of row i (inf: none)
+	double* bred  = rad2 + cc;                             // [28] block reduction scratch
+	int*    owner = (int*) (bred + 28);                    // [cut] row that absorbed k (-1: none)
+	int*    cellid = owner + cc;                           // [cut] packed grid cell of row r
+	int*    cperm = cellid + cc;                           // [cut] rows grouped by bucket
+	int*    cstart = cperm + cc;                           // [NB + 2] bucket starts
+	int*    cfill = cstart + PRUNE_NB + 2;                 // [NB]
+	int*    absb  = cfill + PRUNE_NB;                      // [64] absorbed bits as left by the resolving wave
 	int*    scan  = (int*) (smem + lay.scan);              // [264]
 
 	const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -153,79 +160,137 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 		const double* rec = a.emit_rec + (eb + order[r]) * 9;
 		sm[r] = rec[0]; sm[cc + r] = rec[1]; sm[2 * cc + r] = rec[2];
 	}
-	__syncthreads();   // the sort buffers are dead from here on: nbr / owner / smf take their place
-	// centre the means (any point will do) for the float32 copy; largest centred coordinate for its rounding bound
-	const double ctr0 = (cut > 0) ? sm[0] : 0, ctr1 = (cut > 0) ? sm[cc] : 0, ctr2 = (cut > 0) ? sm[2 * cc] : 0;
-	double cmax = 0;
-	for (int r = tid; r < cut; r += 256) {
-		double c0 = sm[r] - ctr0, c1 = sm[cc + r] - ctr1, c2 = sm[2 * cc + r] - ctr2;
-		smf[r] = (float) c0; smf[cc + r] = (float) c1; smf[2 * cc + r] = (float) c2;
-		cmax = fmax(cmax, fmax(fabs(c0), fmax(fabs(c1), fabs(c2))));
-		owner[r] = -1;
-	}
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) cmax = fmax(cmax, __shfl_xor(cmax, o, 64));
-	if (lane == 0) { scan[wv] = __double2hiint(cmax); scan[4 + wv] = __double2loint(cmax); }
-	__syncthreads();
-	double Rmax = 0;
-	for (int q = 0; q < 4; q++) Rmax = fmax(Rmax, __hiloint2double(scan[q], scan[4 + q]));
-	__syncthreads();
-
+	__syncthreads();   // the sort buffers are dead from here on: nbr / owner / the cell lists take their place
 	PHD_STAMP(2);
-	// ---- B. all closeness tests, two rows per thread
-	for (int rb = 0; rb * 512 < cut; rb++) {
-		int    row[2];
-		bool   valid[2];
-		double Pi[2][6], md[2][3];
-		float  mf[2][3], boundf[2];
-		unsigned long long lo[2] = {0, 0}, hi[2] = {0, 0};
-		int cnt[2] = {0, 0};
+
+	// ---- B. all closeness tests close_i(k), k > i. A pair can only be close when |m_i - m_k|^2 <= T^2 trace(P_i)
+	// (d^T P_i^-1 d >= |d|^2 / lambda_max(P_i) >= |d|^2 / trace(P_i) for a positive definite P_i), so the rows
+	// are binned in a uniform grid of cell size 2 * (largest such radius): the ball of a row then meets at most
+	// 2 x 2 x 2 cells, whose members are the only candidates. Rows whose P_i is not positive definite, or whose
+	// radius exceeds the cell bound, test every later row.
+	{
+		double lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY, rmx = 0;
+		for (int r = tid; r < cut; r += 256) {
+			const double* rec = a.emit_rec + (eb + order[r]) * 9;
+			double P0 = rec[3], P1 = rec[4], P3 = rec[6], P5 = rec[8];
+			double det = P0 * (P3 * P5 - rec[7] * rec[7]) - P1 * (P1 * P5 - rec[7] * rec[5]) + rec[5] * (P1 * rec[7] - P3 * rec[5]);
+			bool pd = P0 > 0 && (P0 * P3 - P1 * P1) > 0 && det > 0;   // Sylvester
+			double rad = pd ? sqrt(prm.merge_thr2 * (P0 + P3 + P5)) : INFINITY;
+			rad2[r] = rad * rad * (1.0 + 1e-6);
+			if (pd) rmx = fmax(rmx, rad);
+			lo0 = fmin(lo0, sm[r]); lo1 = fmin(lo1, sm[cc + r]); lo2 = fmin(lo2, sm[2 * cc + r]);
+			hi0 = fmax(hi0, sm[r]); hi1 = fmax(hi1, sm[cc + r]); hi2 = fmax(hi2, sm[2 * cc + r]);
+			owner[r] = -1;
+		}
+		double red7[7] = {-lo0, -lo1, -lo2, hi0, hi1, hi2, rmx};   // all as maxima
 #pragma unroll
-		for (int h = 0; h < 2; h++) {
-			row[h]   = rb * 512 + h * 256 + tid;
-			valid[h] = row[h] < cut;
-			boundf[h] = -1.0f;
+		for (int q = 0; q < 7; q++) {
 #pragma unroll
-			for (int t = 0; t < 6; t++) Pi[h][t] = 0;
+			for (int o = 32; o > 0; o >>= 1) red7[q] = fmax(red7[q], __shfl_xor(red7[q], o, 64));
+		}
+		if (lane == 0) {
 #pragma unroll
-			for (int t = 0; t < 3; t++) { md[h][t] = 0; mf[h][t] = 0; }
-			if (valid[h]) {
-				const double* rec = a.emit_rec + (eb + order[row[h]]) * 9;
-				double P[6], det;
+			for (int q = 0; q < 7; q++) bred[wv * 7 + q] = red7[q];
+		}
+		for (int t = tid; t <= PRUNE_NB; t += 256) cstart[t] = 0;
+		for (int t = tid; t < PRUNE_NB; t += 256) cfill[t] = 0;
+		__syncthreads();
 #pragma unroll
-				for (int t = 0; t < 6; t++) P[t] = rec[3 + t];
-				inv_sym3(P, Pi[h], det);
+		for (int q = 0; q < 7; q++) red7[q] = fmax(fmax(bred[q], bred[7 + q]), fmax(bred[14 + q], bred[21 + q]));
+		const double mn0 = -red7[0], mn1 = -red7[1], mn2 = -red7[2];
+		const double ext = fmax(red7[3] - mn0, fmax(red7[4] - mn1, red7[5] - mn2));
+		double cell = fmax(2.02 * red7[6], ext / 60.0);   // <= 61 cells per axis
+		if (!(cell > 0)) cell = 1.0;
+		const double icell = 1.0 / cell, rcap = 0.5 * cell / 1.005;
+		auto bucket = [](int cx, int cy, int cz) {
+			return (int) (((unsigned int) cx * 73856093u ^ (unsigned int) cy * 19349663u ^ (unsigned int) cz * 83492791u) & (PRUNE_NB - 1));
+		};
+		// counting sort of the rows by bucket
+		for (int r = tid; r < cut; r += 256) {
+			int cx = (int) ((sm[r] - mn0) * icell), cy = (int) ((sm[cc + r] - mn1) * icell), cz = (int) ((sm[2 * cc + r] - mn2) * icell);
+			cellid[r] = (cx << 16) | (cy << 8) | cz;
+			atomicAdd(&cstart[bucket(cx, cy, cz) + 1], 1);
+		}
+		__syncthreads();
+		if (wv == 0) {   // exclusive prefix over the PRUNE_NB bucket counts (cstart[b + 1] holds the count of bucket b)
+			int run = 0;
+			for (int b0 = 0; b0 < PRUNE_NB; b0 += 64) {
+				int v = cstart[b0 + 1 + lane], incl = v;
 #pragma unroll
-				for (int t = 0; t < 3; t++) { md[h][t] = sm[t * cc + row[h]]; mf[h][t] = smf[t * cc + row[h]]; }
-				// Sylvester: only a positive definite P_i admits the Euclidean bound
-				bool pd = P[0] > 0 && (P[0] * P[3] - P[1] * P[1]) > 0 && det > 0;
-				double rad = sqrt(prm.merge_thr2 * (P[0] + P[3] + P[5])) * 1.001 + 2e-6 * Rmax;   // + float32 rounding of both means
-				boundf[h] = pd ? (float) (rad * rad * 1.001) : INFINITY;
+				for (int o = 1; o < 64; o <<= 1) {
+					int y = __shfl_up(incl, o, 64);
+					if (lane >= o) incl += y;
+				}
+				cstart[b0 + 1 + lane] = run + incl;
+				run += __shfl(incl, 63, 64);
 			}
 		}
-		const int kstart = rb * 512 + wv * 64 + 1;   // rows of this wave are >= kstart - 1
-		for (int k = kstart; k < cut; k++) {
-			float k0 = smf[k], k1 = smf[cc + k], k2 = smf[2 * cc + k];
+		__syncthreads();
+		for (int r = tid; r < cut; r += 256) {
+			int id = cellid[r];
+			int b = bucket(id >> 16, (id >> 8) & 255, id & 255);
+			// fill the bucket from its end: cfill[b] counts down from the bucket's size
+			int pos = cstart[b + 1] - 1 - atomicAdd(&cfill[b], 1);
+			cperm[pos] = r;
+		}
+		__syncthreads();
+
+		for (int i = tid; i < cut; i += 256) {
+			const double* rec = a.emit_rec + (eb + order[i]) * 9;
+			double P[6], Pi[6], det;
 #pragma unroll
-			for (int h = 0; h < 2; h++) {
-				float e0 = mf[h][0] - k0, e1 = mf[h][1] - k1, e2 = mf[h][2] - k2;
-				float sq = e0 * e0 + e1 * e1 + e2 * e2;
-				if (k > row[h] && sq <= boundf[h]) {
-					double d0 = md[h][0] - sm[k], d1 = md[h][1] - sm[cc + k], d2 = md[h][2] - sm[2 * cc + k];
-					if (quad_sym(Pi[h], d0, d1, d2) < prm.merge_thr2) {   // Gaussian.SquareMahalanobis(b.Mean) < threshold^2
-						if (cnt[h] < 3) lo[h] |= (unsigned long long) k << (16 * (cnt[h] + 1));
-						else if (cnt[h] < PRUNE_NBR) hi[h] |= (unsigned long long) k << (16 * (cnt[h] - 3));
-						cnt[h]++;
+			for (int t = 0; t < 6; t++) P[t] = rec[3 + t];
+			inv_sym3(P, Pi, det);
+			const double m0 = sm[i], m1 = sm[cc + i], m2 = sm[2 * cc + i], bound = rad2[i];
+			int cnt = 0;
+			unsigned int e[PRUNE_NBR];   // close rows found (statically indexed only)
+#pragma unroll
+			for (int q = 0; q < PRUNE_NBR; q++) e[q] = 0xffffu;
+			auto test = [&](int k) {
+				double d0 = m0 - sm[k], d1 = m1 - sm[cc + k], d2 = m2 - sm[2 * cc + k];
+				double sq = d0 * d0 + d1 * d1 + d2 * d2;
+				if (sq <= bound && quad_sym(Pi, d0, d1, d2) < prm.merge_thr2) {   // Gaussian.SquareMahalanobis(b.Mean) < threshold^2
+					// keep the 7 smallest row numbers, ascending (insertion through a fixed network)
+					unsigned int v = (unsigned int) k;
+#pragma unroll
+					for (int q = 0; q < PRUNE_NBR; q++) {
+						unsigned int lo_ = min(e[q], v), hi_ = max(e[q], v);
+						e[q] = lo_; v = hi_;
+					}
+					cnt++;
+				}
+			};
+			if (bound <= rcap * rcap) {
+				const int bx = (int) floor((m0 - mn0) * icell - 0.5), by = (int) floor((m1 - mn1) * icell - 0.5),
+				          bz = (int) floor((m2 - mn2) * icell - 0.5);
+				for (int dz = 0; dz < 2; dz++) {
+					for (int dy = 0; dy < 2; dy++) {
+						for (int dx = 0; dx < 2; dx++) {
+							int cx = bx + dx, cy = by + dy, cz = bz + dz;
+							if (cx < 0 || cy < 0 || cz < 0 || cx > 255 || cy > 255 || cz > 255) continue;
+							const int want = (cx << 16) | (cy << 8) | cz;
+							const int b = bucket(cx, cy, cz);
+							for (int q = cstart[b]; q < cstart[b + 1]; q++) {
+								int k = cperm[q];
+								if (k > i && cellid[k] == want) test(k);
+							}
+						}
 					}
 				}
 			}
-		}
-#pragma unroll
-		for (int h = 0; h < 2; h++) {
-			if (valid[h]) {
-				nbr[2 * row[h]]     = lo[h] | (unsigned long long) min(cnt[h], 0xffff);
-				nbr[2 * row[h] + 1] = hi[h];
+			else {
+				for (int k = i + 1; k < cut; k++) test(k);
 			}
+			unsigned long long lo = (unsigned long long) min(cnt, 0xffff), hi = 0;
+#pragma unroll
+			for (int q = 0; q < PRUNE_NBR; q++) {
+				if (q < cnt) {
+					if (q < 3) lo |= (unsigned long long) e[q] << (16 * (q + 1));
+					else hi |= (unsigned long long) e[q] << (16 * (q - 3));
+				}
+			}
+			nbr[2 * i]     = lo;
+			nbr[2 * i + 1] = hi;
 		}
 	}
 	__syncthreads();
@@ -242,14 +307,16 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 			if (base + lane < cut) { vlo = nbr[2 * (base + lane)]; vhi = nbr[2 * (base + lane) + 1]; }
 			const int lolo = (int) (unsigned int) vlo, lohi = (int) (unsigned int) (vlo >> 32);
 			const int hilo = (int) (unsigned int) vhi, hihi = (int) (unsigned int) (vhi >> 32);
-			const int lend = min(64, cut - base);
-			for (int l = 0; l < lend; l++) {
+			// only rows that have close later rows can change anything: walk those, in order
+			unsigned long long todo = __ballot((lolo & 0xffff) != 0);
+			while (todo) {
+				const int l = __ffsll((long long) todo) - 1;
+				todo &= todo - 1;
 				const int i = base + l;
 				unsigned int om = (unsigned int) __builtin_amdgcn_readlane((int) absorbed, l);
 				if ((om >> s0) & 1u) continue;
 				const unsigned int w0 = (unsigned int) __builtin_amdgcn_readlane(lolo, l);
 				const int cnt = (int) (w0 & 0xffff);
-				if (cnt == 0) continue;
 				if (cnt <= PRUNE_NBR) {
 					const unsigned long long lo = ((unsigned long long) (unsigned int) __builtin_amdgcn_readlane(lohi, l) << 32) | w0;
 					const unsigned long long hi = ((unsigned long long) (unsigned int) __builtin_amdgcn_readlane(hihi, l) << 32) |
