@@ -475,33 +475,35 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 	// stable descending order (mlist.Sort, :129): bitonic sort on the weight's bit pattern, then runs of
 	// equal weights put back in map order
 	{
-		unsigned long long* skey = (unsigned long long*) sortw;   // [NS] keys, then overwritten by the sorted weights
+		unsigned long long* sv = (unsigned long long*) sortw;   // [NS] sort words, then overwritten by the sorted weights
 		int NS = 2;
 		while (NS < no) NS <<= 1;
-		for (int t = tid; t < NS; t += 256) {
-			skey[t]    = (t < no) ? prune_key(keyw[t]) : 0ull;
-			sortsrc[t] = (t < no) ? t : -1;
+		for (int t = tid; t < NS; t += 256) sv[t] = (t < no) ? prune_pack(keyw[t], t) : 0ull;
+		__syncthreads();
+		prune_bitonic(sv, NS, tid);
+		// runs that agree in the key bits: order by (weight desc, map index asc); the head thread sorts its run
+		for (int r = tid; r + 1 < no; r += 256) {
+			const unsigned long long kb = prune_kbits(sv[r]);
+			if (prune_kbits(sv[r + 1]) != kb || (r > 0 && prune_kbits(sv[r - 1]) == kb)) continue;
+			int e = r + 2;
+			while (e < no && prune_kbits(sv[e]) == kb) e++;
+			for (int x = r + 1; x < e; x++) {
+				unsigned long long vx = sv[x];
+				int sx = prune_slot(vx);
+				double wx = keyw[sx];
+				int y = x - 1;
+				while (y >= r) {
+					int sy = prune_slot(sv[y]);
+					if (keyw[sy] > wx || (keyw[sy] == wx && sy < sx)) break;
+					sv[y + 1] = sv[y];
+					y--;
+				}
+				sv[y + 1] = vx;
+			}
 		}
 		__syncthreads();
-		prune_bitonic(skey, sortsrc, NS, tid);
-		int tie = 0;
-		for (int r = tid; r + 1 < no; r += 256) tie |= (skey[r] == skey[r + 1]);
-		if (__syncthreads_or(tie)) {
-			if (tid == 0) {
-				int r = 0;
-				while (r < no) {
-					int e = r + 1;
-					while (e < no && skey[e] == skey[r]) e++;
-					for (int x = r + 1; x < e; x++) {
-						int sx = sortsrc[x], y = x - 1;
-						while (y >= r && sortsrc[y] > sx) { sortsrc[y + 1] = sortsrc[y]; y--; }
-						sortsrc[y + 1] = sx;
-					}
-					r = e;
-				}
-			}
-			__syncthreads();
-		}
+		for (int r = tid; r < no; r += 256) sortsrc[r] = prune_slot(sv[r]);
+		__syncthreads();
 		for (int r = tid; r < no; r += 256) sortw[r] = keyw[sortsrc[r]];   // same bytes as skey[r]: each thread rewrites its own slots
 		__syncthreads();
 	}

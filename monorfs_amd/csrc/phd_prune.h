@@ -43,7 +43,7 @@ __host__ __device__ inline PruneLds prune_lds(int cutcap)
 	l.sm    = l.sw + cc;
 	l.order = l.sm + 3 * cc;                 // int[cc]
 	l.x     = l.order + cc / 2;              // sort keys u64[NS] + slots int[NS]  |  nbr, rad2, owner, cell lists (see `rest`)
-	int sortd = NS + NS / 2;
+	int sortd = NS;
 	// nbr u64[2*cc], rad2 double[cc], owner/cellid/cperm int[cc] each, cstart int[NB+2], cfill int[NB], bred double[28], absb int[64]
 	int rest  = 2 * cc + cc + (3 * cc) / 2 + (PRUNE_NB + 2) / 2 + PRUNE_NB / 2 + 28 + 32 + 4;
 	l.scan  = l.x + (sortd > rest ? sortd : rest);
@@ -58,23 +58,45 @@ __device__ __forceinline__ unsigned long long prune_key(double w)
 	return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
 
-// bitonic sort of n (power of two) entries, largest key first
-__device__ __forceinline__ void prune_bitonic(unsigned long long* key, int* slot, int n, int tid)
+// Sort entries are one 64-bit word: the top 44 bits of the weight's key (sign, exponent, 32 mantissa bits),
+// then a 20-bit payload (slot). Entries whose weights agree in those 44 bits (relative difference below
+// 2.4e-10) come out adjacent in arbitrary order; the caller then orders each such run by (full weight desc,
+// canonical index asc) — the reference's sort made stable. 0 sorts last (padding).
+#define PRUNE_SLOT_BITS 20
+#define PRUNE_SLOT_MASK ((1u << PRUNE_SLOT_BITS) - 1u)
+__device__ __forceinline__ unsigned long long prune_pack(double w, int slot)
+{
+	return (prune_key(w) & ~(unsigned long long) PRUNE_SLOT_MASK) | (unsigned int) slot;
+}
+__device__ __forceinline__ int prune_slot(unsigned long long v) { return (int) ((unsigned int) v & PRUNE_SLOT_MASK); }
+__device__ __forceinline__ unsigned long long prune_kbits(unsigned long long v) { return v >> PRUNE_SLOT_BITS; }
+
+__device__ __forceinline__ void prune_ce(unsigned long long* v, int t, int j, int k)
+{
+	int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+	int q = i | j;
+	unsigned long long a = v[i], b = v[q];
+	bool desc = (i & k) == 0;
+	if (desc ? (a < b) : (a > b)) { v[i] = b; v[q] = a; }
+}
+
+// bitonic sort of n (power of two) words, largest first, by 256 threads. Compare-exchange t belongs to the
+// 128-element block t / 64 for every distance j <= 64, and a wave keeps the same blocks from one distance to
+// the next, so those sub-steps need no workgroup barrier — only the distances >= 128 and the stage ends do.
+__device__ __forceinline__ void prune_bitonic(unsigned long long* v, int n, int tid)
 {
 	for (int k = 2; k <= n; k <<= 1) {
-		for (int j = k >> 1; j > 0; j >>= 1) {
-			for (int t = tid; t < (n >> 1); t += 256) {
-				int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-				int q = i | j;
-				unsigned long long a = key[i], b = key[q];
-				bool desc = (i & k) == 0;
-				if (desc ? (a < b) : (a > b)) {
-					key[i] = b; key[q] = a;
-					int s = slot[i]; slot[i] = slot[q]; slot[q] = s;
-				}
-			}
+		int j = k >> 1;
+		for (; j >= 128; j >>= 1) {
+			for (int t = tid; t < (n >> 1); t += 256) prune_ce(v, t, j, k);
 			__syncthreads();
 		}
+		for (; j > 0; j >>= 1) {
+			for (int t = tid; t < (n >> 1); t += 256) prune_ce(v, t, j, k);
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+			__builtin_amdgcn_wave_barrier();
+		}
+		__syncthreads();
 	}
 }
 
@@ -86,8 +108,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	double* sw    = smem + lay.sw;                         // [cut] sorted weights
 	double* sm    = smem + lay.sm;                         // [3][cc] sorted means
 	int*    order = (int*) (smem + lay.order);             // [cut] emit slot of rank r
-	unsigned long long* skey = (unsigned long long*) (smem + lay.x);   // [NS] sort keys
-	int*    sslot = (int*) (skey + NS);                    // [NS] emit slots
+	unsigned long long* sv = (unsigned long long*) (smem + lay.x);     // [NS] sort words
 	unsigned long long* nbr = (unsigned long long*) (smem + lay.x);    // [cut][2]: count + up to 7 close later rows
 	double* rad2  = (double*) (nbr + 2 * cc);              // [cut] squared Euclidean bound of row i (inf: none)
 	double* bred  = rad2 + cc;                             // [28] block reduction scratch
@@ -118,40 +139,41 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 			const int from = first ? 0 : (n >> 1);
 			for (int t = from + tid; t < n; t += 256) {
 				int e = taken + (t - from);
-				bool in = e < ne;
-				skey[t]  = in ? prune_key(a.emit_w[eb + e]) : 0ull;
-				sslot[t] = in ? e : -1;
+				sv[t] = (e < ne) ? prune_pack(a.emit_w[eb + e], e) : 0ull;
 			}
 			taken += n - from;
 			first = false;
 			__syncthreads();
-			prune_bitonic(skey, sslot, n, tid);
-			// equal weights: the reference's list order decides (canonical index ascending)
-			int tie = 0;
-			for (int r = tid; r + 1 < n; r += 256) tie |= (skey[r] == skey[r + 1] && sslot[r] >= 0 && sslot[r + 1] >= 0);
-			if (__syncthreads_or(tie)) {
-				if (tid == 0) {
-					int r = 0;
-					while (r < n && sslot[r] >= 0) {
-						int e = r + 1;
-						while (e < n && sslot[e] >= 0 && skey[e] == skey[r]) e++;
-						for (int x = r + 1; x < e; x++) {   // insertion sort of the run by canonical index
-							int s = sslot[x];
-							int ix = a.emit_idx[eb + s];
-							int y = x - 1;
-							while (y >= r && a.emit_idx[eb + sslot[y]] > ix) { sslot[y + 1] = sslot[y]; y--; }
-							sslot[y + 1] = s;
-						}
-						r = e;
+			prune_bitonic(sv, n, tid);
+			// runs that agree in the key bits: order by (weight desc, canonical index asc); the thread at the
+			// head of a run sorts it (runs are disjoint)
+			for (int r = tid; r + 1 < n; r += 256) {
+				const unsigned long long kb = prune_kbits(sv[r]);
+				if (sv[r + 1] == 0ull || prune_kbits(sv[r + 1]) != kb || (r > 0 && prune_kbits(sv[r - 1]) == kb)) continue;
+				int e = r + 2;
+				while (e < n && sv[e] != 0ull && prune_kbits(sv[e]) == kb) e++;
+				for (int x = r + 1; x < e; x++) {   // insertion sort of the run
+					unsigned long long vx = sv[x];
+					int sx = prune_slot(vx);
+					double wx = a.emit_w[eb + sx];
+					int ix = a.emit_idx[eb + sx];
+					int y = x - 1;
+					while (y >= r) {
+						int sy = prune_slot(sv[y]);
+						double wy = a.emit_w[eb + sy];
+						if (wy > wx || (wy == wx && a.emit_idx[eb + sy] < ix)) break;   // sy stays before sx
+						sv[y + 1] = sv[y];
+						y--;
 					}
+					sv[y + 1] = vx;
 				}
-				__syncthreads();
 			}
+			__syncthreads();
 		}
 		for (int r = tid; r < cut; r += 256) {
-			int s = sslot[r];
-			order[r] = s;
-			sw[r]    = a.emit_w[eb + s];
+			int slt = prune_slot(sv[r]);
+			order[r] = slt;
+			sw[r]    = a.emit_w[eb + slt];
 		}
 	}
 	__syncthreads();
