@@ -62,14 +62,19 @@ def cpu_baseline(frame, params, sample, threads):
         return st
 
     orc.slam_update(params, state(min(P, threads)), frame.z, u=0.5, threads=threads)   # warm-up
-    st = state(P)
     stages = np.zeros(4)
-    t0 = time.perf_counter()
-    orc.slam_update(params, st, frame.z, u=0.5, threads=threads, stage_times=stages)
-    dt = time.perf_counter() - t0
-    return {"value": P * frame.C * frame.M / dt, "unit": "PHD updates/s", "cores": threads, "kind": "port",
-            "sample": "1 step of %d of the %d particles (C=%d, M=%d), oracle/phd_oracle.cpp with OpenMP over particles, %.2f s"
-                      % (P, frame.P, frame.C, frame.M, dt),
+    steps, elapsed = 0, 0.0
+    while elapsed < 12.0 and steps < 200:   # about 10-30 s of CPU work, every step from the same input
+        st = state(P)
+        stt = np.zeros(4)
+        t0 = time.perf_counter()
+        orc.slam_update(params, st, frame.z, u=0.5, threads=threads, stage_times=stt)
+        elapsed += time.perf_counter() - t0
+        stages += stt
+        steps += 1
+    return {"value": steps * P * frame.C * frame.M / elapsed, "unit": "PHD updates/s", "cores": threads, "kind": "port",
+            "sample": "%d steps of %d of the %d particles (C=%d, M=%d), oracle/phd_oracle.cpp with OpenMP over particles, %.1f s"
+                      % (steps, P, frame.P, frame.C, frame.M, elapsed),
             "stage_share": {k: float(v / stages.sum()) for k, v in zip(("predict", "correct", "prune", "reweight"), stages)}}
 
 
@@ -186,7 +191,7 @@ def main():
             out["kernel_ms"] = kernels
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 16)
-            sample = args.cpu_sample or max(threads, min(P, 16 * threads))
+            sample = args.cpu_sample or P
             out["cpu_baseline"] = cpu_baseline(frame, params, sample, threads)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))

@@ -11,8 +11,9 @@ from collections import defaultdict
 
 
 def short(name):
-    name = name.replace("void ", "")
-    return name.split("(")[0]
+    import re
+    name = name.replace("void ", "").split("(")[0]
+    return re.sub(r"<.*>$", "", name)
 
 
 def load_counters(d):
@@ -70,6 +71,14 @@ def main():
     os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
     open(os.path.join(root, "profiles", name + ".md"), "w").write("\n".join(lines) + "\n")
     json.dump(out, open(os.path.join(root, "profiles", name + ".json"), "w"), indent=1)
+    # per-launch HBM bytes of every kernel, read by bench.py for `roofline.traffic`
+    if len(sys.argv) > 3:
+        tfile = os.path.join(root, "profiles", "r01_hbm_traffic.json")
+        traffic = json.load(open(tfile)) if os.path.exists(tfile) else {}
+        traffic[sys.argv[3]] = {k: (v["hbm_read_bytes"] or 0) + (v["hbm_write_bytes"] or 0) for k, v in out["kernels"].items()
+                                if v["hbm_read_bytes"] is not None}
+        traffic["_note"] = "HBM bytes per launch = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 (rocprofv3 --pmc, separate passes; gfx950 FETCH_SIZE correction)"
+        json.dump(traffic, open(tfile, "w"), indent=1)
     print("\n".join(lines))
 
 
