@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="particles in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP events")
+    ap.add_argument("--force-dist", action="store_true", help="take the sharded (RCCL) step path even with one rank (rehearsal)")
     return ap.parse_args()
 
 
@@ -91,8 +92,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the PHD path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from monorfs_amd import navigator
@@ -110,7 +113,7 @@ def main():
     nav.set_frozen(True)     # steady state: every step sees the same P x C x M input
     lib, h = nav._lib, nav._h
 
-    if world > 1:
+    if use_dist:
         Pg = P * world
         gw = torch.as_tensor(DevArray(lib.phd_device_global_weights(h, Pg), Pg), device="cuda")
         scounts = np.zeros(world, np.int32)
@@ -118,7 +121,7 @@ def main():
         ip = C.POINTER(C.c_int32)
 
     def step(u=0.5):
-        if world == 1:
+        if not use_dist:
             nav.step_async(u)
             return
         nav._check(lib.phd_step_local_async(h, 0))
@@ -141,7 +144,7 @@ def main():
         nav._check(lib.phd_migration_unpack_async(h))
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
         nav.sync()
@@ -156,7 +159,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -196,7 +199,7 @@ def main():
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     nav.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -77,3 +77,91 @@ def test_full_size_step_resamples_consistently():
     assert all(np.array_equal(x, y) for x, y in zip(m1, m2))
     nav.close()
     nav2.close()
+
+
+class _Dev:
+    def __init__(self, ptr, n, typestr="<f8"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_step_equals_single_handle(world):
+    """The multi-GPU step sequence (local step, all-gather of the weights, global normalise/resample on every
+    rank, plan, pack, all-to-all, unpack) played by `world` handles on ONE GPU, the exchanges done with
+    device-to-device copies, must leave exactly the state a single handle holding all particles computes."""
+    import ctypes as C
+    import torch
+    from monorfs_amd import navigator
+    Pl, Cc, M = 96, 80, 20
+    f = Frame(Pl * world, Cc, M, 77, weight_profile="steady")
+    p1 = prm3d_defaults(max_particles=Pl * world, max_components=600, max_measurements=M)
+    one = navigator.PHDNavigator(p1, particlecount=Pl * world)
+    one.upload_state(f.planes(), f.counts, f.poses, f.weights)
+    navs = []
+    planes = f.planes()
+    for r in range(world):
+        pr = prm3d_defaults(max_particles=Pl, max_components=600, max_measurements=M)
+        nv = navigator.PHDNavigator(pr, particlecount=Pl)
+        sl = slice(r * Pl, (r + 1) * Pl)
+        nv.upload_state(planes[:, sl], f.counts[sl], f.poses[sl], f.weights[sl])
+        nv.set_measurements(f.z)
+        navs.append(nv)
+    lib = navs[0]._lib
+    ip = C.POINTER(C.c_int32)
+    Pg = Pl * world
+    resampled = []
+    for step in range(2):
+        u = 0.3 + 0.2 * step
+        one.SlamUpdate(None, f.z, u_resample=u)
+        resampled.append(one.resample_sources()[1])
+        # local steps + "all-gather"
+        gws = [torch.as_tensor(_Dev(lib.phd_device_global_weights(nv._h, Pg), Pg), device="cuda") for nv in navs]
+        for nv in navs:
+            nv._check(lib.phd_step_local_async(nv._h, 0))
+        lws = [torch.as_tensor(_Dev(lib.phd_device_local_weights(nv._h), Pl), device="cuda").clone() for nv in navs]
+        for g in gws:
+            g.copy_(torch.cat(lws))
+        torch.cuda.synchronize()
+        sc, rc, sends, recvs, recs = [], [], [], [], []
+        for r, nv in enumerate(navs):
+            nv._check(lib.phd_step_global_async(nv._h, r, world, C.c_double(u)))
+            s, q = np.zeros(world, np.int32), np.zeros(world, np.int32)
+            nv._check(lib.phd_migration_plan(nv._h, r, world, s.ctypes.data_as(ip), q.ctypes.data_as(ip)))
+            nv._check(lib.phd_migration_pack_async(nv._h))
+            sc.append(s); rc.append(q)
+        for r, nv in enumerate(navs):
+            bpp = C.c_int64(0)
+            sp = lib.phd_migration_send_buffer(nv._h, C.byref(bpp))
+            rp = lib.phd_migration_recv_buffer(nv._h)
+            rec = bpp.value // 8
+            recs.append(rec)
+            sends.append(torch.as_tensor(_Dev(sp, max(int(sc[r].sum()), 1) * rec), device="cuda") if sp else None)
+            recvs.append(torch.as_tensor(_Dev(rp, max(int(rc[r].sum()), 1) * rec), device="cuda") if rp else None)
+        # "all-to-all": rank a's block for rank b lands in b's receive buffer after the blocks of ranks < a
+        for b in range(world):
+            off = 0
+            for a_ in range(world):
+                if a_ == b:
+                    continue
+                n = int(sc[a_][b])
+                assert n == int(rc[b][a_])
+                if n:
+                    so = int(sum(sc[a_][x] for x in range(b) if x != a_))
+                    recvs[b][off * recs[b]:(off + n) * recs[b]].copy_(sends[a_][so * recs[a_]:(so + n) * recs[a_]])
+                off += n
+        torch.cuda.synchronize()
+        for nv in navs:
+            nv._check(lib.phd_migration_unpack_async(nv._h))
+            nv.sync()
+        # compare with the single handle
+        w_one = one.VehicleWeights
+        w_sh = np.concatenate([nv.VehicleWeights for nv in navs])
+        assert np.array_equal(w_one, w_sh), "step %d: weights differ" % step
+        assert np.array_equal(one.poses(), np.concatenate([nv.poses() for nv in navs]))
+        for g in (0, Pl - 1, Pl, Pg - 1):
+            a_, b_ = one.MapModel(g), navs[g // Pl].MapModel(g % Pl)
+            assert all(np.array_equal(x, y) for x, y in zip(a_, b_)), "step %d particle %d" % (step, g)
+    assert any(resampled), "no step resampled: the migration path was not exercised"
+    one.close()
+    for nv in navs:
+        nv.close()
