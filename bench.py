@@ -114,6 +114,8 @@ def main():
     lib, h = nav._lib, nav._h
 
     if use_dist:
+        # the library launches on torch's current stream: RCCL collectives and kernels are ordered by the stream
+        nav._check(lib.phd_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream), 1))
         Pg = P * world
         gw = torch.as_tensor(DevArray(lib.phd_device_global_weights(h, Pg), Pg), device="cuda")
         scounts = np.zeros(world, np.int32)
@@ -125,9 +127,8 @@ def main():
             nav.step_async(u)
             return
         nav._check(lib.phd_step_local_async(h, 0))
-        lw = torch.as_tensor(DevArray(lib.phd_device_local_weights(h), P), device="cuda")   # syncs the handle's stream
+        lw = torch.as_tensor(DevArray(lib.phd_device_local_weights(h), P), device="cuda")
         dist.all_gather_into_tensor(gw, lw)
-        torch.cuda.current_stream().synchronize()
         nav._check(lib.phd_step_global_async(h, rank, world, u))
         nav._check(lib.phd_migration_plan(h, rank, world, scounts.ctypes.data_as(ip), rcounts.ctypes.data_as(ip)))
         if True:
@@ -140,7 +141,6 @@ def main():
             send = torch.as_tensor(DevArray(sptr, max(ns, 1) * rec), device="cuda")[:ns * rec] if sptr else torch.empty(0, dtype=torch.float64, device="cuda")
             recv = torch.as_tensor(DevArray(rptr, max(nr, 1) * rec), device="cuda")[:nr * rec] if rptr else torch.empty(0, dtype=torch.float64, device="cuda")
             dist.all_to_all_single(recv, send, (rcounts * rec).tolist(), (scounts * rec).tolist())
-            torch.cuda.current_stream().synchronize()
         nav._check(lib.phd_migration_unpack_async(h))
 
     def barrier():

@@ -195,6 +195,10 @@ void* phd_migration_recv_buffer(phd_navigator* nav);
 int   phd_migration_pack_async(phd_navigator* nav);
 int   phd_migration_unpack_async(phd_navigator* nav);
 void* phd_stream(phd_navigator* nav);                               /* hipStream_t of the handle   */
+/* Lend the handle a host stream (hipStream_t, NULL = the default stream): kernels and the host's
+ * collectives are then ordered by that stream and need no synchronisation in between;
+ * lend = 0 returns to the handle's own stream.                                                   */
+int   phd_set_stream(phd_navigator* nav, void* stream, uint8_t lend);
 
 /* Per-kernel device time in milliseconds, from HIP events recorded around every launch on the
  * handle's stream: the mean over the launches since the last phd_timing_reset; names[i] -> ms[i];

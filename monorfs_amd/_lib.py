@@ -74,6 +74,7 @@ def load():
         "phd_migration_pack_async": (C.c_int, [P]),
         "phd_migration_unpack_async": (C.c_int, [P]),
         "phd_stream": (C.c_void_p, [P]),
+        "phd_set_stream": (C.c_int, [P, C.c_void_p, C.c_uint8]),
         "phd_timing_reset": (C.c_int, [P, C.c_uint8]),
         "phd_last_timings": (C.c_int, [P, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(dp)]),
     }
@@ -90,5 +91,5 @@ EXPORTS = ["phd_api_version", "phd_default_params", "phd_create", "phd_create_er
            "phd_stage_setloglik", "phd_resample", "phd_particle_depleted", "phd_step_local_async",
            "phd_device_local_weights", "phd_device_global_weights", "phd_step_global_async", "phd_migration_plan",
            "phd_plan_migration", "phd_migration_send_buffer", "phd_migration_recv_buffer", "phd_migration_pack_async",
-           "phd_migration_unpack_async", "phd_stream", "phd_timing_reset", "phd_last_timings", "phd_upload_state_soa",
+           "phd_migration_unpack_async", "phd_stream", "phd_set_stream", "phd_timing_reset", "phd_last_timings", "phd_upload_state_soa",
            "phd_download_state_soa"]

@@ -28,7 +28,9 @@ struct phd_navigator {
 	phd_params  prm;
 	DevParams   dp;
 	int         device = 0;
-	hipStream_t stream = nullptr;
+	hipStream_t stream = nullptr;      // the stream every kernel of this handle is launched on
+	hipStream_t own_stream = nullptr;  // created by phd_create; `stream` unless the host lent its own
+	bool sel_host_valid = false;       // h_sel mirrors the device-side bank roles without a round trip
 	int Pcap = 0, cap = 0, Mcap = 0, ecap = 0, Jcap = 0, cutcap = 0;
 	int P = 0, M = 0;
 	bool frozen = false;
@@ -54,6 +56,7 @@ struct phd_navigator {
 	// migration (multi-GPU resampling)
 	double* d_send = nullptr; double* d_recv = nullptr; int* d_plan = nullptr; int migcap = 0;
 	std::vector<int> h_plan_send, h_plan_recv;       // particle lists
+	int* d_sendlist = nullptr; int sendlistcap = 0; int* d_code = nullptr;
 	int nsend = 0, nrecv = 0, last_world_particles = 1;
 
 	// host mirrors handed out by the getters
@@ -334,6 +337,7 @@ int sync_state(phd_navigator* nav)
 	HC(hipMemcpy(nav->h_sel, nav->d_sel + nav->parity * 4, 4 * sizeof(int), hipMemcpyDeviceToHost));
 	HC(hipMemcpy(nav->h_info, nav->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost));
 	HC(hipMemcpy(&nav->h_flags, nav->d_flags, sizeof(int), hipMemcpyDeviceToHost));
+	nav->sel_host_valid = true;
 	return PHD_OK;
 }
 
@@ -404,7 +408,8 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	nav->P = 0;
 
 	auto dalloc = [&](void** ptr, size_t bytes) { return hipMalloc(ptr, std::max<size_t>(bytes, 16)) == hipSuccess; };
-	bool ok = hipStreamCreateWithFlags(&nav->stream, hipStreamNonBlocking) == hipSuccess;
+	bool ok = hipStreamCreateWithFlags(&nav->own_stream, hipStreamNonBlocking) == hipSuccess;
+	nav->stream = nav->own_stream;
 	size_t plane = (size_t) nav->Pcap * nav->cap;
 	for (int i = 0; i < 3 && ok; i++) {
 		ok = ok && dalloc((void**) &nav->bank[i].mix, plane * 10 * 8);
@@ -464,9 +469,9 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_sel); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
-	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cm); hipFree(nav->d_pair_ck); hipFree(nav->d_pair_w); hipFree(nav->d_pair_count); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
+	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cm); hipFree(nav->d_pair_ck); hipFree(nav->d_pair_w); hipFree(nav->d_pair_count); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
-	if (nav->stream) hipStreamDestroy(nav->stream);
+	if (nav->own_stream) hipStreamDestroy(nav->own_stream);
 	delete nav;
 }
 
@@ -617,6 +622,7 @@ int phd_step_async(phd_navigator* nav, uint8_t onlymapping, double u_resample)
 	HC(hipGetLastError());
 	nav->parity ^= 1;
 	nav->stage_valid = false;
+	nav->sel_host_valid = false;   // the rotation depends on the resampling flag, known only on the device
 	return PHD_OK;
 }
 
@@ -922,8 +928,9 @@ void* phd_device_local_weights(phd_navigator* nav)
 {
 	if (!nav) return nullptr;
 	hipSetDevice(nav->device);
-	// un-normalised weights written by the local step live in the OUT bank of the current roles
-	if (sync_state(nav)) return nullptr;
+	// un-normalised weights written by the local step live in the OUT bank of the current roles; the host
+	// mirror of the roles is kept current by phd_migration_unpack_async, so this needs no round trip there
+	if (!nav->sel_host_valid && sync_state(nav)) return nullptr;
 	return nav->bank[nav->h_sel[SEL_OUT]].weights;
 }
 
@@ -1000,8 +1007,11 @@ int phd_migration_plan(phd_navigator* nav, int rank, int world_size, int32_t* se
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	if (world_size < 1 || rank < 0 || rank >= world_size || !send_counts || !recv_counts) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_plan: bad arguments");
 	hipSetDevice(nav->device);
-	int rc = sync_state(nav);
+	int rc = PHD_OK;
+	if (!nav->sel_host_valid) rc = sync_state(nav);
 	if (rc) return rc;
+	HC(hipMemcpyAsync(nav->h_info, nav->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, nav->stream));
+	HC(hipStreamSynchronize(nav->stream));
 	const int Pl = nav->P, Pg = Pl * world_size, first = rank * Pl;
 	for (int r = 0; r < world_size; r++) send_counts[r] = recv_counts[r] = 0;
 	nav->nsend = nav->nrecv = 0;
@@ -1048,15 +1058,17 @@ int phd_migration_pack_async(phd_navigator* nav)
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	hipSetDevice(nav->device);
 	if (nav->nsend == 0) return PHD_OK;
-	// the plan ints live behind the global source vector in d_plan? no: a dedicated upload area
-	int* d_list = nullptr;
-	HC(hipMalloc((void**) &d_list, (size_t) nav->nsend * 4));
-	HC(hipMemcpy(d_list, nav->h_plan_send.data(), (size_t) nav->nsend * 4, hipMemcpyHostToDevice));
+	if (nav->nsend > nav->sendlistcap) {
+		HC(hipStreamSynchronize(nav->stream));
+		hipFree(nav->d_sendlist);
+		nav->d_sendlist = nullptr;
+		HC(hipMalloc((void**) &nav->d_sendlist, (size_t) nav->nsend * 4));
+		nav->sendlistcap = nav->nsend;
+	}
+	HC(hipMemcpyAsync(nav->d_sendlist, nav->h_plan_send.data(), (size_t) nav->nsend * 4, hipMemcpyHostToDevice, nav->stream));
 	StepBufs b = make_bufs(nav);
-	hipLaunchKernelGGL(k_pack_particles, dim3(nav->nsend), dim3(256), 0, nav->stream, b, d_list, nav->d_send);
-	hipError_t e = hipStreamSynchronize(nav->stream);
-	hipFree(d_list);
-	if (e != hipSuccess) return nav->fail(PHD_ERR_DEVICE, hipGetErrorString(e));
+	hipLaunchKernelGGL(k_pack_particles, dim3(nav->nsend), dim3(256), 0, nav->stream, b, nav->d_sendlist, nav->d_send);
+	HC(hipGetLastError());
 	return PHD_OK;
 }
 
@@ -1074,19 +1086,35 @@ int phd_migration_unpack_async(phd_navigator* nav)
 		HC(hipGetLastError());
 	}
 	else {
-		int* d_code = nullptr;
-		HC(hipMalloc((void**) &d_code, (size_t) nav->P * 4));
-		HC(hipMemcpy(d_code, nav->h_plan_recv.data(), (size_t) nav->P * 4, hipMemcpyHostToDevice));
+		if (!nav->d_code) HC(hipMalloc((void**) &nav->d_code, (size_t) nav->Pcap * 4));
+		HC(hipMemcpyAsync(nav->d_code, nav->h_plan_recv.data(), (size_t) nav->P * 4, hipMemcpyHostToDevice, nav->stream));
 		timer_begin(nav, T_GR);
-		hipLaunchKernelGGL(k_unpack_gather, dim3(nav->P), dim3(256), 0, nav->stream, b, d_code, nav->d_recv,
+		hipLaunchKernelGGL(k_unpack_gather, dim3(nav->P), dim3(256), 0, nav->stream, b, nav->d_code, nav->d_recv,
 		                   1.0 / (double) nav->last_world_particles, sel_next, nav->frozen ? 1 : 0);
 		timer_end(nav, T_GR);
-		hipError_t e = hipStreamSynchronize(nav->stream);
-		hipFree(d_code);
-		if (e != hipSuccess) return nav->fail(PHD_ERR_DEVICE, hipGetErrorString(e));
+		HC(hipGetLastError());
 	}
 	nav->parity ^= 1;
 	nav->stage_valid = false;
+	if (nav->sel_host_valid && !nav->frozen) {   // same rotation as the kernels wrote to the device
+		int I = nav->h_sel[SEL_IN], O = nav->h_sel[SEL_OUT], T = nav->h_sel[SEL_TMP];
+		if (nav->h_info[1]) { nav->h_sel[0] = T; nav->h_sel[1] = I; nav->h_sel[2] = O; nav->h_sel[3] = T; }
+		else                { nav->h_sel[0] = O; nav->h_sel[1] = T; nav->h_sel[2] = I; nav->h_sel[3] = O; }
+	}
+	else if (nav->sel_host_valid) {
+		nav->h_sel[3] = nav->h_info[1] ? nav->h_sel[SEL_TMP] : nav->h_sel[SEL_OUT];
+	}
+	return PHD_OK;
+}
+
+// Lend the handle a stream of the host (e.g. the framework's current stream) so that the library's kernels and
+// the host's collectives are ordered by the stream itself (NULL = the default stream); lend = 0 returns to the handle's own.
+int phd_set_stream(phd_navigator* nav, void* stream, uint8_t lend)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	hipSetDevice(nav->device);
+	HC(hipStreamSynchronize(nav->stream));
+	nav->stream = lend ? (hipStream_t) stream : nav->own_stream;   // a NULL lent stream is the legacy default stream
 	return PHD_OK;
 }
 

@@ -105,6 +105,8 @@ def test_sharded_step_equals_single_handle(world):
         sl = slice(r * Pl, (r + 1) * Pl)
         nv.upload_state(planes[:, sl], f.counts[sl], f.poses[sl], f.weights[sl])
         nv.set_measurements(f.z)
+        # kernels of every handle and the copies that stand in for the collectives share torch's current stream
+        nv._check(nv._lib.phd_set_stream(nv._h, C.c_void_p(torch.cuda.current_stream().cuda_stream), 1))
         navs.append(nv)
     lib = navs[0]._lib
     ip = C.POINTER(C.c_int32)
