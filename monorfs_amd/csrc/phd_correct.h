@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void k_correct(const DevParams prm, const Step
 	__shared__ double part[4 * MP], denom[MP];
 	__shared__ double tile[TILE * CM_PLANES];   // [TILE][18]
 	__shared__ double etab[EXPTAB_N];
-	__shared__ int    s_npair;
+	__shared__ int    s_npair, s_ncand;
 
 	const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int M = a.M;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void k_correct(const DevParams prm, const Step
 	const int np = vin.count[p] + a.born_count[p];
 	const PoseD pose = load_pose(bin.poses + (size_t) p * 7);
 	exp_tab_init(etab, tid);
-	if (tid == 0) s_npair = 0;
+	if (tid == 0) { s_npair = 0; s_ncand = 0; }
 	for (int k = tid; k < MP; k += 256) {
 		double z[3] = {0, 0, 1}, x[3] = {0, 0, 0};
 		if (k < M) {
@@ -259,8 +259,10 @@ __global__ __launch_bounds__(256) void k_correct(const DevParams prm, const Step
 	const double* cm = a.cm + (size_t) p * a.cmcap;
 	int2*   pairs_ck = (int2*) (a.pair_ck + (size_t) p * a.ecap);
 	double* pairs_w  = a.pair_w + (size_t) p * a.ecap;
+	int*    cands    = a.cand + (size_t) p * a.candcap;   // (component << 8 | measurement) of the pairs worth a second look
 
 	for (int sweep = 0; sweep < 2; sweep++) {
+		if (sweep == 1 && s_ncand <= a.candcap) break;   // the queue held every candidate: handled below
 		for (int c0 = 0; c0 < np; c0 += TILE) {
 			const int c = c0 + tid;
 			if (c < np) {
@@ -283,7 +285,20 @@ __global__ __launch_bounds__(256) void k_correct(const DevParams prm, const Step
 						double sq = e0 * e0 + e1 * e1 + e2 * e2;
 						double d2 = quad_gen(Si, zx[b] - tt[0], zy[b] - tt[1], zr[b] - tt[2]);
 						double v  = tt[13] * (tt[12] * exp_neg(-0.5 * d2, etab));   // PD w * mc.Evaluate(z)
-						if (zv[b] && sq <= g2) wsum[b] += v;
+						const bool near = zv[b] && sq <= g2;
+						if (near) wsum[b] += v;
+						// only a pair with d2 <= dcut can reach MinWeight: remember it for the second pass
+						const bool cand = near && d2 <= tt[17];
+						unsigned long long bal = __ballot(cand);
+						if (bal) {
+							int base = 0, first = __ffsll((long long) bal) - 1;
+							if (lane == first) base = atomicAdd(&s_ncand, __popcll(bal));
+							base = __shfl(base, first, 64);
+							if (cand) {
+								int slot = base + __popcll(bal & lanemask_lt());
+								if (slot < a.candcap) cands[slot] = ((c0 + cc) << 8) | (b * 64 + lane);
+							}
+						}
 					}
 				};
 				int cc = wv;
@@ -335,6 +350,27 @@ __global__ __launch_bounds__(256) void k_correct(const DevParams prm, const Step
 			}
 			__syncthreads();
 		}
+	}
+	// second pass over the queued candidates only: w' = PD w q / (kappa + weightsum) >= MinWeight (:899)
+	if (s_ncand <= a.candcap) {
+		const int ncand = s_ncand;
+		for (int j = tid; j < ncand; j += 256) {
+			const int code = cands[j], c = code >> 8, k = code & 255;
+			double Si[9];
+#pragma unroll
+			for (int t = 0; t < 9; t++) Si[t] = cm[(size_t) (3 + t) * cstride + c];
+			const double d2 = quad_gen(Si, zs[k * 3] - cm[c], zs[k * 3 + 1] - cm[cstride + c], zs[k * 3 + 2] - cm[2 * cstride + c]);
+			const double q   = cm[(size_t) 12 * cstride + c] * exp_neg(-0.5 * d2, etab);
+			const double wgt = cm[(size_t) 13 * cstride + c] * q / denom[k];
+			if (!(wgt < minw)) {
+				int slot = atomicAdd(&s_npair, 1);
+				if (slot < a.ecap) {
+					pairs_ck[slot] = make_int2(c, k);
+					pairs_w[slot]  = wgt;
+				}
+			}
+		}
+		__syncthreads();
 	}
 	if (tid == 0) a.pair_count[p] = s_npair;
 }

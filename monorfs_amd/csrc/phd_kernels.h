@@ -71,6 +71,8 @@ struct StepBufs {
 	int*    pair_ck;     // [P][ecap][2]
 	double* pair_w;      // [P][ecap]
 	int*    pair_count;  // [P]
+	int*    cand;        // [P][candcap] candidate pairs of k_correct's first sweep
+	int     candcap;
 	// map estimate handed from k_alpha_assoc to k_alpha_density
 	double* alm;         // [P][3][Jcap] landmark means
 	int*    aJ;          // [P] landmarks

@@ -49,6 +49,7 @@ struct phd_navigator {
 	double* d_jscratch = nullptr;
 	double* d_cm = nullptr; int cmcap = 0;
 	int* d_pair_ck = nullptr; double* d_pair_w = nullptr; int* d_pair_count = nullptr;
+	int* d_cand = nullptr; int candcap = 0;
 	double* d_alm = nullptr; int* d_aJ = nullptr; double* d_account = nullptr;
 	double* d_stamps = nullptr;
 	double* d_gw = nullptr; int gwcap = 0;           // gathered weights of all ranks
@@ -160,6 +161,7 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.alpha = nav->d_alpha; b.setll = nav->d_setll; b.flags = nav->d_flags; b.murty = nav->d_murty; b.jscratch = nav->d_jscratch;
 	b.cm = nav->d_cm; b.cmcap = nav->cmcap; b.cmplane = (size_t) nav->Pcap * nav->cmcap;
 	b.pair_ck = nav->d_pair_ck; b.pair_w = nav->d_pair_w; b.pair_count = nav->d_pair_count;
+	b.cand = nav->d_cand; b.candcap = nav->candcap;
 	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account; b.stamps = nav->d_stamps;
 	return b;
 }
@@ -438,6 +440,8 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	ok = ok && dalloc((void**) &nav->d_cm, (size_t) CM_PLANES * nav->Pcap * nav->cmcap * 8);
 	ok = ok && dalloc((void**) &nav->d_pair_ck, E * 8) && dalloc((void**) &nav->d_pair_w, E * 8);
 	ok = ok && dalloc((void**) &nav->d_pair_count, (size_t) nav->Pcap * 4);
+	nav->candcap = 16 * nav->cmcap;   // a quarter of all pairs at 64 measurements; beyond it the full second sweep runs
+	ok = ok && dalloc((void**) &nav->d_cand, (size_t) nav->Pcap * nav->candcap * 4);
 #ifdef PHD_STAMPS
 	ok = ok && dalloc((void**) &nav->d_stamps, (size_t) nav->Pcap * 16 * 8);
 #endif
@@ -469,7 +473,7 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_sel); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
-	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cm); hipFree(nav->d_pair_ck); hipFree(nav->d_pair_w); hipFree(nav->d_pair_count); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
+	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cm); hipFree(nav->d_pair_ck); hipFree(nav->d_pair_w); hipFree(nav->d_pair_count); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
 	if (nav->own_stream) hipStreamDestroy(nav->own_stream);
 	delete nav;
