@@ -47,6 +47,21 @@ __device__ __forceinline__ unsigned int pk_next(unsigned int perm, int n, int me
 	return pk_reverse(perm, measurestart, n);
 }
 
+// the first n (<= 5) 12-bit fields of v in ascending order (9-comparator network)
+__device__ __forceinline__ unsigned long long pk_sort5(unsigned long long v, int n)
+{
+	int f[5];
+#pragma unroll
+	for (int i = 0; i < 5; i++) f[i] = (i < n) ? (int) ((v >> (12 * i)) & 4095) : 4096 + i;
+#define PK_CE(a_, b_) { int lo_ = min(f[a_], f[b_]), hi_ = max(f[a_], f[b_]); f[a_] = lo_; f[b_] = hi_; }
+	PK_CE(0, 1) PK_CE(3, 4) PK_CE(2, 4) PK_CE(2, 3) PK_CE(1, 4) PK_CE(0, 3) PK_CE(0, 2) PK_CE(1, 3) PK_CE(1, 2)
+#undef PK_CE
+	unsigned long long o = 0;
+#pragma unroll
+	for (int i = 0; i < 5; i++) o |= (unsigned long long) (f[i] & 4095) << (12 * i);
+	return o;
+}
+
 // log-sum-exp over every pairing of a cluster with n <= 5 rows, enumerated exactly like
 // LexicographicalPairing(component, map.Count) (`modelsize` is compared with COMPACTED row indices,
 // PHDNavigator.cs:493 / GraphCombinatorics.cs:293-299). mat: n x n, row stride 5, stride `ms` between entries.
@@ -351,9 +366,9 @@ __device__ __noinline__ int wave_murty(const MurtyLds& ws, MurtyNodes* nodes, in
 
 struct AlphaLds {
 	int zs, red, lm, pick, scr;                 // persistent, offsets in doubles
-	int p1_keyw, p1_sortw, p1_dw, p1_sortsrc, ns;   // phase 1 (ints follow: sortsrc[ns], dsrc[JL])
+	int p1_keyw, p1_sortw, p1_dw, p1_sortsrc, p1_selidx, ns;   // phase 1 (ints: sortsrc[ns], dsrc[JL]; selidx[ns])
 	int p2_tile, p2_part;                       // phase 2
-	int p3_zh, p3_pdj, p3_res, p3_adj, p3_adjT, p3_int, p3_x;   // phase 3 (ints: labl[JL], roots[JL], labz[MP]); x = mats | murty
+	int p3_zh, p3_pdj, p3_lmd, p3_res, p3_adj, p3_adjT, p3_mem, p3_int, p3_x;   // phase 3 (ints: labl[JL], roots[JL], cnt[JL], labz[MP]); x = mats | murty
 	int bytes;
 };
 
@@ -373,17 +388,20 @@ __host__ __device__ inline AlphaLds alpha_lds(int MP, int ncap)
 	l.p1_sortw = l.p1_keyw + ncap;
 	l.p1_dw = l.p1_sortw + ns;
 	l.p1_sortsrc = l.p1_dw + JL;
-	int ph1 = l.p1_sortsrc + (ns + JL + 1) / 2 - l.scr;
+	l.p1_selidx = l.p1_sortsrc + (ns + JL + 1) / 2;
+	int ph1 = l.p1_selidx + ns / 2 - l.scr;
 	l.p2_tile = l.scr;
 	l.p2_part = l.scr;
 	int ph2 = 0;
 	l.p3_zh = l.scr;
 	l.p3_pdj = l.p3_zh + 3 * JL;
-	l.p3_res = l.p3_pdj + JL;
+	l.p3_lmd = l.p3_pdj + JL;
+	l.p3_res = l.p3_lmd + JL;
 	l.p3_adj = l.p3_res + JL;
 	l.p3_adjT = l.p3_adj + JL * MW;
-	l.p3_int = l.p3_adjT + MP * (JL / 64);
-	l.p3_x   = l.p3_int + (2 * JL + MP + 1) / 2;
+	l.p3_mem = l.p3_adjT + MP * (JL / 64);
+	l.p3_int = l.p3_mem + 2 * JL;
+	l.p3_x   = l.p3_int + (3 * JL + MP + 1) / 2;
 	int xs = 25 * 64 > MURTY_LDS_DOUBLES ? 25 * 64 : MURTY_LDS_DOUBLES;
 	int ph3 = l.p3_x + xs + 2 - l.scr;
 	int mx = ph1 > ph2 ? ph1 : ph2;
@@ -395,8 +413,8 @@ __host__ __device__ inline AlphaLds alpha_lds(int MP, int ncap)
 // per-particle HBM slab used instead of LDS when J > ALPHA_JL (doubles; ints packed two per double)
 __host__ __device__ inline size_t alpha_jscratch_doubles(int Jcap)
 {
-	// lm 3J, dw J, zh 3J, pdj J, res J, adj 4J, part 4J  |  pick, dsrc, labl, roots : 4J ints
-	return (size_t) 17 * Jcap + 2 * (size_t) Jcap;
+	// lm 3J, dw J, zh 3J, lpd J, res J, adj 4J, part 4J  |  pick, dsrc, labl, roots : 4J ints  |  lmd J, memL J, memZ J, cnt J ints
+	return (size_t) 23 * Jcap;
 }
 
 template <int ZB>
@@ -424,7 +442,10 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 	const PoseD pose = load_pose(bin.poses + (size_t) p * 7);
 
 	for (int k = tid; k < MP * 3; k += 256) zs[k] = (k < M * 3) ? a.z[k] : 0.0;
+	exp_tab_init(etab, tid);
 
+	PHD_STAMP_DECL;
+	PHD_STAMP(0);
 	// ---- phase 1: BestMapEstimate (Map.cs:119-142)
 	double* keyw    = smem + lay.p1_keyw;              // [ncap] weights in map order
 	double* sortw   = smem + lay.p1_sortw;             // [ncap] weights, stable descending
@@ -472,9 +493,121 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 			s_J = J;
 		}
 	}
-	// stable descending order (mlist.Sort, :129): bitonic sort on the weight's bit pattern, then runs of
-	// equal weights put back in map order
-	{
+	PHD_STAMP(1);
+	__syncthreads();
+	const int J = s_J;
+	// stable descending order (mlist.Sort, :129). Only the first min(J, no) entries of the sorted list are ever
+	// read (the pick below takes at most J of them), so when J <= no the J heaviest are selected (radix select on
+	// the weight's bit pattern, ties by map index) and only those are ordered.
+	if (J >= 1 && J <= no) {
+		int* hist   = (int*) red;                                   // [256]
+		int* selidx = (int*) (smem + lay.p1_selidx);                // [J] selected components, unordered
+		__shared__ int s_bin, s_need, s_binc, s_nsel, s_wc[4];
+		__shared__ unsigned long long s_T;
+		unsigned long long prefix = 0;
+		int need = J, binc = 0, shift = 56;
+		for (; shift >= 0; shift -= 8) {
+			hist[tid] = 0;
+			__syncthreads();
+			for (int c0 = 0; c0 < no; c0 += 256) {
+				const int c = c0 + tid;
+				const unsigned long long key = (c < no) ? prune_key(keyw[c]) : 0ull;
+				const bool in = c < no && (shift == 56 || (key >> (shift + 8)) == (prefix >> (shift + 8)));
+				const int digit = (int) ((key >> shift) & 255);
+				// equal weights are common (components never detected since birth): the lanes that share the first
+				// candidate's digit add once, together
+				const unsigned long long cand = __ballot(in);
+				if (cand) {
+					const int lead = __ffsll((long long) cand) - 1;
+					const int d0 = __shfl(digit, lead, 64);
+					const unsigned long long same = __ballot(in && digit == d0);
+					if (lane == lead) atomicAdd(&hist[d0], __popcll(same));
+					else if (in && digit != d0) atomicAdd(&hist[digit], 1);
+				}
+			}
+			__syncthreads();
+			if (wv == 0) {   // the bin holding the need-th largest: lane l looks at bins 255 - 4l .. 252 - 4l
+				const int b0 = 255 - 4 * lane;
+				const int c0 = hist[b0], c1 = hist[b0 - 1], c2 = hist[b0 - 2], c3 = hist[b0 - 3];
+				const int tot = c0 + c1 + c2 + c3;
+				int incl = tot;
+#pragma unroll
+				for (int o = 1; o < 64; o <<= 1) {
+					int y = __shfl_up(incl, o, 64);
+					if (lane >= o) incl += y;
+				}
+				const int excl = incl - tot;
+				if (excl < need && need <= incl) {
+					int r = need - excl, b = b0, cb = c0;
+					if (r > c0) {
+						r -= c0; b = b0 - 1; cb = c1;
+						if (r > c1) {
+							r -= c1; b = b0 - 2; cb = c2;
+							if (r > c2) { r -= c2; b = b0 - 3; cb = c3; }
+						}
+					}
+					s_bin = b; s_need = r; s_binc = cb;
+				}
+			}
+			__syncthreads();
+			prefix |= (unsigned long long) s_bin << shift;
+			need = s_need;
+			binc = s_binc;
+			if (binc == 1) break;   // one weight carries this prefix: it is the J-th largest
+		}
+		if (binc == 1 && shift > 0) {
+			for (int c = tid; c < no; c += 256) {
+				const unsigned long long key = prune_key(keyw[c]);
+				if ((key >> shift) == (prefix >> shift)) s_T = key;
+			}
+			__syncthreads();
+			prefix = s_T;
+		}
+		const unsigned long long T = prefix;   // key of the J-th largest weight; `need` of the `binc` equal ones are taken
+		if (tid == 0) s_nsel = 0;
+		__syncthreads();
+		if (need == binc) {
+			for (int c = tid; c < no; c += 256) {
+				if (prune_key(keyw[c]) >= T) selidx[atomicAdd(&s_nsel, 1)] = c;
+			}
+		}
+		else {
+			// more weights equal to the J-th than fit: the first `need` in map order (stable sort)
+			int eqbase = 0;
+			for (int c0 = 0; c0 < no; c0 += 256) {
+				const int c = c0 + tid;
+				const unsigned long long key = (c < no) ? prune_key(keyw[c]) : 0ull;
+				const bool eq = c < no && key == T;
+				const unsigned long long bal = __ballot(eq);
+				if (lane == 0) s_wc[wv] = __popcll(bal);
+				__syncthreads();
+				int rank = eqbase + __popcll(bal & lanemask_lt());
+				for (int q = 0; q < wv; q++) rank += s_wc[q];
+				if ((c < no && key > T) || (eq && rank < need)) selidx[atomicAdd(&s_nsel, 1)] = c;
+				eqbase += s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+				__syncthreads();
+			}
+		}
+		__syncthreads();
+		// order the J selected by (weight desc, map index asc): every entry counts the entries before it
+		for (int t = tid; t < J; t += 256) {
+			const int ct = selidx[t];
+			const double wt = keyw[ct];
+			int rank = 0;
+#pragma unroll 4
+			for (int u = 0; u < J; u++) {
+				const int cu = selidx[u];
+				const double wu = keyw[cu];
+				rank += (wu > wt || (wu == wt && cu < ct)) ? 1 : 0;
+			}
+			sortw[rank]   = wt;
+			sortsrc[rank] = ct;
+		}
+		__syncthreads();
+	}
+	else if (J > no) {
+		// more landmarks than components: the whole list, bitonic sort on the weight's bit pattern, then runs of
+		// equal weights put back in map order
 		unsigned long long* sv = (unsigned long long*) sortw;   // [NS] sort words, then overwritten by the sorted weights
 		int NS = 2;
 		while (NS < no) NS <<= 1;
@@ -507,7 +640,7 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 		for (int r = tid; r < no; r += 256) sortw[r] = keyw[sortsrc[r]];   // same bytes as skey[r]: each thread rewrites its own slots
 		__syncthreads();
 	}
-	const int J = s_J;
+	PHD_STAMP(2);
 	// landmark-indexed arrays: LDS, or the HBM slab of this particle when the estimate is large
 	const bool inlds = J <= JL;
 	const int  JS = inlds ? JL : a.Jcap;               // stride of the landmark-indexed arrays
@@ -515,7 +648,8 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 	double* lm   = inlds ? smem + lay.lm     : gj;                       // [3][JS] landmark means of the map estimate
 	double* dw   = inlds ? smem + lay.p1_dw  : gj + 3 * (size_t) JS;     // [JS] derived (w - 1) entries, FIFO
 	double* zh   = inlds ? smem + lay.p3_zh  : gj + 4 * (size_t) JS;     // [3][JS] h(m_j)
-	double* pdj  = inlds ? smem + lay.p3_pdj : gj + 7 * (size_t) JS;     // [JS] detection probability of landmark j
+	double* lpd  = inlds ? smem + lay.p3_pdj : gj + 7 * (size_t) JS;     // [JS] log PD of landmark j
+	double* lmd  = inlds ? smem + lay.p3_lmd : gj + 19 * (size_t) JS;    // [JS] log(1 - PD)
 	double* res  = inlds ? smem + lay.p3_res : gj + 8 * (size_t) JS;     // [JS] per-cluster log-sum-exp, in cluster order
 	unsigned long long* adj = (unsigned long long*) (inlds ? smem + lay.p3_adj : gj + 9 * (size_t) JS);   // [JS][MW]
 	int* gi      = (int*) (gj + 17 * (size_t) JS);
@@ -523,7 +657,10 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 	int* dsrc    = inlds ? sortsrc + lay.ns : gi + JS;                   // [JS]
 	int* labl    = inlds ? (int*) (smem + lay.p3_int) : gi + 2 * JS;     // [JS]
 	int* roots   = inlds ? labl + JL : gi + 3 * JS;                      // [JS]
-	int* labz    = (int*) (smem + lay.p3_int) + 2 * JL;                  // [MP]
+	int* cnt     = inlds ? labl + 2 * JL : (int*) (gj + 22 * (size_t) JS);   // [JS] members of the cluster rooted at j: landmarks | measurements << 16
+	unsigned long long* memL = (unsigned long long*) (inlds ? smem + lay.p3_mem : gj + 20 * (size_t) JS);        // [JS] its first 5 landmarks, 12-bit fields
+	unsigned long long* memZ = (unsigned long long*) (inlds ? smem + lay.p3_mem + JL : gj + 21 * (size_t) JS);   // [JS] its first 5 measurements
+	int* labz    = (int*) (smem + lay.p3_int) + 3 * JL;                  // [MP]
 	double* xreg = smem + lay.p3_x;                                      // mats [25][64]  |  Murty scratch
 	// When the largest weight minus one does not exceed the J-th largest weight no appended entry can be
 	// picked among the first J: the estimate is simply the J heaviest components, in order.
@@ -563,6 +700,7 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 	__threadfence_block();
 	__syncthreads();
 
+	PHD_STAMP(3);
 	// ---- phase 3: SetLogLikelihood (PHDNavigator.cs:462-515) on the matrix of SetLogLikeMatrix (:415-453)
 	{
 		double* mats = xreg;   // [25][64] one 5x5 matrix per lane (dead before the Murty path reuses the region)
@@ -573,10 +711,15 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 			double m[3] = {lm[j], lm[JS + j], lm[2 * JS + j]}, z[3], l[3];
 			measure_perfect(prm, pose, m, z, l);
 			zh[j] = z[0]; zh[JS + j] = z[1]; zh[2 * JS + j] = z[2];
-			pdj[j] = detection_probability_m(prm, z);
+			const double pdv = detection_probability_m(prm, z);
+			lpd[j] = log(pdv);
+			lmd[j] = log(1 - pdv);
 #pragma unroll
 			for (int b = 0; b < MW; b++) adj[(size_t) j * MW + b] = 0;
 			labl[j] = j;
+			cnt[j]  = 0;
+			memL[j] = 0;
+			memZ[j] = 0;
 		}
 		for (int k = tid; k < M; k += 256) labz[k] = J + k;
 		for (int t = tid; t < MP * JW; t += 256) adjT[t] = 0;
@@ -586,8 +729,8 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 		// detection block: defined iff Mahalanobis(z_k; h(m_j), R) < 5 (:433-442), every pair in parallel
 		for (int e = tid; e < J * M; e += 256) {
 			const int j = e / M, k = e - j * M;
-			double dist = sqrt(quad_gen(prm.Rinv, zh[j] - zs[k * 3], zh[JS + j] - zs[k * 3 + 1], zh[2 * JS + j] - zs[k * 3 + 2]));
-			if (dist < 5) {   // :436
+			const double q = quad_gen(prm.Rinv, zh[j] - zs[k * 3], zh[JS + j] - zs[k * 3 + 1], zh[2 * JS + j] - zs[k * 3 + 2]);
+			if (q < prm.g2_assoc) {   // sqrt(q) < 5, :436
 				atomicOr(&adj[(size_t) j * MW + (k >> 6)], 1ull << (k & 63));
 				if (inlds) atomicOr(&adjT[(size_t) k * JW + (j >> 6)], 1ull << (j & 63));
 			}
@@ -595,6 +738,7 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 		__threadfence_block();
 		__syncthreads();
 
+		PHD_STAMP(4);
 		// connected components of the bipartite (landmark, measurement) graph by min-label propagation;
 		// a cluster's label ends as its smallest landmark index, which is also its position in the
 		// reference's component list (rows with detection entries are inserted first, ascending).
@@ -641,6 +785,19 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 			if (!s_changed) break;
 			__syncthreads();
 		}
+		// members of every cluster, appended in arrival order (sorted by the reader)
+		for (int j = tid; j < J; j += 256) {
+			const int r = labl[j];
+			const int slot = atomicAdd(&cnt[r], 1) & 0xffff;
+			if (slot < 5) atomicOr(&memL[r], (unsigned long long) j << (12 * slot));
+		}
+		for (int k = tid; k < M; k += 256) {
+			const int r = labz[k];
+			if (r < J) {
+				const int slot = atomicAdd(&cnt[r], 0x10000) >> 16;
+				if (slot < 5) atomicOr(&memZ[r], (unsigned long long) k << (12 * slot));
+			}
+		}
 		if (wv == 0) {   // clusters that hold a detection entry, in ascending order of their first landmark
 			int nr = 0;
 			for (int j0 = 0; j0 < J; j0 += 64) {
@@ -662,13 +819,96 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 		const int nroots = s_nroots;
 		const double logmult = prm.logRmult;
 
-		// clusters with n <= 5 rows: every pairing (PHDNavigator.cs:492-494), one lane per cluster
-		if (wv == 0) {
+		PHD_STAMP(5);
+		// clusters with n <= 5 rows: every pairing (PHDNavigator.cs:492-494)
+		if (J >= 5) {
+			// `modelsize` = J >= n, so LexicographicalPairing walks all n! pairings once and their log-sum-exp is
+			// the log of the permanent of exp(matrix). One thread per cluster; the 5 x 5 matrix sits in registers
+			// with every index static: landmark x -> row x and misdetection column x, measurement y -> clutter
+			// row 4 - y and column 4 - y (n = nl + nz <= 5 keeps the two ranges apart; a free row keeps a 1 on the
+			// diagonal). Landmark rows are scaled by their largest entry.
+			for (int ri = tid; ri < nroots; ri += 256) {
+				const int root = roots[ri];
+				const int cn = cnt[root];
+				const int nl = cn & 0xffff, nz = cn >> 16;
+				if (nl + nz > 5) {
+					res[ri] = NAN;   // solved below by the Murty path
+					s_big = 1;
+					continue;
+				}
+				const unsigned long long Lp = pk_sort5(memL[root], nl), Zp = pk_sort5(memZ[root], nz);   // members, ascending
+				double E[25];
+#pragma unroll
+				for (int e = 0; e < 25; e++) E[e] = (e % 6 == 0) ? 1.0 : 0.0;
+				double rsum = 0;
+				bool dead = false;
+#pragma unroll
+				for (int x = 0; x < 4; x++) {
+					if (x < nl) {
+						const int j = (int) ((Lp >> (12 * x)) & 4095);
+						const double md = lmd[j], lp = lpd[j];   // :445, :439
+						const double h0 = zh[j], h1 = zh[JS + j], h2 = zh[2 * JS + j];
+						double D[4], rx = md;
+#pragma unroll
+						for (int y = 0; y < 4 - x; y++) {
+							D[y] = -INFINITY;
+							if (y < nz) {
+								const int k = (int) ((Zp >> (12 * y)) & 4095);
+								if ((adj[(size_t) j * MW + (k >> 6)] >> (k & 63)) & 1ull) {
+									double dist = sqrt(quad_gen(prm.Rinv, h0 - zs[k * 3], h1 - zs[k * 3 + 1], h2 - zs[k * 3 + 2]));
+									D[y] = lp + logmult - 0.5 * dist * dist;
+									rx = fmax(rx, D[y]);
+								}
+							}
+						}
+						if (rx == -INFINITY) dead = true;   // a row with no finite entry: every pairing is -inf
+						else {
+							rsum += rx;
+							E[x * 6] = exp_neg(md - rx, etab);
+#pragma unroll
+							for (int y = 0; y < 4 - x; y++) {
+								if (y < nz) E[x * 5 + 4 - y] = (D[y] == -INFINITY) ? 0.0 : exp_neg(D[y] - rx, etab);
+							}
+						}
+					}
+				}
+#pragma unroll
+				for (int y = 0; y < 4; y++) {
+					if (y < nz) {
+						E[(4 - y) * 6] = prm.kappa;   // :449
+#pragma unroll
+						for (int x = 0; x < 4 - y; x++) {
+							if (x < nl) E[(4 - y) * 5 + x] = 1.0;   // zero quadrant, :480-488
+						}
+					}
+				}
+				// permanent by rows over the sets of used columns
+				double f[32];
+#pragma unroll
+				for (int m = 0; m < 32; m++) f[m] = 0;
+				f[0] = 1;
+#pragma unroll
+				for (int i = 0; i < 5; i++) {
+#pragma unroll
+					for (int m = 0; m < 32; m++) {
+						if (__builtin_popcount(m) == i) {
+#pragma unroll
+							for (int c = 0; c < 5; c++) {
+								if (!((m >> c) & 1)) f[m | (1 << c)] = fma(f[m], E[i * 5 + c], f[m | (1 << c)]);
+							}
+						}
+					}
+				}
+				res[ri] = dead ? -INFINITY : rsum + log(f[31]);
+			}
+		}
+		else if (wv == 0) {
+			// a map estimate of fewer than 5 landmarks: `modelsize` may cut the enumeration short
+			// (GraphCombinatorics.cs:293-299), so these few clusters are enumerated literally, one lane each
 			for (int r0 = 0; r0 < nroots; r0 += 64) {
 				int ri = r0 + lane;
 				if (ri < nroots) {
 					int root = roots[ri];
-					// members, ascending: up to 5 landmarks / measurements as 12-bit fields of a register
 					unsigned long long Lp = 0, Zp = 0;
 					int nl = 0, nz = 0, nrow = 0;
 					for (int j = root; j < J; j++) {
@@ -692,10 +932,10 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 								if ((adj[(size_t) j * MW + (k >> 6)] >> (k & 63)) & 1ull) {
 									double dist = sqrt(quad_gen(prm.Rinv, zh[j] - zs[k * 3], zh[JS + j] - zs[k * 3 + 1],
 									                            zh[2 * JS + j] - zs[k * 3 + 2]));
-									mat[(x * 5 + y) * 64] = log(pdj[j]) + logmult - 0.5 * dist * dist;   // :439
+									mat[(x * 5 + y) * 64] = lpd[j] + logmult - 0.5 * dist * dist;   // :439
 								}
 							}
-							mat[(x * 5 + nz + x) * 64] = log(1 - pdj[j]);   // :445
+							mat[(x * 5 + nz + x) * 64] = lmd[j];   // :445
 						}
 						for (int y = 0; y < nz; y++) {
 							mat[((nl + y) * 5 + y) * 64] = prm.logkappa;   // :449
@@ -768,10 +1008,10 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 								if ((adj[(size_t) j * MW + (k >> 6)] >> (k & 63)) & 1ull) {
 									double dist = sqrt(quad_gen(prm.Rinv, zh[j] - zs[k * 3], zh[JS + j] - zs[k * 3 + 1],
 									                            zh[2 * JS + j] - zs[k * 3 + 2]));
-									v = log(pdj[j]) + logmult - 0.5 * dist * dist;
+									v = lpd[j] + logmult - 0.5 * dist * dist;
 								}
 							}
-							else if (y - nz == x) v = log(1 - pdj[j]);
+							else if (y - nz == x) v = lmd[j];
 						}
 						else {
 							if (y < nz) { if (y == x - nl) v = prm.logkappa; }
@@ -803,6 +1043,7 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 			}
 			__syncthreads();
 		}
+		PHD_STAMP(6);
 		// total over the components: clusters holding detections, the lone landmarks (misdetection only,
 		// log(1 - PD_j)) and the lone measurements (clutter, log kappa). The reference adds them in that order one
 		// by one; here every thread adds its share and the shares are summed in a fixed tree.
@@ -813,7 +1054,7 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 				bool has = false;
 #pragma unroll
 				for (int b = 0; b < MW; b++) has |= adj[(size_t) j * MW + b] != 0;
-				if (!has) tpart += log(1 - pdj[j]);
+				if (!has) tpart += lmd[j];
 			}
 			for (int k = tid; k < M; k += 256) {
 				if (labz[k] == J + k) tpart += prm.logkappa;
@@ -824,6 +1065,8 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 		}
 		__syncthreads();
 	}
+	PHD_STAMP(7);
+	PHD_STAMP_FLUSH(3, 8);
 	if (tid == 0) {
 		a.setll[p]   = s_total;
 		a.aJ[p]      = J;

@@ -12,11 +12,11 @@
 #ifdef PHD_STAMPS
 #define PHD_STAMP_DECL long long stamp_[12]; for (int s_ = 0; s_ < 12; s_++) stamp_[s_] = 0
 #define PHD_STAMP(i) stamp_[i] = clock64()
-#define PHD_STAMP_FLUSH(n) if (threadIdx.x == 0 && a.stamps) { for (int s_ = 0; s_ + 1 < (n); s_++) a.stamps[(size_t) blockIdx.x * 16 + s_] = (double) (stamp_[s_ + 1] - stamp_[s_]); }
+#define PHD_STAMP_FLUSH(id, n) if (threadIdx.x == 0 && a.stamps && a.stamp_kernel == (id)) { for (int s_ = 0; s_ < (n); s_++) a.stamps[(size_t) blockIdx.x * 16 + s_] = (double) (stamp_[s_] - stamp_[0]); }
 #else
 #define PHD_STAMP_DECL
 #define PHD_STAMP(i)
-#define PHD_STAMP_FLUSH(n)
+#define PHD_STAMP_FLUSH(id, n)
 #endif
 
 // Parameters as the kernels consume them (built once on the host from phd_params).
@@ -38,6 +38,7 @@ struct DevParams {
 	double g2_explore;      // SQUARED distance; same for Map.Evaluate(x, 3 * DensityDistanceThreshold) (:958). Squared-
 	                        // Euclidean metric: the radius itself; Euclidean: radius^2; gate disabled: +inf
 	double merge_thr2;      // MergeThreshold^2                 (Gaussian.cs:245)
+	double g2_assoc;        // smallest q with sqrt(q) >= 5: `Mahalanobis < 5` (PHDNavigator.cs:436) is q < g2_assoc exactly
 	double min_eff;
 	double emit_log_floor;  // log(minw * kappa): no emitted weight can come from below it
 	int    gate_metric;

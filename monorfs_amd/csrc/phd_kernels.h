@@ -78,6 +78,7 @@ struct StepBufs {
 	int*    aJ;          // [P] landmarks
 	double* account;     // [P] expected size of the corrected map
 	double* stamps;      // [P][16] phase stamps of the diagnostic build (NULL otherwise)
+	int     stamp_kernel; // which kernel writes them (env PHD_STAMP_KERNEL): 2 prune, 3 assoc, 4 density, 1 correct
 };
 
 __device__ __forceinline__ MixView bank_view(const StepBufs& a, int role)

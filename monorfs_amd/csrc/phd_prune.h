@@ -214,6 +214,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 #pragma unroll
 			for (int q = 0; q < 7; q++) bred[wv * 7 + q] = red7[q];
 		}
+		PHD_STAMP(6);
 		for (int t = tid; t <= PRUNE_NB; t += 256) cstart[t] = 0;
 		for (int t = tid; t < PRUNE_NB; t += 256) cfill[t] = 0;
 		__syncthreads();
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 			cperm[pos] = r;
 		}
 		__syncthreads();
+		PHD_STAMP(7);
 
 		for (int i = tid; i < cut; i += 256) {
 			const double* rec = a.emit_rec + (eb + order[i]) * 9;
@@ -265,6 +267,9 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 			inv_sym3(P, Pi, det);
 			const double m0 = sm[i], m1 = sm[cc + i], m2 = sm[2 * cc + i], bound = rad2[i];
 			int cnt = 0;
+#ifdef PHD_STAMPS
+			int dbg_walk = 0, dbg_test = 0;
+#endif
 			unsigned int e[PRUNE_NBR];   // close rows found (statically indexed only)
 #pragma unroll
 			for (int q = 0; q < PRUNE_NBR; q++) e[q] = 0xffffu;
@@ -294,6 +299,10 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 							const int b = bucket(cx, cy, cz);
 							for (int q = cstart[b]; q < cstart[b + 1]; q++) {
 								int k = cperm[q];
+#ifdef PHD_STAMPS
+								dbg_walk++;
+								if (k > i && cellid[k] == want) dbg_test++;
+#endif
 								if (k > i && cellid[k] == want) test(k);
 							}
 						}
@@ -313,6 +322,14 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 			}
 			nbr[2 * i]     = lo;
 			nbr[2 * i + 1] = hi;
+#ifdef PHD_STAMPS
+			if (a.stamps && a.stamp_kernel == 2) {
+				atomicAdd(&a.stamps[(size_t) blockIdx.x * 16 + 12], (double) dbg_walk);
+				atomicAdd(&a.stamps[(size_t) blockIdx.x * 16 + 13], (double) dbg_test);
+				atomicAdd(&a.stamps[(size_t) blockIdx.x * 16 + 14], (double) cnt);
+				if (!(bound <= rcap * rcap)) atomicAdd(&a.stamps[(size_t) blockIdx.x * 16 + 15], 1.0);
+			}
+#endif
 		}
 	}
 	__syncthreads();
@@ -439,5 +456,5 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	}
 	PHD_STAMP(5);
 	if (tid == 0) vout.count[p] = nsurv_before;
-	PHD_STAMP_FLUSH(6);
+	PHD_STAMP_FLUSH(2, 8);
 }

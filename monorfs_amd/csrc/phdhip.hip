@@ -140,6 +140,8 @@ DevParams make_dev_params(const phd_params& p)
 	d.g2_correct = (p.gate_metric == PHD_GATE_DISABLED) ? INFINITY : (p.gate_metric == PHD_GATE_SQUARED_EUCLIDEAN ? rc : rc * rc);
 	d.g2_explore = (p.gate_metric == PHD_GATE_DISABLED) ? INFINITY : (p.gate_metric == PHD_GATE_SQUARED_EUCLIDEAN ? re : re * re);
 	d.merge_thr2 = p.merge_threshold * p.merge_threshold;
+	d.g2_assoc = 25.0;
+	while (std::sqrt(std::nextafter(d.g2_assoc, 0.0)) >= 5.0) d.g2_assoc = std::nextafter(d.g2_assoc, 0.0);
 	d.min_eff    = p.min_effective_particle;
 	double floor = p.min_weight * p.clutter_density;
 	d.emit_log_floor = (floor > 0) ? std::log(floor) : -INFINITY;
@@ -162,7 +164,7 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.cm = nav->d_cm; b.cmcap = nav->cmcap; b.cmplane = (size_t) nav->Pcap * nav->cmcap;
 	b.pair_ck = nav->d_pair_ck; b.pair_w = nav->d_pair_w; b.pair_count = nav->d_pair_count;
 	b.cand = nav->d_cand; b.candcap = nav->candcap;
-	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account; b.stamps = nav->d_stamps;
+	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account; b.stamps = nav->d_stamps; b.stamp_kernel = getenv("PHD_STAMP_KERNEL") ? atoi(getenv("PHD_STAMP_KERNEL")) : 2;
 	return b;
 }
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase shader-clock shares of a stamped kernel (build with -DPHD_STAMPS into
 monorfs_amd/csrc/libphdhip_stamps.so; never the product build). Usage on the GPU box:
-    python scripts/stamps.py [steady|survey]"""
+    python scripts/stamps.py [steady|survey] [kernel id: 2 = k_prune_merge, 3 = k_alpha_assoc]"""
 import ctypes as C
 import os
 import subprocess
@@ -22,6 +22,8 @@ from monorfs_amd.abi import prm3d_defaults
 from monorfs_amd.synth import Frame
 
 prof = sys.argv[1] if len(sys.argv) > 1 else "steady"
+if len(sys.argv) > 2:
+    os.environ["PHD_STAMP_KERNEL"] = sys.argv[2]   # 2 prune (default), 3 assoc
 f = Frame(2048, 512, 64, 1002, weight_profile=prof)
 p = prm3d_defaults(2048, 600, 64)
 nav = navigator.PHDNavigator(p, particlecount=2048)
@@ -34,6 +36,8 @@ nav.sync()
 out = np.zeros((2048, 16))
 nav._lib.phd_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
 nav._lib.phd_debug_stamps(nav._h, out.ctypes.data_as(C.POINTER(C.c_double)))
-m = out.mean(0)
-print(prof, "mean cycles per phase:", np.round(m[:8]).astype(int), "sum", int(m[:8].sum()))
+m = out.mean(0)   # stamp i = cycles since stamp 0 (stamps need not be numbered in time order)
+idx = [i for i in np.argsort(m[:12], kind="stable") if i == 0 or m[i] > 0]
+print("counters 12..15 (sum over steps run):", m[12:16])
+print(prof, "cycles between stamps:", " ".join("%d->%d:%d" % (a, b, m[b] - m[a]) for a, b in zip(idx[:-1], idx[1:])), "total", int(m[:12].max()))
 nav.close()
