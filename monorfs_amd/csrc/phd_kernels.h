@@ -73,6 +73,7 @@ struct StepBufs {
 	int*    pair_count;  // [P]
 	int*    cand;        // [P][candcap] candidate pairs of k_correct's first sweep
 	int     candcap;
+	double* srec;        // [P][10][cutcap] k_prune_merge: the kept records in sorted order (mean, covariance, weight)
 	// map estimate handed from k_alpha_assoc to k_alpha_density
 	double* alm;         // [P][3][Jcap] landmark means
 	int*    aJ;          // [P] landmarks

@@ -6,14 +6,18 @@
 // the set by its moment match (Gaussian.Merge, Gaussian.cs:297-347).
 //
 // Only the question "is i still present" is sequential. The kernel therefore splits the work:
-//   A. sort     : bitonic sort in LDS on the weight's bit pattern (12-byte entries: key + emit slot), the
-//                 best half kept while further chunks stream in; runs of equal weights are then put in
+//   A. sort     : bitonic sort on the weight's bit pattern (one 64-bit word per entry: key + emit slot), held in
+//                 registers (thread exchanges, lane shuffles, LDS only for the longest distances), the best
+//                 half kept while further chunks stream in; runs of equal weights are then put in
 //                 canonical-index order, which makes the order the reference's sort made stable
-//   B. pairs    : every closeness test close_i(k), k > i, in parallel — two rows per thread, the other
-//                 means broadcast from LDS. A float32 Euclidean bound
+//   S. stage    : the kept records are gathered once, in sorted order, into a plane-per-field slab in HBM
+//                 (every later read is coalesced); means and Euclidean bounds go to LDS
+//   B. pairs    : every closeness test close_i(k), k > i, in parallel, one row per thread. A Euclidean bound
 //                 |d|^2 > T^2 trace(P_i)  =>  d^T P_i^-1 d >= |d|^2 / lambda_max(P_i) > T^2
-//                 (radius inflated for the float32 rounding) rejects far pairs; the survivors take the
-//                 exact FP64 test. Each row keeps its first 7 close rows.
+//                 limits the candidates of a row to a ball; the rows are binned in a uniform grid (hashed
+//                 cells) and the <= 8 buckets the ball meets are walked as one list of float32 records, the
+//                 survivors of the float32 distance test take the exact FP64 test. Each row keeps its first 7
+//                 close rows.
 //   C. resolve  : one wave walks the rows in weight order, 64 row records at a time held in its lanes and
 //                 the "absorbed" bits spread over its lanes (integer work only); rows with more than 7
 //                 close rows are re-tested by the 64 lanes.
@@ -24,11 +28,11 @@
 #include "phd_device.h"
 
 #define PRUNE_NBR 7
-#define PRUNE_NB 1024   // buckets of the spatial hash
+#define PRUNE_NB 2048   // buckets of the spatial hash
 
 struct PruneLds {
-	int sw, sm, order, x, scan;   // offsets in doubles
-	int NS;                       // sort width (power of two >= 2 * cutcap)
+	int rad2, sm, x, scan;   // offsets in doubles
+	int NS;                  // sort width (power of two >= 2 * cutcap)
 	int bytes;
 };
 
@@ -39,15 +43,13 @@ __host__ __device__ inline PruneLds prune_lds(int cutcap)
 	int NS = 512;
 	while (NS < 2 * cutcap) NS <<= 1;
 	l.NS    = NS;
-	l.sw    = 0;
-	l.sm    = l.sw + cc;
-	l.order = l.sm + 3 * cc;                 // int[cc]
-	l.x     = l.order + cc / 2;              // sort keys u64[NS] + slots int[NS]  |  nbr, rad2, owner, cell lists (see `rest`)
-	int sortd = NS;
-	// nbr u64[2*cc], rad2 double[cc], owner/cellid/cperm int[cc] each, cstart int[NB+2], cfill int[NB], bred double[28], absb int[64]
-	int rest  = 2 * cc + cc + (3 * cc) / 2 + (PRUNE_NB + 2) / 2 + PRUNE_NB / 2 + 28 + 32 + 4;
-	l.scan  = l.x + (sortd > rest ? sortd : rest);
-	l.bytes = (l.scan + 136) * 8;            // int[264] + spare
+	l.rad2  = 0;
+	l.sm    = l.rad2 + cc;
+	l.x     = l.sm + 3 * cc;                 // sort words u64[NS]  |  the lists of the pair search (see `rest`)
+	// nbr u64[2*cc], cand float4[cc], owner int[cc], cellid int[cc], cstart int[NB+2], absb int[64]
+	int rest  = 2 * cc + 2 * cc + cc + (PRUNE_NB + 2) / 2 + 32 + 4;
+	l.scan  = l.x + (NS > rest ? NS : rest);
+	l.bytes = (l.scan + 136) * 8;            // int[264] | double[28], + spare
 	return l;
 }
 
@@ -100,25 +102,88 @@ __device__ __forceinline__ void prune_bitonic(unsigned long long* v, int n, int 
 	}
 }
 
+// In-register bitonic sort of n = 256 * EPT words, largest first: thread t holds the EPT consecutive words
+// sv[t * EPT ..). Distances below EPT are exchanges inside a thread, distances below 64 * EPT are lane
+// shuffles inside a wave; only the few larger ones go through LDS.
+template <int EPT>
+__device__ __forceinline__ void prune_sort_regs(unsigned long long* sv, int tid)
+{
+	constexpr int n = 256 * EPT;
+	unsigned long long v[EPT];
+#pragma unroll
+	for (int i = 0; i < EPT; i++) v[i] = sv[tid * EPT + i];
+	for (int k = 2; k <= n; k <<= 1) {
+		int j = k >> 1;
+		if (j >= 64 * EPT) {
+#pragma unroll
+			for (int i = 0; i < EPT; i++) sv[tid * EPT + i] = v[i];
+			__syncthreads();
+			for (; j >= 64 * EPT; j >>= 1) {
+				for (int t = tid; t < (n >> 1); t += 256) prune_ce(sv, t, j, k);
+				__syncthreads();
+			}
+#pragma unroll
+			for (int i = 0; i < EPT; i++) v[i] = sv[tid * EPT + i];
+		}
+		for (; j >= EPT; j >>= 1) {
+			const int lx = j / EPT;
+			const bool lower = (tid & lx) == 0;
+#pragma unroll
+			for (int i = 0; i < EPT; i++) {
+				const bool desc = ((tid * EPT + i) & k) == 0;
+				const unsigned long long o = __shfl_xor(v[i], lx, 64);
+				const unsigned long long hi = v[i] > o ? v[i] : o, lo = v[i] > o ? o : v[i];
+				v[i] = (lower == desc) ? hi : lo;
+			}
+		}
+#pragma unroll
+		for (int jj = EPT / 2; jj > 0; jj >>= 1) {
+			if (jj <= (k >> 1)) {
+#pragma unroll
+				for (int i = 0; i < EPT; i++) {
+					if ((i & jj) == 0) {
+						const bool desc = ((tid * EPT + i) & k) == 0;
+						const unsigned long long x = v[i], y = v[i | jj];
+						const unsigned long long hi = x > y ? x : y, lo = x > y ? y : x;
+						v[i]      = desc ? hi : lo;
+						v[i | jj] = desc ? lo : hi;
+					}
+				}
+			}
+		}
+	}
+#pragma unroll
+	for (int i = 0; i < EPT; i++) sv[tid * EPT + i] = v[i];
+	__syncthreads();
+}
+
+__device__ __forceinline__ void prune_sort(unsigned long long* sv, int n, int tid)
+{
+	switch (n) {
+	case 512:  prune_sort_regs<2>(sv, tid); break;
+	case 1024: prune_sort_regs<4>(sv, tid); break;
+	case 2048: prune_sort_regs<8>(sv, tid); break;
+	case 4096: prune_sort_regs<16>(sv, tid); break;
+	default:   prune_bitonic(sv, n, tid);
+	}
+}
+
 __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const StepBufs a, int cutcap)
 {
 	extern __shared__ __align__(16) double smem[];
 	const PruneLds lay = prune_lds(cutcap);
 	const int cc = (cutcap + 1) & ~1, NS = lay.NS;
-	double* sw    = smem + lay.sw;                         // [cut] sorted weights
+	double* rad2  = smem + lay.rad2;                       // [cut] squared Euclidean bound of row i (inf: none)
 	double* sm    = smem + lay.sm;                         // [3][cc] sorted means
-	int*    order = (int*) (smem + lay.order);             // [cut] emit slot of rank r
 	unsigned long long* sv = (unsigned long long*) (smem + lay.x);     // [NS] sort words
 	unsigned long long* nbr = (unsigned long long*) (smem + lay.x);    // [cut][2]: count + up to 7 close later rows
-	double* rad2  = (double*) (nbr + 2 * cc);              // [cut] squared Euclidean bound of row i (inf: none)
-	double* bred  = rad2 + cc;                             // [28] block reduction scratch
-	int*    owner = (int*) (bred + 28);                    // [cut] row that absorbed k (-1: none)
+	float4* cand  = (float4*) (nbr + 2 * cc);              // [cut] rows grouped by bucket: mean relative to the box (float32), row
+	int*    owner = (int*) (cand + cc);                    // [cut] row that absorbed k (-1: none)
 	int*    cellid = owner + cc;                           // [cut] packed grid cell of row r
-	int*    cperm = cellid + cc;                           // [cut] rows grouped by bucket
-	int*    cstart = cperm + cc;                           // [NB + 2] bucket starts
-	int*    cfill = cstart + PRUNE_NB + 2;                 // [NB]
-	int*    absb  = cfill + PRUNE_NB;                      // [64] absorbed bits as left by the resolving wave
+	int*    cstart = cellid + cc;                          // [NB + 2] bucket b is [cstart[b], cstart[b + 1])
+	int*    absb  = cstart + PRUNE_NB + 2;                 // [64] absorbed bits as left by the resolving wave
 	int*    scan  = (int*) (smem + lay.scan);              // [264]
+	double* bred  = smem + lay.scan;                       // [28] block reduction scratch (before `scan` is used)
 
 	const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	PHD_STAMP_DECL;
@@ -126,6 +191,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	const int ne = a.emit_count[p];
 	const size_t eb = (size_t) p * a.ecap;
 	const int cut = min(min(prm.maxq, ne), cutcap);   // weightcut: every emitted weight is already >= MinWeight
+	double* srec = a.srec + (size_t) p * 10 * cutcap;  // [10][cutcap] the kept records in sorted order: mean, covariance, weight
 
 	PHD_STAMP(0);
 	// ---- A. order by (weight desc, canonical index asc)
@@ -144,7 +210,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 			taken += n - from;
 			first = false;
 			__syncthreads();
-			prune_bitonic(sv, n, tid);
+			prune_sort(sv, n, tid);
 			// runs that agree in the key bits: order by (weight desc, canonical index asc); the thread at the
 			// head of a run sorts it (runs are disjoint)
 			for (int r = tid; r + 1 < n; r += 256) {
@@ -170,40 +236,33 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 			}
 			__syncthreads();
 		}
-		for (int r = tid; r < cut; r += 256) {
-			int slt = prune_slot(sv[r]);
-			order[r] = slt;
-			sw[r]    = a.emit_w[eb + slt];
-		}
 	}
-	__syncthreads();
 	PHD_STAMP(1);
+	// ---- the kept records, gathered once into sorted order (HBM, plane per field); means and bounds to LDS.
+	// A pair can only be close when |m_i - m_k|^2 <= T^2 trace(P_i) (d^T P_i^-1 d >= |d|^2 / lambda_max(P_i) >=
+	// |d|^2 / trace(P_i) for a positive definite P_i).
+	double lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY, rmx = 0;
 	for (int r = tid; r < cut; r += 256) {
-		const double* rec = a.emit_rec + (eb + order[r]) * 9;
-		sm[r] = rec[0]; sm[cc + r] = rec[1]; sm[2 * cc + r] = rec[2];
+		const int slt = prune_slot(sv[r]);
+		const double* rec = a.emit_rec + (eb + slt) * 9;
+		double v[9];
+#pragma unroll
+		for (int t = 0; t < 9; t++) v[t] = rec[t];
+		const double w = a.emit_w[eb + slt];
+#pragma unroll
+		for (int t = 0; t < 9; t++) srec[(size_t) t * cutcap + r] = v[t];
+		srec[(size_t) 9 * cutcap + r] = w;
+		sm[r] = v[0]; sm[cc + r] = v[1]; sm[2 * cc + r] = v[2];
+		const double P0 = v[3], P1 = v[4], P2 = v[5], P3 = v[6], P4 = v[7], P5 = v[8];
+		double det = P0 * (P3 * P5 - P4 * P4) - P1 * (P1 * P5 - P4 * P2) + P2 * (P1 * P4 - P3 * P2);
+		bool pd = P0 > 0 && (P0 * P3 - P1 * P1) > 0 && det > 0;   // Sylvester
+		double rad = pd ? sqrt(prm.merge_thr2 * (P0 + P3 + P5)) : INFINITY;
+		rad2[r] = rad * rad * (1.0 + 1e-6);
+		if (pd) rmx = fmax(rmx, rad);
+		lo0 = fmin(lo0, v[0]); lo1 = fmin(lo1, v[1]); lo2 = fmin(lo2, v[2]);
+		hi0 = fmax(hi0, v[0]); hi1 = fmax(hi1, v[1]); hi2 = fmax(hi2, v[2]);
 	}
-	__syncthreads();   // the sort buffers are dead from here on: nbr / owner / the cell lists take their place
-	PHD_STAMP(2);
-
-	// ---- B. all closeness tests close_i(k), k > i. A pair can only be close when |m_i - m_k|^2 <= T^2 trace(P_i)
-	// (d^T P_i^-1 d >= |d|^2 / lambda_max(P_i) >= |d|^2 / trace(P_i) for a positive definite P_i), so the rows
-	// are binned in a uniform grid of cell size 2 * (largest such radius): the ball of a row then meets at most
-	// 2 x 2 x 2 cells, whose members are the only candidates. Rows whose P_i is not positive definite, or whose
-	// radius exceeds the cell bound, test every later row.
 	{
-		double lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY, rmx = 0;
-		for (int r = tid; r < cut; r += 256) {
-			const double* rec = a.emit_rec + (eb + order[r]) * 9;
-			double P0 = rec[3], P1 = rec[4], P3 = rec[6], P5 = rec[8];
-			double det = P0 * (P3 * P5 - rec[7] * rec[7]) - P1 * (P1 * P5 - rec[7] * rec[5]) + rec[5] * (P1 * rec[7] - P3 * rec[5]);
-			bool pd = P0 > 0 && (P0 * P3 - P1 * P1) > 0 && det > 0;   // Sylvester
-			double rad = pd ? sqrt(prm.merge_thr2 * (P0 + P3 + P5)) : INFINITY;
-			rad2[r] = rad * rad * (1.0 + 1e-6);
-			if (pd) rmx = fmax(rmx, rad);
-			lo0 = fmin(lo0, sm[r]); lo1 = fmin(lo1, sm[cc + r]); lo2 = fmin(lo2, sm[2 * cc + r]);
-			hi0 = fmax(hi0, sm[r]); hi1 = fmax(hi1, sm[cc + r]); hi2 = fmax(hi2, sm[2 * cc + r]);
-			owner[r] = -1;
-		}
 		double red7[7] = {-lo0, -lo1, -lo2, hi0, hi1, hi2, rmx};   // all as maxima
 #pragma unroll
 		for (int q = 0; q < 7; q++) {
@@ -214,10 +273,16 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 #pragma unroll
 			for (int q = 0; q < 7; q++) bred[wv * 7 + q] = red7[q];
 		}
-		PHD_STAMP(6);
-		for (int t = tid; t <= PRUNE_NB; t += 256) cstart[t] = 0;
-		for (int t = tid; t < PRUNE_NB; t += 256) cfill[t] = 0;
-		__syncthreads();
+	}
+	__syncthreads();   // the sort words are dead from here on: nbr / cand / owner / the cell lists take their place
+	PHD_STAMP(2);
+
+	// ---- B. all closeness tests close_i(k), k > i. The rows are binned in a uniform grid of cell size
+	// 2 * (largest radius): the ball of a row then meets at most 2 x 2 x 2 cells, whose members are the only
+	// candidates. Rows whose P_i is not positive definite, or whose radius exceeds the cell bound, test every
+	// later row.
+	{
+		double red7[7];
 #pragma unroll
 		for (int q = 0; q < 7; q++) red7[q] = fmax(fmax(bred[q], bred[7 + q]), fmax(bred[14 + q], bred[21 + q]));
 		const double mn0 = -red7[0], mn1 = -red7[1], mn2 = -red7[2];
@@ -225,49 +290,59 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 		double cell = fmax(2.02 * red7[6], ext / 60.0);   // <= 61 cells per axis
 		if (!(cell > 0)) cell = 1.0;
 		const double icell = 1.0 / cell, rcap = 0.5 * cell / 1.005;
+		// float32 copies of the means relative to the box corner are off by at most 2^-24 ext per coordinate, so a
+		// float32 distance is within ferr of the true one
+		const double ferr = 4e-7 * ext;
 		auto bucket = [](int cx, int cy, int cz) {
 			return (int) (((unsigned int) cx * 73856093u ^ (unsigned int) cy * 19349663u ^ (unsigned int) cz * 83492791u) & (PRUNE_NB - 1));
 		};
+		for (int t = tid; t <= PRUNE_NB; t += 256) cstart[t] = 0;
+		__syncthreads();
 		// counting sort of the rows by bucket
 		for (int r = tid; r < cut; r += 256) {
 			int cx = (int) ((sm[r] - mn0) * icell), cy = (int) ((sm[cc + r] - mn1) * icell), cz = (int) ((sm[2 * cc + r] - mn2) * icell);
 			cellid[r] = (cx << 16) | (cy << 8) | cz;
-			atomicAdd(&cstart[bucket(cx, cy, cz) + 1], 1);
+			atomicAdd(&cstart[bucket(cx, cy, cz)], 1);
+			owner[r] = -1;
 		}
 		__syncthreads();
-		if (wv == 0) {   // exclusive prefix over the PRUNE_NB bucket counts (cstart[b + 1] holds the count of bucket b)
-			int run = 0;
-			for (int b0 = 0; b0 < PRUNE_NB; b0 += 64) {
-				int v = cstart[b0 + 1 + lane], incl = v;
+		{   // inclusive prefix over the PRUNE_NB bucket counts: cstart[b] = end of bucket b; the fill below counts it down to its start
+			constexpr int BT = PRUNE_NB / 256;
+			int c[BT], tot = 0;
 #pragma unroll
-				for (int o = 1; o < 64; o <<= 1) {
-					int y = __shfl_up(incl, o, 64);
-					if (lane >= o) incl += y;
-				}
-				cstart[b0 + 1 + lane] = run + incl;
-				run += __shfl(incl, 63, 64);
+			for (int u = 0; u < BT; u++) { c[u] = cstart[BT * tid + u]; tot += c[u]; }
+			int incl = tot;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				int y = __shfl_up(incl, o, 64);
+				if (lane >= o) incl += y;
 			}
+			if (lane == 63) scan[wv] = incl;
+			__syncthreads();
+			int run = incl - tot;
+			for (int q = 0; q < wv; q++) run += scan[q];
+#pragma unroll
+			for (int u = 0; u < BT; u++) { run += c[u]; cstart[BT * tid + u] = run; }
+			if (tid == 0) cstart[PRUNE_NB] = cut;
 		}
 		__syncthreads();
 		for (int r = tid; r < cut; r += 256) {
 			int id = cellid[r];
 			int b = bucket(id >> 16, (id >> 8) & 255, id & 255);
-			// fill the bucket from its end: cfill[b] counts down from the bucket's size
-			int pos = cstart[b + 1] - 1 - atomicAdd(&cfill[b], 1);
-			cperm[pos] = r;
+			int pos = atomicSub(&cstart[b], 1) - 1;
+			cand[pos] = make_float4((float) (sm[r] - mn0), (float) (sm[cc + r] - mn1), (float) (sm[2 * cc + r] - mn2), __int_as_float(r));
 		}
 		__syncthreads();
 		PHD_STAMP(7);
 
 		for (int i = tid; i < cut; i += 256) {
-			const double* rec = a.emit_rec + (eb + order[i]) * 9;
 			double P[6], Pi[6], det;
 #pragma unroll
-			for (int t = 0; t < 6; t++) P[t] = rec[3 + t];
+			for (int t = 0; t < 6; t++) P[t] = srec[(size_t) (3 + t) * cutcap + i];
 			inv_sym3(P, Pi, det);
 			const double m0 = sm[i], m1 = sm[cc + i], m2 = sm[2 * cc + i], bound = rad2[i];
 			int cnt = 0;
-#ifdef PHD_STAMPS
+#ifdef PHD_STAMP_COUNTERS
 			int dbg_walk = 0, dbg_test = 0;
 #endif
 			unsigned int e[PRUNE_NBR];   // close rows found (statically indexed only)
@@ -287,31 +362,94 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 					cnt++;
 				}
 			};
+#if defined(PHD_EXP) && PHD_EXP == 2
+			if (false) {
+#else
 			if (bound <= rcap * rcap) {
+#endif
 				const int bx = (int) floor((m0 - mn0) * icell - 0.5), by = (int) floor((m1 - mn1) * icell - 0.5),
 				          bz = (int) floor((m2 - mn2) * icell - 0.5);
-				for (int dz = 0; dz < 2; dz++) {
-					for (int dy = 0; dy < 2; dy++) {
-						for (int dx = 0; dx < 2; dx++) {
-							int cx = bx + dx, cy = by + dy, cz = bz + dz;
-							if (cx < 0 || cy < 0 || cz < 0 || cx > 255 || cy > 255 || cz > 255) continue;
-							const int want = (cx << 16) | (cy << 8) | cz;
-							const int b = bucket(cx, cy, cz);
-							for (int q = cstart[b]; q < cstart[b + 1]; q++) {
-								int k = cperm[q];
-#ifdef PHD_STAMPS
-								dbg_walk++;
-								if (k > i && cellid[k] == want) dbg_test++;
+				// the (up to) 8 buckets of the cells the ball meets, walked as one list
+				int qs[8], cum[9], bk[8];
+				cum[0] = 0;
+#pragma unroll
+				for (int c = 0; c < 8; c++) {
+					const int cx = bx + (c & 1), cy = by + ((c >> 1) & 1), cz = bz + (c >> 2);
+					bool ok = !(cx < 0 || cy < 0 || cz < 0 || cx > 255 || cy > 255 || cz > 255);
+					const int b = bucket(cx, cy, cz);
+					bk[c] = ok ? b : -1;
+#pragma unroll
+					for (int u = 0; u < c; u++) ok = ok && bk[u] != b;   // two cells in one bucket: the bucket is walked once
+					const int s0 = cstart[b], s1 = cstart[b + 1];
+					qs[c] = s0;
+					cum[c + 1] = cum[c] + (ok ? s1 - s0 : 0);
+				}
+				const float fx = (float) (m0 - mn0), fy = (float) (m1 - mn1), fz = (float) (m2 - mn2);
+				const double rr = sqrt(bound) + ferr;
+				const float thr = (float) (rr * rr * (1.0 + 1e-5));
+				// four candidates per trip: their records are fetched together
+				unsigned long long pend0 = 0, pend1 = 0;   // up to 8 queued rows as 16-bit fields
+				int npend = 0;
+				auto drain = [&]() {
+					for (; npend > 0; npend--) {
+						const int f = npend - 1;
+						test((int) (((f < 4) ? (pend0 >> (16 * f)) : (pend1 >> (16 * (f - 4)))) & 0xffff));
+					}
+					pend0 = 0; pend1 = 0;
+				};
+#if defined(PHD_EXP) && PHD_EXP == 1
+				cum[8] = 0;
 #endif
-								if (k > i && cellid[k] == want) test(k);
-							}
+#if defined(PHD_EXP) && PHD_EXP == 4
+				cum[8] = min(cum[8], 4);
+#endif
+				for (int t0 = 0; t0 < cum[8]; t0 += 4) {
+					float4 cd[4];
+#pragma unroll
+					for (int v = 0; v < 4; v++) {
+						const int t = min(t0 + v, cum[8] - 1);
+						int c = 0;
+#pragma unroll
+						for (int u = 1; u < 8; u++) c += (t >= cum[u]) ? 1 : 0;
+						int q0 = qs[0], cb = cum[0];
+#pragma unroll
+						for (int u = 1; u < 8; u++) {
+							if (c == u) { q0 = qs[u]; cb = cum[u]; }
+						}
+						cd[v] = cand[q0 + (t - cb)];
+					}
+#pragma unroll
+					for (int v = 0; v < 4; v++) {
+						const int k = __float_as_int(cd[v].w);
+						const float e0 = fx - cd[v].x, e1 = fy - cd[v].y, e2 = fz - cd[v].z;
+#if defined(PHD_EXP) && PHD_EXP == 3
+						const bool pass = t0 + v < cum[8] && k > i && e0 * e0 + e1 * e1 + e2 * e2 <= -1.0f;
+#else
+						const bool pass = t0 + v < cum[8] && k > i && e0 * e0 + e1 * e1 + e2 * e2 <= thr;
+#endif
+#ifdef PHD_STAMP_COUNTERS
+						if (t0 + v < cum[8]) dbg_walk++;
+						if (pass) dbg_test++;
+#endif
+						// the exact test is rare per lane but not per wave: queue the row and test later, so that the
+						// waves do not run the FP64 path on every trip
+						if (pass) {
+							if (npend < 4) pend0 |= (unsigned long long) k << (16 * npend);
+							else           pend1 |= (unsigned long long) k << (16 * (npend - 4));
+							npend++;
 						}
 					}
+					if (npend > 4) drain();   // room for the next trip
 				}
+				drain();
 			}
+#if defined(PHD_EXP) && PHD_EXP == 2
+			else {}
+#else
 			else {
 				for (int k = i + 1; k < cut; k++) test(k);
 			}
+#endif
 			unsigned long long lo = (unsigned long long) min(cnt, 0xffff), hi = 0;
 #pragma unroll
 			for (int q = 0; q < PRUNE_NBR; q++) {
@@ -322,7 +460,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 			}
 			nbr[2 * i]     = lo;
 			nbr[2 * i + 1] = hi;
-#ifdef PHD_STAMPS
+#ifdef PHD_STAMP_COUNTERS   // (slow: contended atomics; counts only, never together with timing)
 			if (a.stamps && a.stamp_kernel == 2) {
 				atomicAdd(&a.stamps[(size_t) blockIdx.x * 16 + 12], (double) dbg_walk);
 				atomicAdd(&a.stamps[(size_t) blockIdx.x * 16 + 13], (double) dbg_test);
@@ -371,10 +509,9 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 				}
 				else {
 					// more close rows than the list holds: re-test row i against every later row, 64 at a time
-					const double* rec = a.emit_rec + (eb + order[i]) * 9;
 					double P[6], Pi[6], det;
 #pragma unroll
-					for (int t = 0; t < 6; t++) P[t] = rec[3 + t];
+					for (int t = 0; t < 6; t++) P[t] = srec[(size_t) (3 + t) * cutcap + i];
 					inv_sym3(P, Pi, det);
 					double m0 = sm[i], m1 = sm[cc + i], m2 = sm[2 * cc + i];
 					for (int s = i >> 6; s < nslots; s++) {
@@ -408,16 +545,20 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 		__syncthreads();
 		if (surv) {
 			const int pos = base + __popcll(bal & lanemask_lt());
-			const double* rec = a.emit_rec + (eb + order[i]) * 9;
+			double rec[10];
+#pragma unroll
+			for (int t = 0; t < 10; t++) rec[t] = srec[(size_t) t * cutcap + i];
 			// Gaussian.Merge (Gaussian.cs:329-346): raw moments, the candidate first, then its set in list order
-			double w = sw[i], m0 = rec[0], m1 = rec[1], m2 = rec[2];
+			double w = rec[9], m0 = rec[0], m1 = rec[1], m2 = rec[2];
 			double W = 0.0 + w;
 			double M0 = 0.0 + w * m0, M1 = 0.0 + w * m1, M2 = 0.0 + w * m2;
 			double C0 = 0.0 + w * (rec[3] + m0 * m0), C1 = 0.0 + w * (rec[4] + m0 * m1), C2 = 0.0 + w * (rec[5] + m0 * m2);
 			double C3 = 0.0 + w * (rec[6] + m1 * m1), C4 = 0.0 + w * (rec[7] + m1 * m2), C5 = 0.0 + w * (rec[8] + m2 * m2);
 			auto absorb = [&](int k) {
-				const double* rk = a.emit_rec + (eb + order[k]) * 9;
-				double wk = sw[k], k0 = rk[0], k1 = rk[1], k2 = rk[2];
+				double rk[10];
+#pragma unroll
+				for (int t = 0; t < 10; t++) rk[t] = srec[(size_t) t * cutcap + k];
+				double wk = rk[9], k0 = rk[0], k1 = rk[1], k2 = rk[2];
 				W += wk;
 				M0 += wk * k0; M1 += wk * k1; M2 += wk * k2;
 				C0 += wk * (rk[3] + k0 * k0); C1 += wk * (rk[4] + k0 * k1); C2 += wk * (rk[5] + k0 * k2);

@@ -52,6 +52,7 @@ struct phd_navigator {
 	int* d_cand = nullptr; int candcap = 0;
 	double* d_alm = nullptr; int* d_aJ = nullptr; double* d_account = nullptr;
 	double* d_stamps = nullptr;
+	double* d_srec = nullptr;
 	double* d_gw = nullptr; int gwcap = 0;           // gathered weights of all ranks
 	double* d_stage = nullptr;                       // staging for uploads
 	// migration (multi-GPU resampling)
@@ -164,7 +165,7 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.cm = nav->d_cm; b.cmcap = nav->cmcap; b.cmplane = (size_t) nav->Pcap * nav->cmcap;
 	b.pair_ck = nav->d_pair_ck; b.pair_w = nav->d_pair_w; b.pair_count = nav->d_pair_count;
 	b.cand = nav->d_cand; b.candcap = nav->candcap;
-	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account; b.stamps = nav->d_stamps; b.stamp_kernel = getenv("PHD_STAMP_KERNEL") ? atoi(getenv("PHD_STAMP_KERNEL")) : 2;
+	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account; b.srec = nav->d_srec; b.stamps = nav->d_stamps; b.stamp_kernel = getenv("PHD_STAMP_KERNEL") ? atoi(getenv("PHD_STAMP_KERNEL")) : 2;
 	return b;
 }
 
@@ -447,6 +448,7 @@ phd_navigator* phd_create(const phd_params* params, int device)
 #ifdef PHD_STAMPS
 	ok = ok && dalloc((void**) &nav->d_stamps, (size_t) nav->Pcap * 16 * 8);
 #endif
+	ok = ok && dalloc((void**) &nav->d_srec, (size_t) nav->Pcap * 10 * nav->cutcap * 8);
 	ok = ok && dalloc((void**) &nav->d_alm, (size_t) nav->Pcap * 3 * nav->Jcap * 8);
 	ok = ok && dalloc((void**) &nav->d_aJ, (size_t) nav->Pcap * 4) && dalloc((void**) &nav->d_account, (size_t) nav->Pcap * 8);
 	ok = ok && dalloc((void**) &nav->d_jscratch, (size_t) nav->Pcap * alpha_jscratch_doubles(nav->Jcap) * 8);
@@ -475,7 +477,7 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_sel); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
-	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cm); hipFree(nav->d_pair_ck); hipFree(nav->d_pair_w); hipFree(nav->d_pair_count); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
+	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cm); hipFree(nav->d_pair_ck); hipFree(nav->d_pair_w); hipFree(nav->d_pair_count); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
 	if (nav->own_stream) hipStreamDestroy(nav->own_stream);
 	delete nav;

@@ -26,3 +26,14 @@ for name, v in (("emitted", ne), ("pruned", no), ("landmarks J", J)):
     v = np.array(v)
     print(prof, name, "min/mean/max", v.min(), v.mean(), v.max())
 nav.close()
+
+# radius of the merge ball sqrt(T^2 trace(P)) over the corrected components of particle 0, and the box they live in
+nav = navigator.PHDNavigator(p, particlecount=2048)
+nav.upload_state(f.planes(), f.counts, f.poses, f.weights)
+nav.run_stages(f.z, with_alpha=False)
+cw, cm, cc = nav.CorrectConditional(0)
+tr = np.trace(cc, axis1=1, axis2=2)
+rad = np.sqrt(p.merge_threshold ** 2 * tr)
+print("merge radius percentiles 1/10/50/90/99/100:", np.percentile(rad, [1, 10, 50, 90, 99, 100]))
+print("box extent:", cm.max(0) - cm.min(0), "rows:", len(cw))
+nav.close()

@@ -13,9 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from monorfs_amd import _lib
 
-so = os.path.join(_lib.CSRC, "libphdhip_stamps.so")
+extra = os.environ.get("PHD_STAMP_DEFS", "").split()   # e.g. "-DPHD_EXP=1" for a what-if build
+so = os.path.join(_lib.CSRC, "libphdhip_stamps%s.so" % "".join(c for c in "".join(extra) if c.isalnum()))
 if not os.path.exists(so):
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + _lib.HIPCC_FLAGS + ["-DPHD_STAMPS", "-o", so, os.path.join(_lib.CSRC, "phdhip.hip")])
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + _lib.HIPCC_FLAGS + ["-DPHD_STAMPS"] + extra + ["-o", so, os.path.join(_lib.CSRC, "phdhip.hip")])
 _lib.SO_PATH = so
 from monorfs_amd import navigator
 from monorfs_amd.abi import prm3d_defaults
