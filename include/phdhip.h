@@ -133,6 +133,10 @@ int phd_sync(phd_navigator* nav);
 /* Benchmark aid: when frozen, a step reads the current state but does not replace it, so every
  * step sees identical input sizes (SURVEY §8d "steady state").                                   */
 int phd_set_frozen(phd_navigator* nav, uint8_t frozen);
+/* Scheduling knob (1..4; 0 = chosen from the particle count, the default; environment PHD_SPLIT at phd_create): the per-particle kernels of a
+ * step are launched as `nsplit` particle sub-ranges on concurrent streams, forked from and joined into the
+ * handle's stream. Results do not depend on it.                                                  */
+int phd_set_split(phd_navigator* nav, int nsplit);
 
 /* Getters. Buffers are library-owned and valid until the next call on the handle.               */
 const double* phd_weights(phd_navigator* nav, int* length);               /* VehicleWeights       */

@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 	__shared__ int s_J, s_changed, s_nroots, s_big;
 	__shared__ double s_ccount, s_total;
 
-	const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int M = a.M, cap = a.cap;
 	const MixView vin = bank_view(a, SEL_IN), vout = bank_view(a, SEL_OUT);
 	const Bank& bin  = a.bank[a.sel[SEL_IN]];
@@ -1083,12 +1083,12 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 __global__ __launch_bounds__(256) void k_alpha_density(const DevParams prm, const StepBufs a)
 {
 	constexpr int JL = ALPHA_JL;
-	__shared__ double tile[TILE * 12];          // [TILE][12]: mean, inverse covariance, weight, multiplier
+	__shared__ double tile[TILE * 10];          // [TILE][10]: gauss_record
 	__shared__ double partl[(JL / 64) * 256];   // [JB][4][64] partial densities (HBM slab when J > JL)
 	__shared__ double red[256];
 	__shared__ double etab[EXPTAB_N];
 
-	const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int cap = a.cap;
 	const MixView vin = bank_view(a, SEL_IN), vout = bank_view(a, SEL_OUT);
 	const Bank& bin  = a.bank[a.sel[SEL_IN]];
@@ -1141,13 +1141,7 @@ __global__ __launch_bounds__(256) void k_alpha_density(const DevParams prm, cons
 						for (int t = 0; t < 6; t++) P[t] = prm.birthP[t];
 					}
 					inv_sym3(P, Pi, det);
-					double* tt = tile + tid * 12;
-#pragma unroll
-					for (int t = 0; t < 3; t++) tt[t] = m[t];
-#pragma unroll
-					for (int t = 0; t < 6; t++) tt[3 + t] = Pi[t];
-					tt[9]  = w;
-					tt[10] = PHD_INV_2PI / sqrt(fabs(det));
+					gauss_record(w, m, Pi, PHD_INV_2PI / sqrt(fabs(det)), tile + tid * 10);
 				}
 				__syncthreads();
 				const int cend = min(TILE, total - c0);
@@ -1160,12 +1154,8 @@ __global__ __launch_bounds__(256) void k_alpha_density(const DevParams prm, cons
 					const double x0 = jv ? lm[j] : 0, x1 = jv ? lm[JS + j] : 0, x2 = jv ? lm[2 * JS + j] : 0;
 					// w * (mult * exp(-d^T Pinv d / 2)) of component cc at this lane's landmark (Map.cs:198)
 					auto dens = [&](int cc) {
-						const double* tt = tile + cc * 12;
-						double d0 = x0 - tt[0], d1 = x1 - tt[1], d2 = x2 - tt[2];
-						double Pi[6];
-#pragma unroll
-						for (int t = 0; t < 6; t++) Pi[t] = tt[3 + t];
-						return tt[9] * (tt[10] * exp_neg(-0.5 * quad_sym(Pi, d0, d1, d2), etab));
+						const double* tt = tile + cc * 10;
+						return exp_neg(gauss_logw(tt, x0 - tt[0], x1 - tt[1], x2 - tt[2]), etab);
 					};
 					double acc = 0, acc2 = 0;
 					int cc = wv * G + g;

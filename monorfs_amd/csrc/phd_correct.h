@@ -47,11 +47,11 @@ __global__ __launch_bounds__(256) void k_explore(const DevParams prm, const Step
 	constexpr int MP = ZB * 64;
 	__shared__ double zmap[3 * MP];        // MeasureToMap(z)
 	__shared__ double part[4 * MP];        // per-wave partial densities
-	__shared__ double tile[TILE * 12];     // [TILE][12]: mean, inverse covariance, weight, multiplier
+	__shared__ double tile[TILE * 10];     // [TILE][10]: gauss_record
 	__shared__ double etab[EXPTAB_N];
 	__shared__ int    born[MP];
 
-	const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int M = a.M;
 	const MixView vin = bank_view(a, SEL_IN);
 	const Bank& bin  = a.bank[a.sel[SEL_IN]];
@@ -91,26 +91,19 @@ __global__ __launch_bounds__(256) void k_explore(const DevParams prm, const Step
 #pragma unroll
 			for (int t = 0; t < 6; t++) P[t] = vin.P[t][sb + c];
 			inv_sym3(P, Pi, det);
-			double* tt = tile + tid * 12;
-			tt[0] = vin.m[0][sb + c]; tt[1] = vin.m[1][sb + c]; tt[2] = vin.m[2][sb + c];
-#pragma unroll
-			for (int t = 0; t < 6; t++) tt[3 + t] = Pi[t];
-			tt[9]  = vin.w[sb + c];
-			tt[10] = PHD_INV_2PI / sqrt(fabs(det));
+			const double m[3] = {vin.m[0][sb + c], vin.m[1][sb + c], vin.m[2][sb + c]};
+			gauss_record(vin.w[sb + c], m, Pi, PHD_INV_2PI / sqrt(fabs(det)), tile + tid * 10);
 		}
 		__syncthreads();
 		const int cend = min(TILE, n - c0);
 		// w * N(x; m, P) of component cc at this lane's measurements, inside the radius gate (Map.cs:214-217)
 		auto visit = [&](int cc) {
-			const double* tt = tile + cc * 12;
-			double Pi[6];
-#pragma unroll
-			for (int t = 0; t < 6; t++) Pi[t] = tt[3 + t];
+			const double* tt = tile + cc * 10;
 #pragma unroll
 			for (int b = 0; b < ZB; b++) {
 				double d0 = wx[b] - tt[0], d1 = wy[b] - tt[1], d2 = wz[b] - tt[2];
 				double sq = d0 * d0 + d1 * d1 + d2 * d2;
-				double v  = tt[9] * (tt[10] * exp_neg(-0.5 * quad_sym(Pi, d0, d1, d2), etab));
+				double v  = exp_neg(gauss_logw(tt, d0, d1, d2), etab);
 				if (zv[b] && sq <= g2) acc[b] += v;
 			}
 		};
@@ -153,7 +146,7 @@ __global__ __launch_bounds__(256) void k_explore(const DevParams prm, const Step
 __global__ __launch_bounds__(256) void k_measure(const DevParams prm, const StepBufs a)
 {
 	__shared__ int s_cnt;
-	const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63;
 	const MixView vin = bank_view(a, SEL_IN);
 	const Bank& bin = a.bank[a.sel[SEL_IN]];
 	const int n = vin.count[p], np = n + a.born_count[p];
@@ -226,7 +219,7 @@ __global__ __launch_bounds__(256) void k_correct(const DevParams prm, const Step
 	__shared__ double etab[EXPTAB_N];
 	__shared__ int    s_npair, s_ncand;
 
-	const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int M = a.M;
 	const MixView vin = bank_view(a, SEL_IN);
 	const Bank& bin = a.bank[a.sel[SEL_IN]];
@@ -378,7 +371,7 @@ __global__ __launch_bounds__(256) void k_correct(const DevParams prm, const Step
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_emit_finish(const DevParams prm, const StepBufs a)
 {
-	const int p = blockIdx.x, tid = threadIdx.x;
+	const int p = a.p0 + blockIdx.x, tid = threadIdx.x;
 	const MixView vin = bank_view(a, SEL_IN);
 	const Bank& bin = a.bank[a.sel[SEL_IN]];
 	const int n = vin.count[p], np = n + a.born_count[p];

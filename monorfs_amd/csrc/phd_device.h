@@ -12,7 +12,7 @@
 #ifdef PHD_STAMPS
 #define PHD_STAMP_DECL long long stamp_[12]; for (int s_ = 0; s_ < 12; s_++) stamp_[s_] = 0
 #define PHD_STAMP(i) stamp_[i] = clock64()
-#define PHD_STAMP_FLUSH(id, n) if (threadIdx.x == 0 && a.stamps && a.stamp_kernel == (id)) { for (int s_ = 0; s_ < (n); s_++) a.stamps[(size_t) blockIdx.x * 16 + s_] = (double) (stamp_[s_] - stamp_[0]); }
+#define PHD_STAMP_FLUSH(id, n) if (threadIdx.x == 0 && a.stamps && a.stamp_kernel == (id)) { for (int s_ = 0; s_ < (n); s_++) a.stamps[(size_t) (a.p0 + blockIdx.x) * 16 + s_] = (double) (stamp_[s_] - stamp_[0]); }
 #else
 #define PHD_STAMP_DECL
 #define PHD_STAMP(i)
@@ -211,28 +211,46 @@ __device__ __forceinline__ double quad_gen(const double A[9], double d0, double 
 // with 2^(j/32) from a 32-entry table in LDS and e^r by a degree-6 Taylor polynomial: a dependent chain of
 // 6 fused multiply-adds instead of the ~14 of a table-free evaluation. Measured against libm on [-700, 0]:
 // <= 2 ulp (3.9e-16). A NaN stays a NaN, anything below -800 gives 0 like exp does.
-#define EXPTAB_N 32
+#define EXPTAB_N 256
 __device__ __forceinline__ void exp_tab_init(double* T, int tid)
 {
 	if (tid < EXPTAB_N) T[tid] = exp2((double) tid / EXPTAB_N);
 }
 
+// exp(x) for x in (-inf, 700]: x = (256 n' + j) ln2 / 256 + r, exp(x) = 2^n' * T[j] * p(r) with |r| <= ln2 / 512 and
+// p the degree-4 Taylor polynomial (truncation 4e-17 relative). Below -800 the result is 0; a NaN stays a NaN.
 __device__ __forceinline__ double exp_neg(double x, const double* __restrict__ T)
 {
 	x = (x < -800.0) ? -800.0 : x;
-	const double n = rint(x * 46.16624130844683);               // 32 / ln 2
-	double r = fma(-n, 0.021660849335603416, x);                 // ln2/32, high part (trailing bits zero)
-	r = fma(-n, 5.689487495325457e-11, r);                      //         low part
+	const double n = rint(x * 369.3299304675746);                // 256 / ln 2
+	double r = fma(-n, 0.002707606166950427, x);                 // ln2/256, high part (trailing bits zero)
+	r = fma(-n, 7.111859369156821e-12, r);                      //          low part
 	const int ni = (int) n;
 	const double t = T[ni & (EXPTAB_N - 1)];
-	double p = 0.001388888888888889;                             // 1/6!
-	p = fma(p, r, 0.008333333333333333);
-	p = fma(p, r, 0.041666666666666664);
-	p = fma(p, r, 0.16666666666666666);
+	double p = fma(r, 0.041666666666666664, 0.16666666666666666);
 	p = fma(p, r, 0.5);
 	p = fma(p, r, 1.0);
 	p = fma(p, r, 1.0);
-	return ldexp(t * p, ni >> 5);
+	return ldexp(t * p, ni >> 8);
+}
+
+// A weighted Gaussian w N(x; m, P) in the form the dense evaluation loops use: exp(g9 + d^T G d), d = x - m, with
+// G = -P^-1 / 2 folded for the upper-triangle sum (off-diagonal entries doubled) and g9 = log(w mult).
+__device__ __forceinline__ void gauss_record(double w, const double m[3], const double Pi[6], double mult, double* g)
+{
+	g[0] = m[0]; g[1] = m[1]; g[2] = m[2];
+	g[3] = -0.5 * Pi[0]; g[4] = -Pi[1]; g[5] = -Pi[2];
+	g[6] = -0.5 * Pi[3]; g[7] = -Pi[4];
+	g[8] = -0.5 * Pi[5];
+	g[9] = log(w * mult);
+}
+
+__device__ __forceinline__ double gauss_logw(const double* __restrict__ g, double d0, double d1, double d2)
+{
+	const double t0 = fma(g[5], d2, fma(g[4], d1, g[3] * d0));
+	const double t1 = fma(g[7], d2, g[6] * d1);
+	const double t2 = g[8] * d2;
+	return fma(t0, d0, fma(t1, d1, fma(t2, d2, g[9])));
 }
 
 // per-component measurement-space quantities of CorrectConditional (PHDNavigator.cs:857-870)

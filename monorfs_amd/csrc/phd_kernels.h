@@ -38,7 +38,8 @@ struct Bank {
 #define SEL_TMP 2   // bank a resampling copy goes to
 
 struct StepBufs {
-	int P;          // particles in this launch
+	int P;          // particles of this handle
+	int p0;         // first particle of this launch (a step may be split into sub-ranges on concurrent streams)
 	int cap;        // slots per particle in a mixture slab
 	int M;          // measurements
 	int Mcap;       // stride of per-measurement scratch

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	int*    scan  = (int*) (smem + lay.scan);              // [264]
 	double* bred  = smem + lay.scan;                       // [28] block reduction scratch (before `scan` is used)
 
-	const int p = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	PHD_STAMP_DECL;
 	const MixView vout = bank_view(a, SEL_OUT);
 	const int ne = a.emit_count[p];
@@ -462,10 +462,10 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 			nbr[2 * i + 1] = hi;
 #ifdef PHD_STAMP_COUNTERS   // (slow: contended atomics; counts only, never together with timing)
 			if (a.stamps && a.stamp_kernel == 2) {
-				atomicAdd(&a.stamps[(size_t) blockIdx.x * 16 + 12], (double) dbg_walk);
-				atomicAdd(&a.stamps[(size_t) blockIdx.x * 16 + 13], (double) dbg_test);
-				atomicAdd(&a.stamps[(size_t) blockIdx.x * 16 + 14], (double) cnt);
-				if (!(bound <= rcap * rcap)) atomicAdd(&a.stamps[(size_t) blockIdx.x * 16 + 15], 1.0);
+				atomicAdd(&a.stamps[(size_t) p * 16 + 12], (double) dbg_walk);
+				atomicAdd(&a.stamps[(size_t) p * 16 + 13], (double) dbg_test);
+				atomicAdd(&a.stamps[(size_t) p * 16 + 14], (double) cnt);
+				if (!(bound <= rcap * rcap)) atomicAdd(&a.stamps[(size_t) p * 16 + 15], 1.0);
 			}
 #endif
 		}

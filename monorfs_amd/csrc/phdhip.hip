@@ -30,6 +30,10 @@ struct phd_navigator {
 	int         device = 0;
 	hipStream_t stream = nullptr;      // the stream every kernel of this handle is launched on
 	hipStream_t own_stream = nullptr;  // created by phd_create; `stream` unless the host lent its own
+	static const int MAXSPLIT = 4;
+	int         nsplit = 0;            // sub-ranges a step's per-particle kernels are split into (0: chosen from the particle count)
+	hipStream_t aux[MAXSPLIT - 1] = {nullptr, nullptr, nullptr};   // streams of the sub-ranges after the first
+	hipEvent_t  ev_fork = nullptr, ev_join[MAXSPLIT - 1] = {nullptr, nullptr, nullptr};
 	bool sel_host_valid = false;       // h_sel mirrors the device-side bank roles without a round trip
 	int Pcap = 0, cap = 0, Mcap = 0, ecap = 0, Jcap = 0, cutcap = 0;
 	int P = 0, M = 0;
@@ -154,7 +158,7 @@ DevParams make_dev_params(const phd_params& p)
 StepBufs make_bufs(phd_navigator* nav)
 {
 	StepBufs b;
-	b.P = nav->P; b.cap = nav->cap; b.M = nav->M; b.Mcap = nav->Mcap; b.ecap = nav->ecap; b.Jcap = nav->Jcap;
+	b.P = nav->P; b.p0 = 0; b.cap = nav->cap; b.M = nav->M; b.Mcap = nav->Mcap; b.ecap = nav->ecap; b.Jcap = nav->Jcap;
 	b.plane = (size_t) nav->Pcap * nav->cap;
 	for (int i = 0; i < 3; i++) b.bank[i] = nav->bank[i];
 	b.sel = nav->d_sel + nav->parity * 4;
@@ -173,8 +177,9 @@ int zb_of(int M) { return M <= 64 ? 1 : (M <= 128 ? 2 : 4); }
 
 
 // HIP events around every kernel launch, on the stream the kernel is launched on
-void timer_begin(phd_navigator* nav, const char* name)
+void timer_begin(phd_navigator* nav, const char* name, hipStream_t st = nullptr)
 {
+	if (!st) st = nav->stream;
 	if (!nav->timing) return;
 	if (nav->ntimers == nav->timers.size()) {
 		if (nav->timers.size() >= 65536) { nav->timing = false; return; }
@@ -185,13 +190,14 @@ void timer_begin(phd_navigator* nav, const char* name)
 	}
 	Timer& t = nav->timers[nav->ntimers];
 	t.name = name;
-	hipEventRecord(t.t0, nav->stream);
+	hipEventRecord(t.t0, st);
 }
 
-void timer_end(phd_navigator* nav, const char* name)
+void timer_end(phd_navigator* nav, const char* name, hipStream_t st = nullptr)
 {
+	if (!st) st = nav->stream;
 	if (!nav->timing || nav->ntimers >= nav->timers.size()) return;
-	hipEventRecord(nav->timers[nav->ntimers].t1, nav->stream);
+	hipEventRecord(nav->timers[nav->ntimers].t1, st);
 	nav->ntimers++;
 }
 
@@ -205,42 +211,59 @@ const char* T_WD = "k_alpha_density";
 const char* T_NR = "k_normalise_resample";
 const char* T_GR = "k_gather_rotate";
 
+// The per-particle kernels of a step. With nsplit > 1 the particle range is cut into sub-ranges whose kernel
+// chains run on concurrent streams (forked from and joined back into the handle's stream), so that the
+// latency-bound kernels of one sub-range overlap the arithmetic-bound kernels of another.
 template <int ZB>
-int launch_map_kernels(phd_navigator* nav, const StepBufs& b, bool with_alpha)
+int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha)
 {
 	const int P = nav->P;
-	timer_begin(nav, T_EX);
-	hipLaunchKernelGGL(k_explore<ZB>, dim3(P), dim3(256), 0, nav->stream, nav->dp, b);
-	timer_end(nav, T_EX);
-	timer_begin(nav, T_ME);
-	hipLaunchKernelGGL(k_measure, dim3(P), dim3(256), 0, nav->stream, nav->dp, b);
-	timer_end(nav, T_ME);
-	timer_begin(nav, T_CO);
-	hipLaunchKernelGGL(k_correct<ZB>, dim3(P), dim3(256), 0, nav->stream, nav->dp, b);
-	timer_end(nav, T_CO);
-	timer_begin(nav, T_EF);
-	hipLaunchKernelGGL(k_emit_finish, dim3(P), dim3(256), 0, nav->stream, nav->dp, b);
-	timer_end(nav, T_EF);
-	HC(hipGetLastError());
-
-	size_t lp = (size_t) prune_lds(nav->cutcap).bytes;
+	// two half-ranges measured best at 2048 particles (1.10 -> 1.02 ms); below ~4 workgroups per CU and sub-range it does not pay
+	const int want = nav->nsplit > 0 ? nav->nsplit : (P >= 1024 ? 2 : 1);
+	const int S = std::max(1, std::min(std::min(want, (int) phd_navigator::MAXSPLIT), P));
+	const size_t lp = (size_t) prune_lds(nav->cutcap).bytes;
+	const AlphaLds lay = alpha_lds(ZB * 64, nav->cutcap);
 	HC(hipFuncSetAttribute((const void*) k_prune_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lp));
-	timer_begin(nav, T_PM);
-	hipLaunchKernelGGL(k_prune_merge, dim3(P), dim3(256), lp, nav->stream, nav->dp, b, nav->cutcap);
-	timer_end(nav, T_PM);
-	HC(hipGetLastError());
-
-	if (with_alpha) {
-		AlphaLds lay = alpha_lds(ZB * 64, nav->cutcap);
-		HC(hipFuncSetAttribute((const void*) k_alpha_assoc<ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
-		timer_begin(nav, T_WA);
-		hipLaunchKernelGGL(k_alpha_assoc<ZB>, dim3(P), dim3(256), lay.bytes, nav->stream, nav->dp, b, nav->cutcap);
-		timer_end(nav, T_WA);
-		timer_begin(nav, T_WD);
-		hipLaunchKernelGGL(k_alpha_density, dim3(P), dim3(256), 0, nav->stream, nav->dp, b);
-		timer_end(nav, T_WD);
-		HC(hipGetLastError());
+	HC(hipFuncSetAttribute((const void*) k_alpha_assoc<ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
+	if (S > 1) {
+		HC(hipEventRecord(nav->ev_fork, nav->stream));
+		for (int s = 1; s < S; s++) HC(hipStreamWaitEvent(nav->aux[s - 1], nav->ev_fork, 0));
 	}
+	for (int s = 0; s < S; s++) {
+		StepBufs b = b0;
+		b.p0 = (int) ((long long) P * s / S);
+		const int n = (int) ((long long) P * (s + 1) / S) - b.p0;
+		if (n <= 0) continue;
+		hipStream_t st = s == 0 ? nav->stream : nav->aux[s - 1];
+		timer_begin(nav, T_EX, st);
+		hipLaunchKernelGGL(k_explore<ZB>, dim3(n), dim3(256), 0, st, nav->dp, b);
+		timer_end(nav, T_EX, st);
+		timer_begin(nav, T_ME, st);
+		hipLaunchKernelGGL(k_measure, dim3(n), dim3(256), 0, st, nav->dp, b);
+		timer_end(nav, T_ME, st);
+		timer_begin(nav, T_CO, st);
+		hipLaunchKernelGGL(k_correct<ZB>, dim3(n), dim3(256), 0, st, nav->dp, b);
+		timer_end(nav, T_CO, st);
+		timer_begin(nav, T_EF, st);
+		hipLaunchKernelGGL(k_emit_finish, dim3(n), dim3(256), 0, st, nav->dp, b);
+		timer_end(nav, T_EF, st);
+		timer_begin(nav, T_PM, st);
+		hipLaunchKernelGGL(k_prune_merge, dim3(n), dim3(256), lp, st, nav->dp, b, nav->cutcap);
+		timer_end(nav, T_PM, st);
+		if (with_alpha) {
+			timer_begin(nav, T_WA, st);
+			hipLaunchKernelGGL(k_alpha_assoc<ZB>, dim3(n), dim3(256), lay.bytes, st, nav->dp, b, nav->cutcap);
+			timer_end(nav, T_WA, st);
+				timer_begin(nav, T_WD, st);
+			hipLaunchKernelGGL(k_alpha_density, dim3(n), dim3(256), 0, st, nav->dp, b);
+			timer_end(nav, T_WD, st);
+		}
+	}
+	for (int s = 1; s < S; s++) {
+		HC(hipEventRecord(nav->ev_join[s - 1], nav->aux[s - 1]));
+		HC(hipStreamWaitEvent(nav->stream, nav->ev_join[s - 1], 0));
+	}
+	HC(hipGetLastError());
 	return PHD_OK;
 }
 
@@ -415,6 +438,12 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	auto dalloc = [&](void** ptr, size_t bytes) { return hipMalloc(ptr, std::max<size_t>(bytes, 16)) == hipSuccess; };
 	bool ok = hipStreamCreateWithFlags(&nav->own_stream, hipStreamNonBlocking) == hipSuccess;
 	nav->stream = nav->own_stream;
+	for (int i = 0; i < phd_navigator::MAXSPLIT - 1; i++) {
+		ok = ok && hipStreamCreateWithFlags(&nav->aux[i], hipStreamNonBlocking) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&nav->ev_join[i], hipEventDisableTiming) == hipSuccess;
+	}
+	ok = ok && hipEventCreateWithFlags(&nav->ev_fork, hipEventDisableTiming) == hipSuccess;
+	if (const char* e = getenv("PHD_SPLIT")) nav->nsplit = std::max(0, atoi(e));
 	size_t plane = (size_t) nav->Pcap * nav->cap;
 	for (int i = 0; i < 3 && ok; i++) {
 		ok = ok && dalloc((void**) &nav->bank[i].mix, plane * 10 * 8);
@@ -480,6 +509,11 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cm); hipFree(nav->d_pair_ck); hipFree(nav->d_pair_w); hipFree(nav->d_pair_count); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
 	if (nav->own_stream) hipStreamDestroy(nav->own_stream);
+	for (int i = 0; i < phd_navigator::MAXSPLIT - 1; i++) {
+		if (nav->aux[i]) hipStreamDestroy(nav->aux[i]);
+		if (nav->ev_join[i]) hipEventDestroy(nav->ev_join[i]);
+	}
+	if (nav->ev_fork) hipEventDestroy(nav->ev_fork);
 	delete nav;
 }
 
@@ -600,6 +634,13 @@ int phd_set_measurements(phd_navigator* nav, const double* z3, int nmeasurements
 		HC(hipStreamSynchronize(nav->stream));
 	}
 	nav->M = nmeasurements;
+	return PHD_OK;
+}
+
+int phd_set_split(phd_navigator* nav, int nsplit)
+{
+	if (!nav || nsplit < 0 || nsplit > phd_navigator::MAXSPLIT) return PHD_ERR_BAD_ARGUMENT;
+	nav->nsplit = nsplit;
 	return PHD_OK;
 }
 

@@ -238,6 +238,10 @@ class PHDNavigator:
     def set_frozen(self, frozen):
         self._check(self._lib.phd_set_frozen(self._h, int(bool(frozen))))
 
+    def set_split(self, nsplit):
+        """Launch a step's per-particle kernels as `nsplit` sub-ranges on concurrent streams (phd_set_split)."""
+        self._check(self._lib.phd_set_split(self._h, int(nsplit)))
+
     def timing_reset(self, enabled=True):
         self._check(self._lib.phd_timing_reset(self._h, int(bool(enabled))))
 
