@@ -3,21 +3,24 @@
 //
 //   k_explore<ZB>   PredictConditional (PHDNavigator.cs:793-819): Explored(model, MeasureToMap(z)) for every
 //                   measurement against the PRIOR map; unexplored measurements become births.
-//   k_measure       per component of the predicted mixture (prior + births): h(m), H, P H^T, S^-1, PD
-//                   (:857-870) written as 18 planes of per-component quantities, and the misdetection copies
-//                   w (1 - PD) (:837-840) that survive MinWeight.
+//   k_measure       per component of the predicted mixture (prior + births): h(m), S^-1, PD (:857-870) reduced to
+//                   the 10 planes the pair sweep needs (h(m), the folded quadratic form, the log of PD w times the
+//                   multiplier), and the misdetection copies w (1 - PD) (:837-840) that survive MinWeight.
 //   k_correct<ZB>   every (component, measurement) pair, measurement per lane, the component broadcast from an
-//                   LDS tile: sweep 0 accumulates weightsum[z] over the near components (:886-890), sweep 1
-//                   finds the pairs whose w' = PD w q / (kappa + weightsum) reaches MinWeight (:899) and
-//                   queues them.
-//   k_emit_finish   Kalman update of the queued pairs (:895-897): m' = m + K nu, P' = (I - K H) P.
+//                   LDS tile: weightsum[z] over the near components (:886-890); pairs that can reach MinWeight
+//                   are queued.
+//   k_emit_finish   the queued pairs: w' = PD w q / (kappa + weightsum) (:899) in the reference's own arithmetic
+//                   and, for those that reach MinWeight, the Kalman update (:895-897) m' = m + K nu,
+//                   P' = (I - K H) P.
 //
-// Splitting keeps the hot pair loops free of the register-hungry per-component algebra (the fused version
-// needed 252 VGPRs and spilled ~100 SGPRs); the price is the 18-plane scratch, written once and read twice.
+// Splitting keeps the hot pair loop free of the register-hungry per-component algebra (the fused version
+// needed 252 VGPRs and spilled ~100 SGPRs); the price is the plane scratch, written once and read once.
 #pragma once
 #include "phd_device.h"
 
-#define CM_PLANES 18   // zh[3], Sinv[9], qmult, pdw, m[3], dcut
+#define CM_PLANES 10   // zh[3], G[6], lw: PD w N(z; zh, S) = exp(lw + d^T G d), d = z - zh
+#define CM_TILE   13   // what the pair sweep stages per component: the planes and the mean
+#define EMIT_LIST 1024 // pairs k_emit_finish gathers before it runs the Kalman path on them
 
 // component c of the predicted mixture = prior slab entry or a birth (mean from the explore kernel)
 __device__ __forceinline__ void load_predicted(const DevParams& prm, const StepBufs& a, const MixView& vin, int p, int n, int c,
@@ -169,15 +172,14 @@ __global__ __launch_bounds__(256) void k_measure(const DevParams prm, const Step
 			const double pdw = q.pd * w;
 #pragma unroll
 			for (int t = 0; t < 3; t++) cm[(size_t) t * cstride + c] = q.zh[t];
-#pragma unroll
-			for (int t = 0; t < 9; t++) cm[(size_t) (3 + t) * cstride + c] = q.Sinv[t];
-			cm[(size_t) 12 * cstride + c] = q.qmult;
-			cm[(size_t) 13 * cstride + c] = pdw;
-#pragma unroll
-			for (int t = 0; t < 3; t++) cm[(size_t) (14 + t) * cstride + c] = m[t];
-			// no pair can reach MinWeight unless  PD w mult exp(-d2/2) >= MinWeight * kappa
-			double dc = 2.0 * (log(pdw * q.qmult) - prm.emit_log_floor) + 1.0;
-			cm[(size_t) 17 * cstride + c] = isinf(prm.emit_log_floor) ? INFINITY : dc;
+			// G = -(S^-1 + S^-T) / 4 folded for the upper-triangle sum of gauss_logw
+			cm[(size_t) 3 * cstride + c] = -0.5 * q.Sinv[0];
+			cm[(size_t) 4 * cstride + c] = -0.5 * (q.Sinv[1] + q.Sinv[3]);
+			cm[(size_t) 5 * cstride + c] = -0.5 * (q.Sinv[2] + q.Sinv[6]);
+			cm[(size_t) 6 * cstride + c] = -0.5 * q.Sinv[4];
+			cm[(size_t) 7 * cstride + c] = -0.5 * (q.Sinv[5] + q.Sinv[7]);
+			cm[(size_t) 8 * cstride + c] = -0.5 * q.Sinv[8];
+			cm[(size_t) 9 * cstride + c] = log(pdw * q.qmult);
 			wm  = (1 - q.pd) * w;        // component.Reweight((1 - PD) w), :838-839
 			mis = !(wm < prm.minw);
 		}
@@ -214,19 +216,20 @@ __global__ __launch_bounds__(256) void k_correct(const DevParams prm, const Step
 {
 	constexpr int MP = ZB * 64;
 	__shared__ double zs[3 * MP], zmap[3 * MP];
-	__shared__ double part[4 * MP], denom[MP];
-	__shared__ double tile[TILE * CM_PLANES];   // [TILE][18]
+	__shared__ double part[4 * MP];
+	__shared__ double tile[TILE * CM_TILE];   // [TILE][13]
 	__shared__ double etab[EXPTAB_N];
-	__shared__ int    s_npair, s_ncand;
+	__shared__ int    s_ncand;
 
 	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int M = a.M;
 	const MixView vin = bank_view(a, SEL_IN);
 	const Bank& bin = a.bank[a.sel[SEL_IN]];
-	const int np = vin.count[p] + a.born_count[p];
+	const int n = vin.count[p], np = n + a.born_count[p];
+	const size_t sb = (size_t) p * a.cap;
 	const PoseD pose = load_pose(bin.poses + (size_t) p * 7);
 	exp_tab_init(etab, tid);
-	if (tid == 0) { s_npair = 0; s_ncand = 0; }
+	if (tid == 0) s_ncand = 0;
 	for (int k = tid; k < MP; k += 256) {
 		double z[3] = {0, 0, 1}, x[3] = {0, 0, 0};
 		if (k < M) {
@@ -247,166 +250,163 @@ __global__ __launch_bounds__(256) void k_correct(const DevParams prm, const Step
 		wx[b] = zmap[k * 3]; wy[b] = zmap[k * 3 + 1]; wz[b] = zmap[k * 3 + 2];
 		wsum[b] = 0;
 	}
-	const double g2 = prm.g2_correct, minw = prm.minw;
+	const double g2 = prm.g2_correct;
 	const size_t cstride = a.cmplane;
 	const double* cm = a.cm + (size_t) p * a.cmcap;
-	int2*   pairs_ck = (int2*) (a.pair_ck + (size_t) p * a.ecap);
-	double* pairs_w  = a.pair_w + (size_t) p * a.ecap;
-	int*    cands    = a.cand + (size_t) p * a.candcap;   // (component << 8 | measurement) of the pairs worth a second look
+	int2* cands = (int2*) a.cand + (size_t) p * a.candcap;   // (component << 8 | measurement, exponent as float32) of the pairs worth a second look
 
-	for (int sweep = 0; sweep < 2; sweep++) {
-		if (sweep == 1 && s_ncand <= a.candcap) break;   // the queue held every candidate: handled below
-		for (int c0 = 0; c0 < np; c0 += TILE) {
-			const int c = c0 + tid;
-			if (c < np) {
-				double* tt = tile + tid * CM_PLANES;
+	// weightsum[z] += PD w q(z) over the components near MeasureToMap(z) (:882-890); a pair can only reach MinWeight
+	// when PD w q(z) >= MinWeight kappa, i.e. its exponent reaches emit_log_floor (half a unit of margin for the
+	// rounding of the folded form): those are queued for k_emit_finish
+	const double xcut = prm.emit_log_floor - 0.5;
+	for (int c0 = 0; c0 < np; c0 += TILE) {
+		const int c = c0 + tid;
+		if (c < np) {
+			double* tt = tile + tid * CM_TILE;
 #pragma unroll
-				for (int t = 0; t < CM_PLANES; t++) tt[t] = cm[(size_t) t * cstride + c];
-			}
-			__syncthreads();
-			const int cend = min(TILE, np - c0);
-			if (sweep == 0) {
-				// weightsum[z] += PD w q(z) over the components near MeasureToMap(z) (:882-890)
-				auto visit = [&](int cc) {
-					const double* tt = tile + cc * CM_PLANES;
-					double Si[9];
+			for (int t = 0; t < CM_PLANES; t++) tt[t] = cm[(size_t) t * cstride + c];
+			if (c < n) {
 #pragma unroll
-					for (int t = 0; t < 9; t++) Si[t] = tt[3 + t];
-#pragma unroll
-					for (int b = 0; b < ZB; b++) {
-						double e0 = wx[b] - tt[14], e1 = wy[b] - tt[15], e2 = wz[b] - tt[16];
-						double sq = e0 * e0 + e1 * e1 + e2 * e2;
-						double d2 = quad_gen(Si, zx[b] - tt[0], zy[b] - tt[1], zr[b] - tt[2]);
-						double v  = tt[13] * (tt[12] * exp_neg(-0.5 * d2, etab));   // PD w * mc.Evaluate(z)
-						const bool near = zv[b] && sq <= g2;
-						if (near) wsum[b] += v;
-						// only a pair with d2 <= dcut can reach MinWeight: remember it for the second pass
-						const bool cand = near && d2 <= tt[17];
-						unsigned long long bal = __ballot(cand);
-						if (bal) {
-							int base = 0, first = __ffsll((long long) bal) - 1;
-							if (lane == first) base = atomicAdd(&s_ncand, __popcll(bal));
-							base = __shfl(base, first, 64);
-							if (cand) {
-								int slot = base + __popcll(bal & lanemask_lt());
-								if (slot < a.candcap) cands[slot] = ((c0 + cc) << 8) | (b * 64 + lane);
-							}
-						}
-					}
-				};
-				int cc = wv;
-				for (; cc + 4 < cend; cc += 8) { visit(cc); visit(cc + 4); }
-				if (cc < cend) visit(cc);
+				for (int t = 0; t < 3; t++) tt[10 + t] = vin.m[t][sb + c];
 			}
 			else {
-				for (int cc = wv; cc < cend; cc += 4) {
-					const double* tt = tile + cc * CM_PLANES;
-					double Si[9];
-#pragma unroll
-					for (int t = 0; t < 9; t++) Si[t] = tt[3 + t];
-					const double dc = tt[17];
-#pragma unroll
-					for (int b = 0; b < ZB; b++) {
-						double e0 = wx[b] - tt[14], e1 = wy[b] - tt[15], e2 = wz[b] - tt[16];
-						double sq = e0 * e0 + e1 * e1 + e2 * e2;
-						double d2 = quad_gen(Si, zx[b] - tt[0], zy[b] - tt[1], zr[b] - tt[2]);
-						bool cand = zv[b] && sq <= g2 && (d2 <= dc);
-						if (__ballot(cand)) {
-							double q   = tt[12] * exp_neg(-0.5 * d2, etab);
-							double wgt = tt[13] * q / denom[b * 64 + lane];   // :899
-							bool   em  = cand && !(wgt < minw);
-							unsigned long long bal = __ballot(em);
-							if (bal) {
-								int base = 0, first = __ffsll((long long) bal) - 1;
-								if (lane == first) base = atomicAdd(&s_npair, __popcll(bal));
-								base = __shfl(base, first, 64);
-								if (em) {
-									int slot = base + __popcll(bal & lanemask_lt());
-									if (slot < a.ecap) {
-										pairs_ck[slot] = make_int2(c0 + cc, b * 64 + lane);
-										pairs_w[slot]  = wgt;
-									}
-								}
-							}
-						}
-					}
-				}
-			}
-			__syncthreads();
-		}
-		if (sweep == 0) {
-#pragma unroll
-			for (int b = 0; b < ZB; b++) part[wv * MP + b * 64 + lane] = wsum[b];
-			__syncthreads();
-			for (int k = tid; k < MP; k += 256) {
-				denom[k] = prm.kappa + (part[k] + part[MP + k] + part[2 * MP + k] + part[3 * MP + k]);
-			}
-			__syncthreads();
-		}
-	}
-	// second pass over the queued candidates only: w' = PD w q / (kappa + weightsum) >= MinWeight (:899)
-	if (s_ncand <= a.candcap) {
-		const int ncand = s_ncand;
-		for (int j = tid; j < ncand; j += 256) {
-			const int code = cands[j], c = code >> 8, k = code & 255;
-			double Si[9];
-#pragma unroll
-			for (int t = 0; t < 9; t++) Si[t] = cm[(size_t) (3 + t) * cstride + c];
-			const double d2 = quad_gen(Si, zs[k * 3] - cm[c], zs[k * 3 + 1] - cm[cstride + c], zs[k * 3 + 2] - cm[2 * cstride + c]);
-			const double q   = cm[(size_t) 12 * cstride + c] * exp_neg(-0.5 * d2, etab);
-			const double wgt = cm[(size_t) 13 * cstride + c] * q / denom[k];
-			if (!(wgt < minw)) {
-				int slot = atomicAdd(&s_npair, 1);
-				if (slot < a.ecap) {
-					pairs_ck[slot] = make_int2(c, k);
-					pairs_w[slot]  = wgt;
-				}
+				const double* bm = a.born_mean + ((size_t) p * a.Mcap + (c - n)) * 3;
+				tt[10] = bm[0]; tt[11] = bm[1]; tt[12] = bm[2];
 			}
 		}
 		__syncthreads();
+		const int cend = min(TILE, np - c0);
+		auto visit = [&](int cc) {
+			const double* tt = tile + cc * CM_TILE;
+#pragma unroll
+			for (int b = 0; b < ZB; b++) {
+				double e0 = wx[b] - tt[10], e1 = wy[b] - tt[11], e2 = wz[b] - tt[12];
+				double sq = e0 * e0 + e1 * e1 + e2 * e2;
+				double x  = gauss_logw(tt, zx[b] - tt[0], zy[b] - tt[1], zr[b] - tt[2]);
+				double v  = exp_neg(x, etab);   // PD w * mc.Evaluate(z)
+				const bool near = zv[b] && sq <= g2;
+				if (near) wsum[b] += v;
+				const bool cand = near && x >= xcut;
+				unsigned long long bal = __ballot(cand);
+				if (bal) {
+					int base = 0, first = __ffsll((long long) bal) - 1;
+					if (lane == first) base = atomicAdd(&s_ncand, __popcll(bal));
+					base = __shfl(base, first, 64);
+					if (cand) {
+						int slot = base + __popcll(bal & lanemask_lt());
+						if (slot < a.candcap) cands[slot] = make_int2(((c0 + cc) << 8) | (b * 64 + lane), __float_as_int((float) x));
+					}
+				}
+			}
+		};
+		int cc = wv;
+		for (; cc + 4 < cend; cc += 8) { visit(cc); visit(cc + 4); }
+		if (cc < cend) visit(cc);
+		__syncthreads();
 	}
-	if (tid == 0) a.pair_count[p] = s_npair;
+#pragma unroll
+	for (int b = 0; b < ZB; b++) part[wv * MP + b * 64 + lane] = wsum[b];
+	__syncthreads();
+	for (int k = tid; k < M; k += 256) {
+		a.denom[(size_t) p * a.Mcap + k] = prm.kappa + (part[k] + part[MP + k] + part[2 * MP + k] + part[3 * MP + k]);
+	}
+	if (tid == 0) a.cand_count[p] = s_ncand;
 }
 
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_emit_finish(const DevParams prm, const StepBufs a)
 {
+	__shared__ double etab[EXPTAB_N];
+	__shared__ int    s_npair;
 	const int p = a.p0 + blockIdx.x, tid = threadIdx.x;
+	const int M = a.M;
 	const MixView vin = bank_view(a, SEL_IN);
 	const Bank& bin = a.bank[a.sel[SEL_IN]];
 	const int n = vin.count[p], np = n + a.born_count[p];
 	const int nmis = a.emit_count[p];
-	int npair = a.pair_count[p];
-	const bool overflow = npair > a.ecap || nmis + npair > a.ecap;
-	npair = min(npair, a.ecap - nmis);
+	const int ncand = a.cand_count[p];
+	exp_tab_init(etab, tid);
+	if (tid == 0) s_npair = 0;
 	__syncthreads();   // every thread has read emit_count before thread 0 rewrites it
 	const PoseD pose = load_pose(bin.poses + (size_t) p * 7);
 	double rq[9];
 	conj_matrix(pose, rq);
-	const int2*   pairs_ck = (const int2*) (a.pair_ck + (size_t) p * a.ecap);
-	const double* pairs_w  = a.pair_w + (size_t) p * a.ecap;
-	for (int j = tid; j < npair; j += 256) {
-		const int2 ck = pairs_ck[j];
+	const int2*   cands = (const int2*) a.cand + (size_t) p * a.candcap;
+	const double* denom = a.denom + (size_t) p * a.Mcap;
+	// the pair (component c, measurement k), already inside the radius gate: weight in the reference's arithmetic,
+	// and the Kalman update when it reaches MinWeight
+	auto pair = [&](int c, int k) {
 		double w, m[3], P[6];
-		load_predicted(prm, a, vin, p, n, ck.x, w, m, P);
+		load_predicted(prm, a, vin, p, n, c, w, m, P);
 		CompMeas q;
 		comp_measure(prm, pose, rq, m, P, q);
+		const double n0 = a.z[k * 3] - q.zh[0], n1 = a.z[k * 3 + 1] - q.zh[1], n2 = a.z[k * 3 + 2] - q.zh[2];
+		const double d2  = quad_gen(q.Sinv, n0, n1, n2);
+		const double qz  = q.qmult * exp_neg(-0.5 * d2, etab);   // mc.Evaluate(z)
+		const double wgt = (q.pd * w) * qz / denom[k];           // :899
+		if (wgt < prm.minw) return;
+		const int slot = nmis + atomicAdd(&s_npair, 1);
+		if (slot >= a.ecap) return;
 		double K[9], Pn[6], mn[3];
 		kalman_gain(q, K);
 		kalman_cov(q, K, P, Pn);
-		const double n0 = a.z[ck.y * 3] - q.zh[0], n1 = a.z[ck.y * 3 + 1] - q.zh[1], n2 = a.z[ck.y * 3 + 2] - q.zh[2];
 #pragma unroll
 		for (int t = 0; t < 3; t++) mn[t] = m[t] + (K[t * 3] * n0 + K[t * 3 + 1] * n1 + K[t * 3 + 2] * n2);   // :896
-		const size_t e = (size_t) p * a.ecap + nmis + j;
-		a.emit_w[e]   = pairs_w[j];
-		a.emit_idx[e] = np + ck.y * np + ck.x;   // position in the reference's `corrected` list: after the np copies, z-major
+		const size_t e = (size_t) p * a.ecap + slot;
+		a.emit_w[e]   = wgt;
+		a.emit_idx[e] = np + k * np + c;   // position in the reference's `corrected` list: after the np copies, z-major
 		double* r = a.emit_rec + e * 9;
 		r[0] = mn[0]; r[1] = mn[1]; r[2] = mn[2];
 #pragma unroll
 		for (int t = 0; t < 6; t++) r[3 + t] = Pn[t];
+	};
+	if (ncand <= a.candcap) {
+		// Most queued pairs fail once the real denominator is known. Their exponent x = log(PD w q) travels with
+		// them as a float32: x - log(denom) < log(MinWeight) by more than the float32 rounding settles it; the
+		// others are compacted into a list so that the waves run the heavy path on full lanes.
+		__shared__ double ldenom[256];
+		__shared__ int    list[EMIT_LIST], s_nlist;
+		for (int k = tid; k < M; k += 256) ldenom[k] = log(denom[k]);
+		if (tid == 0) s_nlist = 0;
+		__syncthreads();
+		const double lminw = log(prm.minw);
+		for (int j0 = 0; j0 < ncand; j0 += 256) {
+			const int j = j0 + tid;
+			bool keep = false;
+			int  code = 0;
+			if (j < ncand) {
+				const int2 cd = cands[j];
+				code = cd.x;
+				const double x = (double) __int_as_float(cd.y);
+				keep = !(x - ldenom[code & 255] < lminw - 1e-3 - 1e-6 * fabs(x));
+			}
+			// (at most 256 new entries per trip: the list is drained whenever fewer than that are free)
+			if (keep) list[atomicAdd(&s_nlist, 1)] = code;
+			__syncthreads();
+			if (s_nlist > EMIT_LIST - 256 || j0 + 256 >= ncand) {
+				const int nl = s_nlist;
+				for (int i = tid; i < nl; i += 256) pair(list[i] >> 8, list[i] & 255);
+				__syncthreads();
+				if (tid == 0) s_nlist = 0;
+				__syncthreads();
+			}
+		}
 	}
+	else {
+		// the queue overflowed (more than a quarter of all pairs are candidates): every pair, gate included
+		for (int j = tid; j < np * M; j += 256) {
+			const int c = j / M, k = j - c * M;
+			double w, m[3], P[6], x[3];
+			load_predicted(prm, a, vin, p, n, c, w, m, P);
+			const double z[3] = {a.z[k * 3], a.z[k * 3 + 1], a.z[k * 3 + 2]};
+			measure_to_map(prm, pose, z, x);
+			const double e0 = x[0] - m[0], e1 = x[1] - m[1], e2 = x[2] - m[2];
+			if (e0 * e0 + e1 * e1 + e2 * e2 <= prm.g2_correct) pair(c, k);
+		}
+	}
+	__syncthreads();
 	if (tid == 0) {
-		if (overflow) atomicOr(a.flags, PHD_FLAG_EMIT_OVERFLOW);
-		a.emit_count[p] = nmis + npair;
+		if (nmis + s_npair > a.ecap) atomicOr(a.flags, PHD_FLAG_EMIT_OVERFLOW);
+		a.emit_count[p] = min(nmis + s_npair, a.ecap);
 	}
 }

@@ -64,16 +64,15 @@ struct StepBufs {
 	int*    flags;       // [1]
 	struct MurtyNodes* murty;   // [P] workspace of the big-cluster solver
 	double* jscratch;    // [P] landmark-indexed arrays of k_weight_alpha when the map estimate outgrows LDS
-	// per-component measurement quantities of the predicted mixture: 18 planes of [Pcap][cmcap]
+	// per-component measurement quantities of the predicted mixture: CM_PLANES planes of [Pcap][cmcap]
 	double* cm;
 	size_t  cmplane;     // doubles per plane = Pcap * cmcap
 	int     cmcap;       // cap + Mcap
-	// (component, measurement) pairs that reach MinWeight, queued for the Kalman update
-	int*    pair_ck;     // [P][ecap][2]
-	double* pair_w;      // [P][ecap]
-	int*    pair_count;  // [P]
-	int*    cand;        // [P][candcap] candidate pairs of k_correct's first sweep
+	// (component, measurement) pairs that may reach MinWeight, queued by k_correct for k_emit_finish
+	int*    cand;        // [P][candcap]
 	int     candcap;
+	int*    cand_count;  // [P] (above candcap: the queue overflowed)
+	double* denom;       // [P][Mcap] kappa + weightsum[z]
 	double* srec;        // [P][10][cutcap] k_prune_merge: the kept records in sorted order (mean, covariance, weight)
 	// map estimate handed from k_alpha_assoc to k_alpha_density
 	double* alm;         // [P][3][Jcap] landmark means
