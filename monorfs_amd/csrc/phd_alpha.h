@@ -104,6 +104,8 @@ struct MurtyNodes {       // per-particle workspace in HBM, touched only when su
 	unsigned char asg[MURTY_POOL][MURTY_NMAX];    // assignment (row -> column)
 	unsigned int  elim[MURTY_POOL][MURTY_NMAX];   // eliminated columns of every row, as a bit mask
 	unsigned int  forced[MURTY_POOL];             // forced rows; a forced edge is (row, asg[row])
+	double        profit[MURTY_NMAX * MURTY_NMAX];    // the cluster's matrix
+	double        reduced[MURTY_NMAX * MURTY_NMAX];   // and the copy a child node solves on
 };
 
 __device__ __forceinline__ double wave_min(double v)
@@ -187,7 +189,8 @@ __device__ __forceinline__ double wave_assignment_value(const double* profit, in
 	return total;
 }
 
-// LDS scratch of the Murty path
+// scratch of the Murty path: the two matrices in the particle's HBM workspace (such clusters are rare, LDS is
+// better spent on occupancy), the rest in LDS
 struct MurtyLds {
 	double* profit;    // [NMAX*NMAX]
 	double* reduced;   // [NMAX*NMAX]
@@ -198,7 +201,7 @@ struct MurtyLds {
 	int*    L;         // [NMAX]
 	int*    Z;         // [NMAX]
 };
-#define MURTY_LDS_DOUBLES (2 * MURTY_NMAX * MURTY_NMAX + MURTY_OUT + MURTY_POOL + (2 * MURTY_POOL + 2 * MURTY_NMAX + 1) / 2)
+#define MURTY_LDS_DOUBLES (MURTY_OUT + MURTY_POOL + (2 * MURTY_POOL + 2 * MURTY_NMAX + 1) / 2)
 
 // Enumerate the pairings of one cluster best-first and record their values into logcomp exactly as
 // the loop of SetLogLikelihood does (PHDNavigator.cs:501-509), including its read of the stale
@@ -378,7 +381,7 @@ __host__ __device__ inline AlphaLds alpha_lds(int MP, int ncap)
 	AlphaLds l;
 	l.zs   = 0;
 	l.red  = l.zs + 3 * MP;
-	l.lm   = l.red + 256 + EXPTAB_N;   // red[256], exp table[32]
+	l.lm   = l.red + 256;              // red[256]: reduction scratch, histogram of the select, exp table of the cluster sums
 	l.pick = l.lm + 3 * JL;
 	l.scr  = l.pick + JL / 2;
 	int ns = 2;
@@ -402,7 +405,7 @@ __host__ __device__ inline AlphaLds alpha_lds(int MP, int ncap)
 	l.p3_mem = l.p3_adjT + MP * (JL / 64);
 	l.p3_int = l.p3_mem + 2 * JL;
 	l.p3_x   = l.p3_int + (3 * JL + MP + 1) / 2;
-	int xs = 25 * 64 > MURTY_LDS_DOUBLES ? 25 * 64 : MURTY_LDS_DOUBLES;
+	int xs = 25 * 4 > MURTY_LDS_DOUBLES ? 25 * 4 : MURTY_LDS_DOUBLES;
 	int ph3 = l.p3_x + xs + 2 - l.scr;
 	int mx = ph1 > ph2 ? ph1 : ph2;
 	mx = mx > ph3 ? mx : ph3;
@@ -418,7 +421,7 @@ __host__ __device__ inline size_t alpha_jscratch_doubles(int Jcap)
 }
 
 template <int ZB>
-__global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const StepBufs a, int ncap)
+__global__ __launch_bounds__(256, 4) void k_alpha_assoc(const DevParams prm, const StepBufs a, int ncap)
 {
 	constexpr int MP = ZB * 64;
 	constexpr int MW = ZB;   // 64-bit adjacency words per landmark
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 	const AlphaLds lay = alpha_lds(MP, ncap);
 	double* zs   = smem + lay.zs;          // [MP][3] measurements
 	double* red  = smem + lay.red;         // [256] reduction scratch
-	double* etab = red + 256;              // [32] 2^(j/32)
+	double* etab = red;                    // [256] exp table (filled before the cluster sums, once `red` is idle)
 	__shared__ int s_J, s_changed, s_nroots, s_big;
 	__shared__ double s_ccount, s_total;
 
@@ -442,7 +445,6 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 	const PoseD pose = load_pose(bin.poses + (size_t) p * 7);
 
 	for (int k = tid; k < MP * 3; k += 256) zs[k] = (k < M * 3) ? a.z[k] : 0.0;
-	exp_tab_init(etab, tid);
 
 	PHD_STAMP_DECL;
 	PHD_STAMP(0);
@@ -661,7 +663,7 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 	unsigned long long* memL = (unsigned long long*) (inlds ? smem + lay.p3_mem : gj + 20 * (size_t) JS);        // [JS] its first 5 landmarks, 12-bit fields
 	unsigned long long* memZ = (unsigned long long*) (inlds ? smem + lay.p3_mem + JL : gj + 21 * (size_t) JS);   // [JS] its first 5 measurements
 	int* labz    = (int*) (smem + lay.p3_int) + 3 * JL;                  // [MP]
-	double* xreg = smem + lay.p3_x;                                      // mats [25][64]  |  Murty scratch
+	double* xreg = smem + lay.p3_x;                                      // mats [25][4]  |  Murty scratch
 	// When the largest weight minus one does not exceed the J-th largest weight no appended entry can be
 	// picked among the first J: the estimate is simply the J heaviest components, in order.
 	const bool straight = J <= no && (J == 0 || !(sortw[0] - 1 > sortw[J - 1]));
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 	PHD_STAMP(3);
 	// ---- phase 3: SetLogLikelihood (PHDNavigator.cs:462-515) on the matrix of SetLogLikeMatrix (:415-453)
 	{
-		double* mats = xreg;   // [25][64] one 5x5 matrix per lane (dead before the Murty path reuses the region)
+		double* mats = xreg;   // [25][4] one 5x5 matrix per cluster of a tiny map (dead before the Murty path reuses the region)
 
 		constexpr int JW = JL / 64;                                   // words of a transposed adjacency row (LDS case)
 		unsigned long long* adjT = (unsigned long long*) (smem + lay.p3_adjT);   // [MP][JW] landmarks gated with measurement k
@@ -815,6 +817,7 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 			}
 			if (lane == 0) s_nroots = nr;
 		}
+		exp_tab_init(etab, tid);
 		__syncthreads();
 		const int nroots = s_nroots;
 		const double logmult = prm.logRmult;
@@ -923,8 +926,8 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 						s_big = 1;
 					}
 					else {
-						double* mat = mats + lane;   // entry e at mat[e * 64]
-						for (int e = 0; e < 25; e++) mat[e * 64] = -INFINITY;
+						double* mat = mats + lane;   // entry e at mat[e * 4] (fewer than 5 landmarks: at most 4 clusters)
+						for (int e = 0; e < 25; e++) mat[e * 4] = -INFINITY;
 						for (int x = 0; x < nl; x++) {
 							int j = (int) ((Lp >> (12 * x)) & 4095);
 							for (int y = 0; y < nz; y++) {
@@ -932,16 +935,16 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 								if ((adj[(size_t) j * MW + (k >> 6)] >> (k & 63)) & 1ull) {
 									double dist = sqrt(quad_gen(prm.Rinv, zh[j] - zs[k * 3], zh[JS + j] - zs[k * 3 + 1],
 									                            zh[2 * JS + j] - zs[k * 3 + 2]));
-									mat[(x * 5 + y) * 64] = lpd[j] + logmult - 0.5 * dist * dist;   // :439
+									mat[(x * 5 + y) * 4] = lpd[j] + logmult - 0.5 * dist * dist;   // :439
 								}
 							}
-							mat[(x * 5 + nz + x) * 64] = lmd[j];   // :445
+							mat[(x * 5 + nz + x) * 4] = lmd[j];   // :445
 						}
 						for (int y = 0; y < nz; y++) {
-							mat[((nl + y) * 5 + y) * 64] = prm.logkappa;   // :449
-							for (int x = 0; x < nl; x++) mat[((nl + y) * 5 + nz + x) * 64] = 0;   // :480-488
+							mat[((nl + y) * 5 + y) * 4] = prm.logkappa;   // :449
+							for (int x = 0; x < nl; x++) mat[((nl + y) * 5 + nz + x) * 4] = 0;   // :480-488
 						}
-						res[ri] = cluster_enumerate(mat, 64, nrow, J);
+						res[ri] = cluster_enumerate(mat, 4, nrow, J);
 					}
 				}
 			}
@@ -954,10 +957,9 @@ __global__ __launch_bounds__(256) void k_alpha_assoc(const DevParams prm, const 
 			// shared logcomp array; the other waves wait.
 			if (wv == 0) {
 				MurtyLds ws;
-				double* big = xreg;
-				ws.profit  = big;
-				ws.reduced = ws.profit + MURTY_NMAX * MURTY_NMAX;
-				ws.logcomp = ws.reduced + MURTY_NMAX * MURTY_NMAX;
+				ws.profit  = a.murty[p].profit;
+				ws.reduced = a.murty[p].reduced;
+				ws.logcomp = xreg;
 				ws.fkey    = ws.logcomp + MURTY_OUT;
 				ws.fnode   = (int*) (ws.fkey + MURTY_POOL);
 				ws.freelist = ws.fnode + MURTY_POOL;

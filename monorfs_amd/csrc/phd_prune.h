@@ -31,7 +31,7 @@
 #define PRUNE_NB 2048   // buckets of the spatial hash
 
 struct PruneLds {
-	int rad2, sm, x, scan;   // offsets in doubles
+	int rad2, x, scan;       // offsets in doubles
 	int NS;                  // sort width (power of two >= 2 * cutcap)
 	int bytes;
 };
@@ -44,10 +44,9 @@ __host__ __device__ inline PruneLds prune_lds(int cutcap)
 	while (NS < 2 * cutcap) NS <<= 1;
 	l.NS    = NS;
 	l.rad2  = 0;
-	l.sm    = l.rad2 + cc;
-	l.x     = l.sm + 3 * cc;                 // sort words u64[NS]  |  the lists of the pair search (see `rest`)
-	// nbr u64[2*cc], cand float4[cc], owner int[cc], cellid int[cc], cstart int[NB+2], absb int[64]
-	int rest  = 2 * cc + 2 * cc + cc + (PRUNE_NB + 2) / 2 + 32 + 4;
+	l.x     = l.rad2 + cc;                   // sort words u64[NS]  |  the lists of the pair search (see `rest`)
+	// nbr u64[2*cc], cand float4[cc], owner int[cc], cstart int[NB+2], absb int[64]
+	int rest  = 2 * cc + 2 * cc + cc / 2 + (PRUNE_NB + 2) / 2 + 32 + 4;
 	l.scan  = l.x + (NS > rest ? NS : rest);
 	l.bytes = (l.scan + 136) * 8;            // int[264] | double[28], + spare
 	return l;
@@ -174,13 +173,11 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	const PruneLds lay = prune_lds(cutcap);
 	const int cc = (cutcap + 1) & ~1, NS = lay.NS;
 	double* rad2  = smem + lay.rad2;                       // [cut] squared Euclidean bound of row i (inf: none)
-	double* sm    = smem + lay.sm;                         // [3][cc] sorted means
 	unsigned long long* sv = (unsigned long long*) (smem + lay.x);     // [NS] sort words
 	unsigned long long* nbr = (unsigned long long*) (smem + lay.x);    // [cut][2]: count + up to 7 close later rows
 	float4* cand  = (float4*) (nbr + 2 * cc);              // [cut] rows grouped by bucket: mean relative to the box (float32), row
-	int*    owner = (int*) (cand + cc);                    // [cut] row that absorbed k (-1: none)
-	int*    cellid = owner + cc;                           // [cut] packed grid cell of row r
-	int*    cstart = cellid + cc;                          // [NB + 2] bucket b is [cstart[b], cstart[b + 1])
+	int*    owner = (int*) (cand + cc);                    // [cut] row that absorbed k (-1: none); the row's bucket while the grid is built
+	int*    cstart = owner + cc;                          // [NB + 2] bucket b is [cstart[b], cstart[b + 1])
 	int*    absb  = cstart + PRUNE_NB + 2;                 // [64] absorbed bits as left by the resolving wave
 	int*    scan  = (int*) (smem + lay.scan);              // [264]
 	double* bred  = smem + lay.scan;                       // [28] block reduction scratch (before `scan` is used)
@@ -238,7 +235,8 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 		}
 	}
 	PHD_STAMP(1);
-	// ---- the kept records, gathered once into sorted order (HBM, plane per field); means and bounds to LDS.
+	// ---- the kept records, gathered once into sorted order (HBM, plane per field; every later read of a row's own
+	// record is coalesced); the Euclidean bounds go to LDS.
 	// A pair can only be close when |m_i - m_k|^2 <= T^2 trace(P_i) (d^T P_i^-1 d >= |d|^2 / lambda_max(P_i) >=
 	// |d|^2 / trace(P_i) for a positive definite P_i).
 	double lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY, rmx = 0;
@@ -252,7 +250,6 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 #pragma unroll
 		for (int t = 0; t < 9; t++) srec[(size_t) t * cutcap + r] = v[t];
 		srec[(size_t) 9 * cutcap + r] = w;
-		sm[r] = v[0]; sm[cc + r] = v[1]; sm[2 * cc + r] = v[2];
 		const double P0 = v[3], P1 = v[4], P2 = v[5], P3 = v[6], P4 = v[7], P5 = v[8];
 		double det = P0 * (P3 * P5 - P4 * P4) - P1 * (P1 * P5 - P4 * P2) + P2 * (P1 * P4 - P3 * P2);
 		bool pd = P0 > 0 && (P0 * P3 - P1 * P1) > 0 && det > 0;   // Sylvester
@@ -300,10 +297,10 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 		__syncthreads();
 		// counting sort of the rows by bucket
 		for (int r = tid; r < cut; r += 256) {
-			int cx = (int) ((sm[r] - mn0) * icell), cy = (int) ((sm[cc + r] - mn1) * icell), cz = (int) ((sm[2 * cc + r] - mn2) * icell);
-			cellid[r] = (cx << 16) | (cy << 8) | cz;
-			atomicAdd(&cstart[bucket(cx, cy, cz)], 1);
-			owner[r] = -1;
+			const double s0 = srec[r] - mn0, s1 = srec[(size_t) cutcap + r] - mn1, s2 = srec[(size_t) 2 * cutcap + r] - mn2;
+			const int b = bucket((int) (s0 * icell), (int) (s1 * icell), (int) (s2 * icell));
+			owner[r] = b;
+			atomicAdd(&cstart[b], 1);
 		}
 		__syncthreads();
 		{   // inclusive prefix over the PRUNE_NB bucket counts: cstart[b] = end of bucket b; the fill below counts it down to its start
@@ -327,10 +324,10 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 		}
 		__syncthreads();
 		for (int r = tid; r < cut; r += 256) {
-			int id = cellid[r];
-			int b = bucket(id >> 16, (id >> 8) & 255, id & 255);
-			int pos = atomicSub(&cstart[b], 1) - 1;
-			cand[pos] = make_float4((float) (sm[r] - mn0), (float) (sm[cc + r] - mn1), (float) (sm[2 * cc + r] - mn2), __int_as_float(r));
+			const double s0 = srec[r] - mn0, s1 = srec[(size_t) cutcap + r] - mn1, s2 = srec[(size_t) 2 * cutcap + r] - mn2;
+			const int pos = atomicSub(&cstart[owner[r]], 1) - 1;
+			cand[pos] = make_float4((float) s0, (float) s1, (float) s2, __int_as_float(r));
+			owner[r] = -1;
 		}
 		__syncthreads();
 		PHD_STAMP(7);
@@ -340,7 +337,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 #pragma unroll
 			for (int t = 0; t < 6; t++) P[t] = srec[(size_t) (3 + t) * cutcap + i];
 			inv_sym3(P, Pi, det);
-			const double m0 = sm[i], m1 = sm[cc + i], m2 = sm[2 * cc + i], bound = rad2[i];
+			const double m0 = srec[i], m1 = srec[(size_t) cutcap + i], m2 = srec[(size_t) 2 * cutcap + i], bound = rad2[i];
 			int cnt = 0;
 #ifdef PHD_STAMP_COUNTERS
 			int dbg_walk = 0, dbg_test = 0;
@@ -349,7 +346,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 #pragma unroll
 			for (int q = 0; q < PRUNE_NBR; q++) e[q] = 0xffffu;
 			auto test = [&](int k) {
-				double d0 = m0 - sm[k], d1 = m1 - sm[cc + k], d2 = m2 - sm[2 * cc + k];
+				double d0 = m0 - srec[k], d1 = m1 - srec[(size_t) cutcap + k], d2 = m2 - srec[(size_t) 2 * cutcap + k];
 				double sq = d0 * d0 + d1 * d1 + d2 * d2;
 				if (sq <= bound && quad_sym(Pi, d0, d1, d2) < prm.merge_thr2) {   // Gaussian.SquareMahalanobis(b.Mean) < threshold^2
 					// keep the 7 smallest row numbers, ascending (insertion through a fixed network)
@@ -513,11 +510,11 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 #pragma unroll
 					for (int t = 0; t < 6; t++) P[t] = srec[(size_t) (3 + t) * cutcap + i];
 					inv_sym3(P, Pi, det);
-					double m0 = sm[i], m1 = sm[cc + i], m2 = sm[2 * cc + i];
+					double m0 = srec[i], m1 = srec[(size_t) cutcap + i], m2 = srec[(size_t) 2 * cutcap + i];
 					for (int s = i >> 6; s < nslots; s++) {
 						int k = s * 64 + lane;
 						if (k > i && k < cut && !((absorbed >> s) & 1u)) {
-							if (quad_sym(Pi, m0 - sm[k], m1 - sm[cc + k], m2 - sm[2 * cc + k]) < prm.merge_thr2) {
+							if (quad_sym(Pi, m0 - srec[k], m1 - srec[(size_t) cutcap + k], m2 - srec[(size_t) 2 * cutcap + k]) < prm.merge_thr2) {
 								absorbed |= 1u << s;
 								owner[k] = i;
 							}
