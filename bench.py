@@ -164,6 +164,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernels = nav.last_timings()
+    launches = nav.last_timing_counts() if kernels else {}
 
     if rank == 0:
         units = P * world * Cc * M * args.steps
@@ -178,8 +179,12 @@ def main():
                           "particles_per_gpu": P, "components": Cc, "measurements": M, "max_quantity": maxq,
                           "parallelism": "particles sharded x%d" % world}}
         if kernels:
-            dom = max(kernels, key=kernels.get)
-            alg_bytes = 160.0 * P * Cc          # 80 B/component read + 80 B written, per particle
+            # the step's per-particle kernels run once per particle sub-range (phd_set_split): a kernel's cost per
+            # step is its mean launch duration x launches per step, and the dominant kernel is the largest of those
+            per_step = {k: launches[k] / args.steps for k in kernels}
+            dom = max(kernels, key=lambda k: kernels[k] * per_step[k])
+            particles_per_launch = P / per_step[dom]
+            alg_bytes = 160.0 * particles_per_launch * Cc   # 80 B/component read + 80 B written, per particle
             achieved = alg_bytes / (kernels[dom] * 1e-3) / 1e9
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
@@ -190,8 +195,10 @@ def main():
                     traffic = None
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernels[dom]}
+                               "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernels[dom],
+                               "particles_per_launch": particles_per_launch, "launches_per_step": per_step[dom]}
             out["kernel_ms"] = kernels
+            out["kernel_launches_per_step"] = per_step
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 16)
             sample = args.cpu_sample or P

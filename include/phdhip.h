@@ -209,6 +209,9 @@ int   phd_set_stream(phd_navigator* nav, void* stream, uint8_t lend);
  * returns the number of entries. phd_timing_reset(nav, 0) switches the events off.               */
 int phd_timing_reset(phd_navigator* nav, uint8_t enabled);
 int phd_last_timings(phd_navigator* nav, const char*** names, const double** ms);
+/* Launches behind each mean of the last phd_last_timings call, same order (a split step launches a kernel
+ * once per particle sub-range).                                                                  */
+int phd_last_timing_counts(phd_navigator* nav, const int** counts);
 
 /* Bulk upload / download of the whole particle set in the device layout (benchmark and tests):
  * planes[10][nparticles][stride] = w, mean x y z, covariance xx xy xz yy yz zz; counts[nparticles];

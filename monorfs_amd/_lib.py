@@ -78,6 +78,7 @@ def load():
         "phd_set_stream": (C.c_int, [P, C.c_void_p, C.c_uint8]),
         "phd_timing_reset": (C.c_int, [P, C.c_uint8]),
         "phd_last_timings": (C.c_int, [P, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(dp)]),
+        "phd_last_timing_counts": (C.c_int, [P, C.POINTER(C.POINTER(C.c_int))]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)   # raises AttributeError if the library does not export a declared symbol
@@ -92,5 +93,5 @@ EXPORTS = ["phd_api_version", "phd_default_params", "phd_create", "phd_create_er
            "phd_stage_setloglik", "phd_resample", "phd_particle_depleted", "phd_step_local_async",
            "phd_device_local_weights", "phd_device_global_weights", "phd_step_global_async", "phd_migration_plan",
            "phd_plan_migration", "phd_migration_send_buffer", "phd_migration_recv_buffer", "phd_migration_pack_async",
-           "phd_migration_unpack_async", "phd_stream", "phd_set_stream", "phd_timing_reset", "phd_last_timings", "phd_upload_state_soa",
+           "phd_migration_unpack_async", "phd_stream", "phd_set_stream", "phd_timing_reset", "phd_last_timings", "phd_last_timing_counts", "phd_upload_state_soa",
            "phd_download_state_soa"]

@@ -955,6 +955,13 @@ int phd_last_timings(phd_navigator* nav, const char*** names, const double** ms)
 	return (int) nav->tnames.size();
 }
 
+int phd_last_timing_counts(phd_navigator* nav, const int** counts)
+{
+	if (!nav) return 0;
+	if (counts) *counts = nav->tcounts.data();
+	return (int) nav->tcounts.size();
+}
+
 // ---- multi-GPU ----------------------------------------------------------------------------------
 // Particles are sharded contiguously: rank r owns global slots [r * P, (r + 1) * P). One step is
 //   phd_step_local_async                      predict / correct / prune / reweight of the shard

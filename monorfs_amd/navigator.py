@@ -250,3 +250,12 @@ class PHDNavigator:
         ms = dp()
         n = self._lib.phd_last_timings(self._h, C.byref(names), C.byref(ms))
         return {names[i].decode(): ms[i] for i in range(n)}
+
+    def last_timing_counts(self):
+        """launches behind each mean of the last last_timings() call (a split step launches each kernel per sub-range)"""
+        names = C.POINTER(C.c_char_p)()
+        ms = dp()
+        n = self._lib.phd_last_timings(self._h, C.byref(names), C.byref(ms))
+        cnt = C.POINTER(C.c_int)()
+        self._lib.phd_last_timing_counts(self._h, C.byref(cnt))
+        return {names[i].decode(): cnt[i] for i in range(n)}

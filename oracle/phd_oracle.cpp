@@ -1409,4 +1409,32 @@ int orc_max_threads(void)
 #endif
 }
 
+// OSPA distance between two landmark sets (postanalysis/Plot.cs:531-581; LandmarkDistance :583-586), the acceptance
+// metric of SURVEY 8d (C = 1, P = 1 there). The transport problem is solved on C^P - d^P (entries below 1e-5 are left
+// at the sparse matrix's default 0, :562), maximised by the same Hungarian as the association step (:573), then mapped
+// back with x -> C^P - x, default included (:575; SparseMatrix.Apply, SparseMatrix.cs:526-542).
+double orc_ospa(const double* a3, int na, const double* b3, int nb, double C, double P, double* cardinality)
+{
+	if (na > nb) { std::swap(a3, b3); std::swap(na, nb); }
+	if (na == 0) {
+		double c = (nb == 0) ? 0 : C;
+		if (cardinality) *cardinality = c;
+		return c;
+	}
+	const double CP = std::pow(C, P);
+	Dense t; t.n = nb; t.v.assign((size_t) nb * nb, 0.0);
+	for (int i = 0; i < na; i++) {
+		for (int k = 0; k < nb; k++) {
+			double d0 = a3[i * 3] - b3[k * 3], d1 = a3[i * 3 + 1] - b3[k * 3 + 1], d2 = a3[i * 3 + 2] - b3[k * 3 + 2];
+			double dist = std::pow(std::min(C, std::sqrt(d0 * d0 + d1 * d1 + d2 * d2)), P);
+			if (CP - dist > 1e-5) t.v[(size_t) i * nb + k] = CP - dist;
+		}
+	}
+	std::vector<int> best;
+	hungarian(t, best);
+	for (double& x : t.v) x = CP - x;
+	if (cardinality) *cardinality = C * std::pow((double) (nb - na) / nb, 1.0 / P);
+	return std::pow(assignment_value(t, best) / nb, 1.0 / P);
+}
+
 }  // extern "C"

@@ -137,6 +137,18 @@ def hungarian(mat):
     return out.tolist() if ok else None
 
 
+def ospa(a, b, cutoff=1.0, order=1.0):
+    """Plot.OSPA (postanalysis/Plot.cs:531-581): (distance, cardinality part) between two sets of 3-D landmarks;
+    cutoff = C, order = P (1 and 1 in SURVEY 8d)."""
+    a, ap = _d(np.asarray(a, float).reshape(-1, 3))
+    b, bp = _d(np.asarray(b, float).reshape(-1, 3))
+    lib.orc_ospa.restype = C.c_double
+    lib.orc_ospa.argtypes = [dp, C.c_int, dp, C.c_int, C.c_double, C.c_double, dp]
+    card, cp = _d(np.zeros(1))
+    d = lib.orc_ospa(ap, len(a), bp, len(b), float(cutoff), float(order), cp)
+    return d, card[0]
+
+
 def assignment_value(mat, matches):
     m, mp = _d(mat)
     a, ap = _i(matches)

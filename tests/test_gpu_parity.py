@@ -155,6 +155,12 @@ def test_slam_update_sequence(nav_mod, P, C, M, seed):
         assert close(nav.poses(), st.poses, 1e-15)
         for i in (0, P // 2, P - 1):
             assert_mix_close(nav.MapModel(i), st.map(i), 1e-7, "step %d map[%d]" % (step, i))
+        # the acceptance metric of SURVEY 8d: OSPA (C = 1, P = 1; Plot.cs:531-581) between the best particle's map
+        # estimate on the device and in the oracle stays within 1e-4
+        glm, _ = orc.best_map_estimate(nav.MapModel(nav.BestParticle))
+        olm, _ = orc.best_map_estimate(st.map(best))
+        d, card = orc.ospa(glm, olm)
+        assert card == 0 and d < 1e-4, "step %d: OSPA %g (cardinality part %g)" % (step, d, card)
         nres += res
     assert nres > 0, "the sequence never resampled: the gather path was not exercised"
     nav.close()

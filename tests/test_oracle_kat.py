@@ -212,3 +212,31 @@ def test_fuzzy_visibility_ramp():
     assert orc.detection_probability(p, pose, edge) == 0.0
     half = orc.measure_to_map(p, pose, np.array([-320 + 1.5 * np.sqrt(2.0), 0.0, 1.0]))
     assert abs(orc.detection_probability(p, pose, half) - 0.45) < 1e-9
+
+
+def test_ospa_hand_cases():
+    """Plot.OSPA (postanalysis/Plot.cs:531-581) on cases small enough to do by hand (C = 1, P = 1 unless stated)."""
+    a = np.array([[0, 0, 0], [1, 0, 0], [0, 2, 0]], float)
+    # identical sets, any order: distance 0, no cardinality error
+    d, card = orc.ospa(a, a[[2, 0, 1]])
+    assert d == 0 and card == 0
+    # both empty / one empty (:539-542)
+    assert orc.ospa(np.zeros((0, 3)), np.zeros((0, 3))) == (0, 0)
+    assert orc.ospa(np.zeros((0, 3)), a) == (1, 1)
+    # one landmark moved by 0.25, one missing: (0 + 0.25 + C) / 3, cardinality part C * (1/3)
+    b = np.array([[0, 0, 0], [1.25, 0, 0]], float)
+    d, card = orc.ospa(a, b)
+    assert np.isclose(d, (0.25 + 1.0) / 3, atol=1e-12) and np.isclose(card, 1.0 / 3, atol=1e-12)
+    # distances are cut at C (LandmarkDistance, :583-586): a far landmark costs C, not its distance
+    d, _ = orc.ospa(a, a + np.array([[0, 0, 0], [0, 0, 0], [50, 0, 0]]))
+    assert np.isclose(d, 1.0 / 3, atol=1e-12)
+    # the assignment is the optimal one, not the index order: a permuted and slightly shifted copy
+    rng = np.random.default_rng(7)
+    x = rng.uniform(-3, 3, (9, 3))
+    y = (x + rng.normal(0, 0.01, x.shape))[rng.permutation(9)]
+    d, card = orc.ospa(x, y)
+    best = np.linalg.norm(x[:, None] - y[None], axis=2).min(1).mean()
+    assert card == 0 and np.isclose(d, best, atol=1e-12)
+    # order 2 and a different cutoff: root mean square of the cut distances
+    d, card = orc.ospa(a, b, cutoff=2.0, order=2.0)
+    assert np.isclose(d, np.sqrt((0.25 ** 2 + 2.0 ** 2) / 3), atol=1e-12) and np.isclose(card, 2.0 * np.sqrt(1 / 3), atol=1e-12)
