@@ -43,6 +43,7 @@ public class PhdHipLib
 	[DllImport(Lib)] public extern static IntPtr phd_last_error(HandleRef nav);
 	[DllImport(Lib)] public extern static int    phd_reset(HandleRef nav, int nparticles, IntPtr pose7, IntPtr w, IntPtr mean3, IntPtr cov9, int ncomp);
 	[DllImport(Lib)] public extern static int    phd_set_poses(HandleRef nav, IntPtr poses7, int nparticles);
+	[DllImport(Lib)] public extern static int    phd_update_motion(HandleRef nav, IntPtr odometry6, IntPtr noise6, int nparticles, [MarshalAs(UnmanagedType.U1)] bool perfectstill);
 	[DllImport(Lib)] public extern static int    phd_slam_update(HandleRef nav, IntPtr z3, int nmeasurements, [MarshalAs(UnmanagedType.U1)] bool onlymapping, double uresample);
 	[DllImport(Lib)] public extern static IntPtr phd_weights(HandleRef nav, out int length);
 	[DllImport(Lib)] public extern static int    phd_best_particle(HandleRef nav);
@@ -146,6 +147,23 @@ public unsafe class HipPHDNavigator : Navigator<PRM3DMeasurer, Pose3D, PixelRang
 		double[] poses = new double[7 * VehicleParticles.Length];
 		for (int i = 0; i < VehicleParticles.Length; i++) { VehicleParticles[i].Pose.State.CopyTo(poses, 7 * i); }
 		fixed (double* pp = poses) { Check(PhdHipLib.phd_set_poses(nav, (IntPtr) pp, VehicleParticles.Length)); }
+		UpdateTrajectory(time);
+	}
+
+	/// <summary>Alternative to Update with the motion step on the device (phd_update_motion): only the reading and the
+	/// noise vectors drawn here cross the boundary; the managed particles are refreshed from phd_poses when needed.</summary>
+	public void UpdateOnDevice(GameTime time, double[] reading)
+	{
+		int      n     = VehicleParticles.Length;
+		double[] noise = new double[6 * n];
+		double   dt    = time.ElapsedGameTime.TotalSeconds;
+		for (int i = 0; i < n; i++) {
+			double[] v = dt.Multiply(Util.RandomGaussianVector(new double[6], VehicleParticles[i].MotionCovariance));   // TrackVehicle.cs:95-97
+			v.CopyTo(noise, 6 * i);
+		}
+		fixed (double* pr = reading) fixed (double* pn = noise) {
+			Check(PhdHipLib.phd_update_motion(nav, (IntPtr) pr, OnlyMapping ? IntPtr.Zero : (IntPtr) pn, n, SimulatedVehicle<PRM3DMeasurer, Pose3D, PixelRangeMeasurement>.PerfectStill));
+		}
 		UpdateTrajectory(time);
 	}
 

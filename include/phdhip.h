@@ -113,6 +113,13 @@ int phd_reset(phd_navigator* nav, int nparticles, const double* pose7,
 /* The host keeps the motion model and its RNG (TrackVehicle.UpdateNoisy, TrackVehicle.cs:89-102):
  * after Navigator.Update (PHDNavigator.cs:295-314) it hands the particle poses over.             */
 int phd_set_poses(phd_navigator* nav, const double* poses7, int nparticles);
+/* SURVEY row f1 (next to the path): the particle motion step itself on the device. TrackVehicle.UpdateNoisy
+ * (TrackVehicle.cs:89-102) = Pose3D.AddOdometry (Pose3D.cs:314-333) of the reading (dx dy dz dpitch dyaw droll),
+ * then of the particle's own noise vector noise6[i*6..] = dt * chol(MotionCovariance) * N(0, I) drawn by the host
+ * (Util.cs:173-202; NULL: none). perfect_still: a zero reading skips the noise (SimulatedVehicle.cs:190-202).
+ * Replaces the per-frame phd_set_poses upload.                                                   */
+int phd_update_motion(phd_navigator* nav, const double* odometry6, const double* noise6, int nparticles,
+                      uint8_t perfect_still);
 /* Test/bench access to the public arrays VehicleWeights / MapModels (PHDNavigator.cs:128,134).   */
 int phd_set_weights(phd_navigator* nav, const double* weights, int nparticles);
 int phd_set_map(phd_navigator* nav, int particle, const double* w, const double* mean3,

@@ -141,6 +141,60 @@ __global__ __launch_bounds__(256) void k_gather_rotate(const StepBufs a, const i
 	if (tid < 7) a.bank[T].poses[(size_t) i * 7 + tid] = a.bank[O].poses[(size_t) s * 7 + tid];
 }
 
+// Particle motion: TrackVehicle.UpdateNoisy (TrackVehicle.cs:89-102) = Pose3D.AddOdometry
+// (Pose3D.cs:314-333) of the odometry reading, then of the particle's own noise vector (drawn by the host).
+struct Quat4 { double w, x, y, z; };
+
+__device__ __forceinline__ Quat4 quat_mul(const Quat4& a, const Quat4& b)   // Quaternion.cs:295-301
+{
+	return Quat4{a.w * b.w - (a.x * b.x + a.y * b.y + a.z * b.z),
+	             a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+	             a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+	             a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
+}
+
+__device__ inline void add_odometry(double s[7], const double* d)
+{
+	const Quat4 q{s[3], s[4], s[5], s[6]};
+	const double l0 = 0.5 * d[3], l1 = 0.5 * d[4], l2 = 0.5 * d[5];   // FromLinear, Quaternion.cs:145-149
+	const double phi = sqrt(l0 * l0 + l1 * l1 + l2 * l2);
+	Quat4 dq{1, 0, 0, 0};                                              // Exp, :185-196
+	if (!(phi < 1e-12)) {
+		const double sn = sin(phi);
+		dq = Quat4{cos(phi), sn * (l0 / phi), sn * (l1 / phi), sn * (l2 / phi)};
+	}
+	const Quat4 nq = quat_mul(q, dq);
+	Quat4 mid{1, 0, 0, 0};                                             // Sqrt, :225-235
+	if (!(fabs(dq.w - -1.0) < 1e-8)) {
+		const double rw = sqrt(0.5 * (1 + dq.w)), alpha = 1 / (2 * rw);
+		mid = Quat4{rw, alpha * dq.x, alpha * dq.y, alpha * dq.z};
+	}
+	const Quat4 mr = quat_mul(q, mid);
+	const Quat4 dl = quat_mul(quat_mul(mr, Quat4{0, d[0], d[1], d[2]}), Quat4{mr.w, -mr.x, -mr.y, -mr.z});
+	const double alpha = 1 / sqrt(nq.w * nq.w + nq.x * nq.x + nq.y * nq.y + nq.z * nq.z);   // Normalize, :240-245
+	s[0] += dl.x; s[1] += dl.y; s[2] += dl.z;
+	s[3] = alpha * nq.w; s[4] = alpha * nq.x; s[5] = alpha * nq.y; s[6] = alpha * nq.z;
+}
+
+__global__ __launch_bounds__(256) void k_motion(double* poses, int P, const double* odometry, const double* noise, int use_noise)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	if (i >= P) return;
+	double s[7], d[6];
+#pragma unroll
+	for (int t = 0; t < 7; t++) s[t] = poses[(size_t) i * 7 + t];
+#pragma unroll
+	for (int t = 0; t < 6; t++) d[t] = odometry[t];
+	add_odometry(s, d);
+	if (use_noise) {
+#pragma unroll
+		for (int t = 0; t < 6; t++) d[t] = noise[(size_t) i * 6 + t];
+		add_odometry(s, d);
+	}
+#pragma unroll
+	for (int t = 0; t < 7; t++) poses[(size_t) i * 7 + t] = s[t];
+}
+
 // replicate particle 0 of the IN bank over `P` particles of the OUT bank (PHDNavigator.reset, :256-263)
 __global__ __launch_bounds__(256) void k_replicate(const StepBufs a, double weight)
 {

@@ -57,6 +57,7 @@ struct phd_navigator {
 	double* d_alm = nullptr; int* d_aJ = nullptr; double* d_account = nullptr;
 	double* d_stamps = nullptr;
 	double* d_srec = nullptr;
+	double* d_motion = nullptr;   // odometry[6] + noise[P][6] of phd_update_motion
 	double* d_gw = nullptr; int gwcap = 0;           // gathered weights of all ranks
 	double* d_stage = nullptr;                       // staging for uploads
 	// migration (multi-GPU resampling)
@@ -505,7 +506,7 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_sel); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
-	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cm); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
+	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_motion); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cm); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
 	if (nav->own_stream) hipStreamDestroy(nav->own_stream);
 	for (int i = 0; i < phd_navigator::MAXSPLIT - 1; i++) {
@@ -554,6 +555,27 @@ int phd_set_poses(phd_navigator* nav, const double* poses7, int nparticles)
 	hipSetDevice(nav->device);
 	HC(hipMemcpyAsync(nav->bank[cur_bank(nav)].poses, poses7, (size_t) nparticles * 7 * 8, hipMemcpyHostToDevice, nav->stream));
 	HC(hipStreamSynchronize(nav->stream));
+	return PHD_OK;
+}
+
+// TrackVehicle.UpdateNoisy for every particle, on the device: the host passes the odometry reading
+// and, per particle, the noise vector it drew (RNG and Cholesky factor stay managed); no pose array crosses PCIe.
+int phd_update_motion(phd_navigator* nav, const double* odometry6, const double* noise6, int nparticles, uint8_t perfect_still)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (!odometry6 || nparticles != nav->P) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_update_motion: particle count mismatch");
+	hipSetDevice(nav->device);
+	bool zero = true;
+	for (int t = 0; t < 6; t++) zero = zero && odometry6[t] == 0;
+	const int use_noise = noise6 && !(perfect_still && zero);   // "static friction makes the robot stay put", TrackVehicle.cs:93-94
+	if (!nav->d_motion) HC(hipMalloc((void**) &nav->d_motion, ((size_t) nav->Pcap * 6 + 6) * 8));
+	HC(hipMemcpyAsync(nav->d_motion, odometry6, 6 * 8, hipMemcpyHostToDevice, nav->stream));
+	if (use_noise) HC(hipMemcpyAsync(nav->d_motion + 6, noise6, (size_t) nparticles * 6 * 8, hipMemcpyHostToDevice, nav->stream));
+	hipLaunchKernelGGL(k_motion, dim3((nparticles + 255) / 256), dim3(256), 0, nav->stream, nav->bank[cur_bank(nav)].poses, nparticles,
+	                   (const double*) nav->d_motion, (const double*) (nav->d_motion + 6), use_noise);
+	HC(hipGetLastError());
+	HC(hipStreamSynchronize(nav->stream));   // the caller's buffers are free again
+	nav->stage_valid = false;
 	return PHD_OK;
 }
 

@@ -64,6 +64,13 @@ public:
 		check(phd_set_poses(nav_, particleposes.empty() ? nullptr : particleposes[0].data(), (int) particleposes.size()));
 	}
 
+	// The same step with the motion model on the device (phd_update_motion): the odometry reading and
+	// one noise vector per particle (dt * chol(MotionCovariance) * N(0, I), drawn by the host; empty: none)
+	void UpdateOdometry(const std::array<double, 6>& reading, const std::vector<std::array<double, 6>>& noise, bool perfectstill)
+	{
+		check(phd_update_motion(nav_, reading.data(), noise.empty() ? nullptr : noise[0].data(), ParticleCount, perfectstill ? 1 : 0));
+	}
+
 	// ≙ SlamUpdate (:323-362); `uniform` replaces (double) Util.Uniform.Next() of ResampleParticles (:727)
 	void SlamUpdate(const std::vector<PixelRangeMeasurement>& measurements, double uniform)
 	{

@@ -137,6 +137,18 @@ class PHDNavigator:
         (TrackVehicle.UpdateNoisy): the caller hands over the propagated particle poses."""
         self.set_poses(poses)
 
+    def UpdateOdometry(self, time, reading, noise=None, perfect_still=False):
+        """≙ PHDNavigator.Update (:295-314) with the motion step on the device (phd_update_motion):
+        `reading` is the odometry (dx dy dz dpitch dyaw droll), `noise` the per-particle vectors
+        dt * chol(MotionCovariance) * N(0, I) the host drew (TrackVehicle.UpdateNoisy, TrackVehicle.cs:89-102)."""
+        reading = np.ascontiguousarray(reading, np.float64).reshape(6)
+        if noise is not None:
+            noise = np.ascontiguousarray(noise, np.float64).reshape(-1, 6)
+            if len(noise) != self.particle_count:
+                raise ValueError("one noise vector per particle")
+        self._check(self._lib.phd_update_motion(self._h, _ptr(reading), _ptr(noise) if noise is not None else None,
+                                                self.particle_count, int(bool(perfect_still))))
+
     def SlamUpdate(self, time, measurements, u_resample=0.5):
         """≙ PHDNavigator.SlamUpdate (:323-362)."""
         z = np.ascontiguousarray(measurements, np.float64).reshape(-1, 3)

@@ -1409,6 +1409,83 @@ int orc_max_threads(void)
 #endif
 }
 
+// ---- particle motion -------------------------------------------------------------
+// Quaternion.Exp (Quaternion.cs:185-196), Sqrt (:225-235), Normalize (:240-245), Log / ToLinear (:135-139, :203-217)
+static Quat qexp(const double* lie)
+{
+	double phi = std::sqrt(lie[0] * lie[0] + lie[1] * lie[1] + lie[2] * lie[2]);
+	if (phi < 1e-12) return Quat{1, 0, 0, 0};
+	double s = std::sin(phi);
+	return Quat{std::cos(phi), s * (lie[0] / phi), s * (lie[1] / phi), s * (lie[2] / phi)};
+}
+
+static Quat qsqrt(const Quat& q)
+{
+	if (std::fabs(q.w - -1.0) < 1e-8) return Quat{1, 0, 0, 0};
+	double rw = std::sqrt(0.5 * (1 + q.w)), alpha = 1 / (2 * rw);
+	return Quat{rw, alpha * q.x, alpha * q.y, alpha * q.z};
+}
+
+static Quat qnormalize(const Quat& q)
+{
+	double alpha = 1 / std::sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+	return Quat{alpha * q.w, alpha * q.x, alpha * q.y, alpha * q.z};
+}
+
+// Pose3D.AddOdometry (Pose3D.cs:314-333): state in, state out (x y z qw qx qy qz). The orientation of the input
+// is used as stored (the reference's Pose3D(location, orientation) constructor does not normalise, :169-176).
+void orc_add_odometry(const double* pose7, const double* delta6, double* out7)
+{
+	const Quat q{pose7[3], pose7[4], pose7[5], pose7[6]};
+	const double half[3] = {0.5 * delta6[3], 0.5 * delta6[4], 0.5 * delta6[5]};   // FromLinear, Quaternion.cs:145-149
+	Quat dorientation   = qexp(half);
+	Quat neworientation = qmul(q, dorientation);
+	Quat middelta       = qsqrt(dorientation);
+	Quat midrotation    = qmul(q, middelta);
+	Quat dl = qmul(qmul(midrotation, Quat{0, delta6[0], delta6[1], delta6[2]}), qconj(midrotation));
+	Quat o  = qnormalize(neworientation);
+	out7[0] = pose7[0] + dl.x; out7[1] = pose7[1] + dl.y; out7[2] = pose7[2] + dl.z;
+	out7[3] = o.w; out7[4] = o.x; out7[5] = o.y; out7[6] = o.z;
+}
+
+// Pose3D.DiffOdometry (Pose3D.cs:338-356): the delta that takes `origin` to `pose`
+void orc_diff_odometry(const double* pose7, const double* origin7, double* delta6)
+{
+	const Quat qa{pose7[3], pose7[4], pose7[5], pose7[6]}, qo{origin7[3], origin7[4], origin7[5], origin7[6]};
+	Quat dq = qmul(qconj(qo), qa);
+	Quat mid = qmul(qo, qsqrt(dq));
+	Quat dx = qmul(qmul(qconj(mid), Quat{0, pose7[0] - origin7[0], pose7[1] - origin7[1], pose7[2] - origin7[2]}), mid);
+	Quat n = qnormalize(dq);                                      // Log normalises first, :205
+	double phi = std::acos(n.w), mag = std::sqrt(n.x * n.x + n.y * n.y + n.z * n.z);
+	double lie[3] = {0, 0, 0};
+	if (!(mag < 1e-12)) { lie[0] = phi * (n.x / mag); lie[1] = phi * (n.y / mag); lie[2] = phi * (n.z / mag); }
+	delta6[0] = dx.x; delta6[1] = dx.y; delta6[2] = dx.z;
+	delta6[3] = 2 * lie[0]; delta6[4] = 2 * lie[1]; delta6[5] = 2 * lie[2];   // ToLinear = 2 Log, :135-139
+}
+
+// Quaternion.CreateFromYawPitchRoll (Quaternion.cs:254-273), for the fixtures of Pose3DTest
+void orc_quaternion_ypr(double yaw, double pitch, double roll, double* q4)
+{
+	double y2 = 0.5 * yaw, p2 = 0.5 * pitch, r2 = 0.5 * roll;
+	double sy = std::sin(y2), cy = std::cos(y2), sp = std::sin(p2), cp = std::cos(p2), sr = std::sin(r2), cr = std::cos(r2);
+	q4[0] = cy * cp * cr + sy * sp * sr; q4[1] = cy * sp * cr + sy * cp * sr;
+	q4[2] = sy * cp * cr - cy * sp * sr; q4[3] = cy * cp * sr - sy * sp * cr;
+}
+
+// TrackVehicle.UpdateNoisy (TrackVehicle.cs:89-102) for every particle: the odometry reading, then the particle's own
+// noise vector (dt * chol(Q) * N(0, I), drawn by the host: Util.cs:173-202) unless PerfectStill holds and the reading is 0
+void orc_update_motion(double* poses7, int nparticles, const double* odometry6, const double* noise6, int perfect_still)
+{
+	bool zero = true;
+	for (int t = 0; t < 6; t++) zero = zero && odometry6[t] == 0;
+	for (int i = 0; i < nparticles; i++) {
+		double tmp[7];
+		orc_add_odometry(poses7 + (size_t) i * 7, odometry6, tmp);
+		if (noise6 && !(perfect_still && zero)) orc_add_odometry(tmp, noise6 + (size_t) i * 6, poses7 + (size_t) i * 7);
+		else for (int t = 0; t < 7; t++) poses7[(size_t) i * 7 + t] = tmp[t];
+	}
+}
+
 // OSPA distance between two landmark sets (postanalysis/Plot.cs:531-581; LandmarkDistance :583-586), the acceptance
 // metric of SURVEY 8d (C = 1, P = 1 there). The transport problem is solved on C^P - d^P (entries below 1e-5 are left
 // at the sparse matrix's default 0, :562), maximised by the same Hungarian as the association step (:573), then mapped

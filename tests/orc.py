@@ -137,6 +137,43 @@ def hungarian(mat):
     return out.tolist() if ok else None
 
 
+def add_odometry(pose7, delta6):
+    """Pose3D.AddOdometry (Pose3D.cs:314-333)"""
+    a, ap = _d(np.asarray(pose7, float).reshape(7))
+    d, dptr = _d(np.asarray(delta6, float).reshape(6))
+    out, op = _d(np.zeros(7))
+    lib.orc_add_odometry(ap, dptr, op)
+    return out
+
+
+def diff_odometry(pose7, origin7):
+    """Pose3D.DiffOdometry (Pose3D.cs:338-356)"""
+    a, ap = _d(np.asarray(pose7, float).reshape(7))
+    o, optr = _d(np.asarray(origin7, float).reshape(7))
+    out, op = _d(np.zeros(6))
+    lib.orc_diff_odometry(ap, optr, op)
+    return out
+
+
+def quaternion_ypr(yaw, pitch, roll):
+    out, op = _d(np.zeros(4))
+    lib.orc_quaternion_ypr.argtypes = [C.c_double, C.c_double, C.c_double, dp]
+    lib.orc_quaternion_ypr(yaw, pitch, roll, op)
+    return out
+
+
+def update_motion(poses, reading, noise=None, perfect_still=False):
+    """TrackVehicle.UpdateNoisy (TrackVehicle.cs:89-102) over all particles; returns the new poses"""
+    out, op = _d(np.array(poses, float).reshape(-1, 7).copy())
+    r, rp = _d(np.asarray(reading, float).reshape(6))
+    if noise is not None:
+        nz, nzp = _d(np.asarray(noise, float).reshape(-1, 6))
+    else:
+        nzp = None
+    lib.orc_update_motion(op, len(out), rp, nzp, int(bool(perfect_still)))
+    return out
+
+
 def ospa(a, b, cutoff=1.0, order=1.0):
     """Plot.OSPA (postanalysis/Plot.cs:531-581): (distance, cardinality part) between two sets of 3-D landmarks;
     cutoff = C, order = P (1 and 1 in SURVEY 8d)."""

@@ -275,3 +275,28 @@ def test_big_association_clusters(nav_mod, seed, groups, per_group, mpg):
         assert np.isclose(alpha[i], a, rtol=1e-6, atol=0)
     assert biggest > 5, "the frame did not produce a cluster with more than 5 rows (largest %d)" % biggest
     nav.close()
+
+
+def test_motion_update_matches_oracle(nav_mod):
+    """TrackVehicle.UpdateNoisy on the device (phd_update_motion) against the oracle, including the
+    branches of Quaternion.Exp (no rotation) and the PerfectStill shortcut."""
+    rng = np.random.default_rng(77)
+    f = Frame(300, 4, 3, 71, weight_profile="steady")
+    nav, p = make_nav(nav_mod, f)
+    poses = f.poses.copy()
+    poses[:, 3:] += rng.normal(0, 0.3, (f.P, 4))
+    poses[:, 3:] /= np.linalg.norm(poses[:, 3:], axis=1, keepdims=True)
+    nav.set_poses(poses)
+    for reading, perfect in ((np.array([0.02, -0.01, 0.03, 0.01, -0.02, 0.015]), False),
+                             (np.array([0.1, 0.0, 0.0, 0.0, 0.0, 0.0]), False),       # translation only: Exp takes its identity branch
+                             (np.zeros(6), True), (np.zeros(6), False)):
+        noise = rng.normal(0, 1, (f.P, 6)) * [5e-3, 5e-3, 5e-3, 2e-4, 2e-4, 2e-4]
+        noise[::7, 3:] = 0                                                            # noise without rotation for some particles
+        want = orc.update_motion(poses, reading, noise, perfect)
+        nav.UpdateOdometry(None, reading, noise, perfect_still=perfect)
+        got = nav.poses()
+        assert np.allclose(got, want, rtol=0, atol=1e-14), np.max(np.abs(got - want))
+        poses = want
+    nav.UpdateOdometry(None, [0.01, 0, 0, 0, 0.02, 0])                                # no noise vector at all
+    assert np.allclose(nav.poses(), orc.update_motion(poses, [0.01, 0, 0, 0, 0.02, 0]), rtol=0, atol=1e-14)
+    nav.close()
