@@ -16,6 +16,9 @@ int main()
 		nav.SlamUpdate(z, 0.5);   // three births per particle, corrected by their own measurements in the same frame
 		monorfs::Map m0 = nav.BestMapModel();
 		if (m0.size() < 3 || m0.size() > 6) { std::printf("expected 3..6 components after the first frame, got %zu\n", m0.size()); return 1; }
+		// the motion step on the device: a small forward move, one noise vector per particle
+		std::vector<std::array<double, 6>> noise(8, std::array<double, 6>{1e-4, 0, -1e-4, 0, 1e-5, 0});
+		nav.UpdateOdometry({0.01, 0, 0, 0, 0, 0.002}, noise, false);
 		nav.SlamUpdate(z, 0.5);   // now detected
 		monorfs::Map m1 = nav.BestMapModel();
 		double sumw = 0;
