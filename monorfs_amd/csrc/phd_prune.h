@@ -28,7 +28,7 @@
 #include "phd_device.h"
 
 #define PRUNE_NBR 7
-#define PRUNE_NB 2048   // buckets of the spatial hash
+#define PRUNE_NB 4096   // buckets of the spatial hash (16-bit counters, two per LDS word)
 
 struct PruneLds {
 	int rad2, x, scan;       // offsets in doubles
@@ -45,8 +45,8 @@ __host__ __device__ inline PruneLds prune_lds(int cutcap)
 	l.NS    = NS;
 	l.rad2  = 0;
 	l.x     = l.rad2 + cc;                   // sort words u64[NS]  |  the lists of the pair search (see `rest`)
-	// nbr u64[2*cc], cand float4[cc], owner int[cc], cstart int[NB+2], absb int[64]
-	int rest  = 2 * cc + 2 * cc + cc / 2 + (PRUNE_NB + 2) / 2 + 32 + 4;
+	// nbr u64[2*cc], cand float4[cc], owner int[cc], cstart u16[NB+2], absb int[64]
+	int rest  = 2 * cc + 2 * cc + cc / 2 + (PRUNE_NB + 2) / 4 + 1 + 32 + 4;
 	l.scan  = l.x + (NS > rest ? NS : rest);
 	l.bytes = (l.scan + 136) * 8;            // int[264] | double[28], + spare
 	return l;
@@ -177,8 +177,9 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	unsigned long long* nbr = (unsigned long long*) (smem + lay.x);    // [cut][2]: count + up to 7 close later rows
 	float4* cand  = (float4*) (nbr + 2 * cc);              // [cut] rows grouped by bucket: mean relative to the box (float32), row
 	int*    owner = (int*) (cand + cc);                    // [cut] row that absorbed k (-1: none); the row's bucket while the grid is built
-	int*    cstart = owner + cc;                          // [NB + 2] bucket b is [cstart[b], cstart[b + 1])
-	int*    absb  = cstart + PRUNE_NB + 2;                 // [64] absorbed bits as left by the resolving wave
+	unsigned int* cw = (unsigned int*) (owner + cc);       // [(NB + 2) / 2] two 16-bit bucket boundaries per word
+	const unsigned short* cstart = (const unsigned short*) cw;   // [NB + 2] bucket b is [cstart[b], cstart[b + 1])
+	int*    absb  = (int*) (cw + (PRUNE_NB + 2) / 2 + 1);  // [64] absorbed bits as left by the resolving wave
 	int*    scan  = (int*) (smem + lay.scan);              // [264]
 	double* bred  = smem + lay.scan;                       // [28] block reduction scratch (before `scan` is used)
 
@@ -290,24 +291,30 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 		// float32 copies of the means relative to the box corner are off by at most 2^-24 ext per coordinate, so a
 		// float32 distance is within ferr of the true one
 		const double ferr = 4e-7 * ext;
+		// Hash of a grid cell. The low three bits are the parities of the cell coordinates, so the 2 x 2 x 2 cells a
+		// ball meets always fall into 8 different buckets (no bucket is walked twice); the rest mixes the halved
+		// coordinates. Cells outside the box hash like any other: whatever they collide with fails the distance test.
+		constexpr unsigned int HA = 73856093u, HB = 19349663u, HC = 83492791u;
 		auto bucket = [](int cx, int cy, int cz) {
-			return (int) (((unsigned int) cx * 73856093u ^ (unsigned int) cy * 19349663u ^ (unsigned int) cz * 83492791u) & (PRUNE_NB - 1));
+			const unsigned int h = (unsigned int) (cx >> 1) * HA ^ (unsigned int) (cy >> 1) * HB ^ (unsigned int) (cz >> 1) * HC;
+			return (int) (((h & (PRUNE_NB / 8 - 1)) << 3) | (cx & 1) | ((cy & 1) << 1) | ((cz & 1) << 2));
 		};
-		for (int t = tid; t <= PRUNE_NB; t += 256) cstart[t] = 0;
+		for (int t = tid; t < (PRUNE_NB + 2) / 2 + 1; t += 256) cw[t] = 0;
 		__syncthreads();
-		// counting sort of the rows by bucket
+		// counting sort of the rows by bucket (16-bit counters: cut <= 65535)
 		for (int r = tid; r < cut; r += 256) {
 			const double s0 = srec[r] - mn0, s1 = srec[(size_t) cutcap + r] - mn1, s2 = srec[(size_t) 2 * cutcap + r] - mn2;
 			const int b = bucket((int) (s0 * icell), (int) (s1 * icell), (int) (s2 * icell));
 			owner[r] = b;
-			atomicAdd(&cstart[b], 1);
+			atomicAdd(&cw[b >> 1], 1u << (16 * (b & 1)));
 		}
 		__syncthreads();
-		{   // inclusive prefix over the PRUNE_NB bucket counts: cstart[b] = end of bucket b; the fill below counts it down to its start
-			constexpr int BT = PRUNE_NB / 256;
-			int c[BT], tot = 0;
+		{   // inclusive prefix over the bucket counts: cstart[b] = end of bucket b; the fill below counts it down to its start
+			constexpr int WT = PRUNE_NB / 2 / 256;   // words per thread
+			unsigned int wd[WT];
+			int tot = 0;
 #pragma unroll
-			for (int u = 0; u < BT; u++) { c[u] = cstart[BT * tid + u]; tot += c[u]; }
+			for (int u = 0; u < WT; u++) { wd[u] = cw[WT * tid + u]; tot += (int) (wd[u] & 0xffff) + (int) (wd[u] >> 16); }
 			int incl = tot;
 #pragma unroll
 			for (int o = 1; o < 64; o <<= 1) {
@@ -319,13 +326,18 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 			int run = incl - tot;
 			for (int q = 0; q < wv; q++) run += scan[q];
 #pragma unroll
-			for (int u = 0; u < BT; u++) { run += c[u]; cstart[BT * tid + u] = run; }
-			if (tid == 0) cstart[PRUNE_NB] = cut;
+			for (int u = 0; u < WT; u++) {
+				const int e0 = run + (int) (wd[u] & 0xffff), e1 = e0 + (int) (wd[u] >> 16);
+				cw[WT * tid + u] = (unsigned int) e0 | ((unsigned int) e1 << 16);
+				run = e1;
+			}
+			if (tid == 0) cw[PRUNE_NB / 2] = (unsigned int) cut;   // cstart[NB]: the end of the last bucket
 		}
 		__syncthreads();
 		for (int r = tid; r < cut; r += 256) {
 			const double s0 = srec[r] - mn0, s1 = srec[(size_t) cutcap + r] - mn1, s2 = srec[(size_t) 2 * cutcap + r] - mn2;
-			const int pos = atomicSub(&cstart[owner[r]], 1) - 1;
+			const int b = owner[r], sh = 16 * (b & 1);
+			const int pos = (int) ((atomicSub(&cw[b >> 1], 1u << sh) >> sh) & 0xffff) - 1;
 			cand[pos] = make_float4((float) s0, (float) s1, (float) s2, __int_as_float(r));
 			owner[r] = -1;
 		}
@@ -366,25 +378,9 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 #endif
 				const int bx = (int) floor((m0 - mn0) * icell - 0.5), by = (int) floor((m1 - mn1) * icell - 0.5),
 				          bz = (int) floor((m2 - mn2) * icell - 0.5);
-				// the (up to) 8 buckets of the cells the ball meets, walked as one list
-				int qs[8], cum[9], bk[8];
-				cum[0] = 0;
-#pragma unroll
-				for (int c = 0; c < 8; c++) {
-					const int cx = bx + (c & 1), cy = by + ((c >> 1) & 1), cz = bz + (c >> 2);
-					bool ok = !(cx < 0 || cy < 0 || cz < 0 || cx > 255 || cy > 255 || cz > 255);
-					const int b = bucket(cx, cy, cz);
-					bk[c] = ok ? b : -1;
-#pragma unroll
-					for (int u = 0; u < c; u++) ok = ok && bk[u] != b;   // two cells in one bucket: the bucket is walked once
-					const int s0 = cstart[b], s1 = cstart[b + 1];
-					qs[c] = s0;
-					cum[c + 1] = cum[c] + (ok ? s1 - s0 : 0);
-				}
 				const float fx = (float) (m0 - mn0), fy = (float) (m1 - mn1), fz = (float) (m2 - mn2);
 				const double rr = sqrt(bound) + ferr;
 				const float thr = (float) (rr * rr * (1.0 + 1e-5));
-				// four candidates per trip: their records are fetched together
 				unsigned long long pend0 = 0, pend1 = 0;   // up to 8 queued rows as 16-bit fields
 				int npend = 0;
 				auto drain = [&]() {
@@ -394,49 +390,50 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 					}
 					pend0 = 0; pend1 = 0;
 				};
-#if defined(PHD_EXP) && PHD_EXP == 1
-				cum[8] = 0;
-#endif
-#if defined(PHD_EXP) && PHD_EXP == 4
-				cum[8] = min(cum[8], 4);
-#endif
-				for (int t0 = 0; t0 < cum[8]; t0 += 4) {
-					float4 cd[4];
-#pragma unroll
-					for (int v = 0; v < 4; v++) {
-						const int t = min(t0 + v, cum[8] - 1);
-						int c = 0;
-#pragma unroll
-						for (int u = 1; u < 8; u++) c += (t >= cum[u]) ? 1 : 0;
-						int q0 = qs[0], cb = cum[0];
-#pragma unroll
-						for (int u = 1; u < 8; u++) {
-							if (c == u) { q0 = qs[u]; cb = cum[u]; }
-						}
-						cd[v] = cand[q0 + (t - cb)];
-					}
-#pragma unroll
-					for (int v = 0; v < 4; v++) {
-						const int k = __float_as_int(cd[v].w);
-						const float e0 = fx - cd[v].x, e1 = fy - cd[v].y, e2 = fz - cd[v].z;
-#if defined(PHD_EXP) && PHD_EXP == 3
-						const bool pass = t0 + v < cum[8] && k > i && e0 * e0 + e1 * e1 + e2 * e2 <= -1.0f;
-#else
-						const bool pass = t0 + v < cum[8] && k > i && e0 * e0 + e1 * e1 + e2 * e2 <= thr;
-#endif
+				// the exact test is rare per lane but not per wave: a candidate that passes the float32 distance test is
+				// queued and tested later, so that the waves do not run the FP64 path at every candidate
+				auto visit = [&](const float4& cd) {
+					const int k = __float_as_int(cd.w);
+					const float e0 = fx - cd.x, e1 = fy - cd.y, e2 = fz - cd.z;
+					const bool pass = k > i && e0 * e0 + e1 * e1 + e2 * e2 <= thr;
 #ifdef PHD_STAMP_COUNTERS
-						if (t0 + v < cum[8]) dbg_walk++;
-						if (pass) dbg_test++;
+					dbg_walk++;
+					if (pass) dbg_test++;
 #endif
-						// the exact test is rare per lane but not per wave: queue the row and test later, so that the
-						// waves do not run the FP64 path on every trip
-						if (pass) {
-							if (npend < 4) pend0 |= (unsigned long long) k << (16 * npend);
-							else           pend1 |= (unsigned long long) k << (16 * (npend - 4));
-							npend++;
+					if (pass) {
+						if (npend < 4) pend0 |= (unsigned long long) k << (16 * npend);
+						else           pend1 |= (unsigned long long) k << (16 * (npend - 4));
+						npend++;
+					}
+				};
+				// the 8 buckets of the cells the ball meets: with 4096 buckets most hold no row or one, so the first row of
+				// every bucket is handled in straight-line code and only longer buckets are looped over
+				const unsigned int xa0 = (unsigned int) (bx >> 1) * HA, xa1 = (unsigned int) ((bx + 1) >> 1) * HA;
+				const unsigned int yb0 = (unsigned int) (by >> 1) * HB, yb1 = (unsigned int) ((by + 1) >> 1) * HB;
+				const unsigned int zc0 = (unsigned int) (bz >> 1) * HC, zc1 = (unsigned int) ((bz + 1) >> 1) * HC;
+				const int par0 = (bx & 1) | ((by & 1) << 1) | ((bz & 1) << 2);
+				int qs[8], qe[8];
+#pragma unroll
+				for (int c = 0; c < 8; c++) {
+					const unsigned int h = ((c & 1) ? xa1 : xa0) ^ ((c & 2) ? yb1 : yb0) ^ ((c & 4) ? zc1 : zc0);
+					const int b = (int) ((h & (PRUNE_NB / 8 - 1)) << 3) | (par0 ^ c);   // neighbours flip the parity bits
+					qs[c] = cstart[b];
+					qe[c] = cstart[b + 1];
+				}
+				bool more = false;
+#pragma unroll
+				for (int c = 0; c < 8; c++) {
+					if (qs[c] < qe[c]) visit(cand[qs[c]]);
+					more = more || qe[c] - qs[c] > 1;
+				}
+				if (more) {
+#pragma unroll
+					for (int c = 0; c < 8; c++) {
+						for (int q = qs[c] + 1; q < qe[c]; q++) {
+							visit(cand[q]);
+							if (npend > 7) drain();
 						}
 					}
-					if (npend > 4) drain();   // room for the next trip
 				}
 				drain();
 			}
