@@ -371,11 +371,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 					cnt++;
 				}
 			};
-#if defined(PHD_EXP) && PHD_EXP == 2
-			if (false) {
-#else
 			if (bound <= rcap * rcap) {
-#endif
 				const int bx = (int) floor((m0 - mn0) * icell - 0.5), by = (int) floor((m1 - mn1) * icell - 0.5),
 				          bz = (int) floor((m2 - mn2) * icell - 0.5);
 				const float fx = (float) (m0 - mn0), fy = (float) (m1 - mn1), fz = (float) (m2 - mn2);
@@ -437,13 +433,9 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 				}
 				drain();
 			}
-#if defined(PHD_EXP) && PHD_EXP == 2
-			else {}
-#else
 			else {
 				for (int k = i + 1; k < cut; k++) test(k);
 			}
-#endif
 			unsigned long long lo = (unsigned long long) min(cnt, 0xffff), hi = 0;
 #pragma unroll
 			for (int q = 0; q < PRUNE_NBR; q++) {

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from monorfs_amd import _lib
 
-extra = os.environ.get("PHD_STAMP_DEFS", "").split()   # e.g. "-DPHD_EXP=1" for a what-if build
+extra = os.environ.get("PHD_STAMP_DEFS", "").split()   # extra -D flags, e.g. "-DPHD_STAMP_COUNTERS" (visit / test counters of k_prune_merge instead of clean timing)
 so = os.path.join(_lib.CSRC, "libphdhip_stamps%s.so" % "".join(c for c in "".join(extra) if c.isalnum()))
 if not os.path.exists(so):
     subprocess.check_call(["/opt/rocm/bin/hipcc"] + _lib.HIPCC_FLAGS + ["-DPHD_STAMPS"] + extra + ["-o", so, os.path.join(_lib.CSRC, "phdhip.hip")])
