@@ -414,6 +414,15 @@ phd_navigator* phd_create(const phd_params* params, int device)
 		g_create_error = "capacities out of range (need max_components >= max_quantity >= 1, max_measurements <= 256)";
 		return nullptr;
 	}
+	{
+		// k_prune_merge and k_alpha_assoc keep their per-particle working set in LDS (160 KB per CU)
+		const int zb = zb_of(params->max_measurements);
+		const size_t need = std::max((size_t) prune_lds(params->max_quantity).bytes, (size_t) alpha_lds(zb * 64, params->max_quantity).bytes);
+		if (need > 160 * 1024 - 512) {
+			g_create_error = "max_quantity too large: pruning one particle needs " + std::to_string(need) + " bytes of LDS (160 KB per CU; about 3400 components fit)";
+			return nullptr;
+		}
+	}
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
 		g_create_error = "no HIP device: libphdhip has no CPU path";

@@ -47,6 +47,11 @@ def test_create_fails_loudly_without_device_or_bad_params():
     p.max_components = 10   # < max_quantity
     assert not lib.phd_create(C.byref(p), 0)
     assert b"capacities" in lib.phd_create_error()
+    # MaxQuantity beyond what one particle's prune can keep in LDS is refused at creation, not at the first launch
+    p = prm3d_defaults(4, 6000, 16)
+    p.max_quantity = 6000
+    assert not lib.phd_create(C.byref(p), 0)
+    assert b"max_quantity too large" in lib.phd_create_error()
     if not torch.cuda.is_available():
         p = prm3d_defaults(4, 600, 16)
         assert not lib.phd_create(C.byref(p), 0)
