@@ -1,5 +1,5 @@
 // Probe behind DESIGN.md §4 "MFMA: not used": issue rate of v_mfma_f64_16x16x4_f64 against v_fma_f64 on gfx950.
-//   hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o /tmp/mfma_probe scripts/mfma_f64_probe.hip && /tmp/mfma_probe
+//   hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o /tmp/mfma_probe scripts/probes/mfma_f64_rate.hip && /tmp/mfma_probe
 // Result on MI355X (profiles/r01_mfma_f64_probe.txt): 47 TFLOP/s through the matrix core, 53 TFLOP/s through v_fma_f64.
 // Every wave runs a chain-free loop (4 independent accumulators); one wave per SIMD and four waves per SIMD.
 #include <hip/hip_runtime.h>
