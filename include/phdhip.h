@@ -211,6 +211,14 @@ void* phd_stream(phd_navigator* nav);                               /* hipStream
  * lend = 0 returns to the handle's own stream.                                                   */
 int   phd_set_stream(phd_navigator* nav, void* stream, uint8_t lend);
 
+/* SURVEY row f4 (next to the path): PHDNavigator.QuasiSetLogLikelihood (PHDNavigator.cs:526-531) — the set
+ * log-likelihood with everything fully visible (constant PD, gate 12) — for a BATCH of candidate poses against one
+ * landmark set and one measurement set: the shape of the smoother's pose searches (LoopyPHDNavigator.cs:777-909).
+ * poses7[nposes][7], landmarks3[nlandmarks][3], z3[nmeasurements][3]; out[nposes]. nposes <= max_particles,
+ * nlandmarks <= min(1024, max_quantity). Synchronous; does not touch the particle state.                         */
+int phd_quasi_set_loglik(phd_navigator* nav, const double* poses7, int nposes, const double* landmarks3, int nlandmarks,
+                         const double* z3, int nmeasurements, double* out);
+
 /* Per-kernel device time in milliseconds, from HIP events recorded around every launch on the
  * handle's stream: the mean over the launches since the last phd_timing_reset; names[i] -> ms[i];
  * returns the number of entries. phd_timing_reset(nav, 0) switches the events off.               */

@@ -420,13 +420,16 @@ __host__ __device__ inline size_t alpha_jscratch_doubles(int Jcap)
 	return (size_t) 23 * Jcap;
 }
 
-template <int ZB>
-__global__ __launch_bounds__(256, 4) void k_alpha_assoc(const DevParams prm, const StepBufs a, int ncap)
+// QUASI = false: BestMapEstimate + SetLogLikelihood of particle p (k_alpha_assoc).
+// QUASI = true : QuasiSetLogLikelihood (PHDNavigator.cs:526-713, value) of candidate pose p against one
+//                given landmark set — the same association sum with everything fully visible: constant PD (:574-575),
+//                unit-weight measurement Gaussians (:583), detection gate 12 (:615). The map estimate is an input here.
+template <int ZB, bool QUASI>
+__device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const StepBufs& a, int ncap, double* smem)
 {
 	constexpr int MP = ZB * 64;
 	constexpr int MW = ZB;   // 64-bit adjacency words per landmark
 	constexpr int JL = ALPHA_JL;
-	extern __shared__ __align__(16) double smem[];
 	const AlphaLds lay = alpha_lds(MP, ncap);
 	double* zs   = smem + lay.zs;          // [MP][3] measurements
 	double* red  = smem + lay.red;         // [256] reduction scratch
@@ -439,10 +442,9 @@ __global__ __launch_bounds__(256, 4) void k_alpha_assoc(const DevParams prm, con
 	const MixView vin = bank_view(a, SEL_IN), vout = bank_view(a, SEL_OUT);
 	const Bank& bin  = a.bank[a.sel[SEL_IN]];
 	const Bank& bout = a.bank[a.sel[SEL_OUT]];
-	const int n = vin.count[p], nb = a.born_count[p], no = vout.count[p];
-	const int np = n + nb;
-	const size_t sbi = (size_t) p * cap, sbo = (size_t) p * cap;
-	const PoseD pose = load_pose(bin.poses + (size_t) p * 7);
+	const int no = QUASI ? 0 : vout.count[p];
+	const size_t sbo = (size_t) p * cap;
+	const PoseD pose = load_pose(QUASI ? a.qposes + (size_t) p * 7 : bin.poses + (size_t) p * 7);
 
 	for (int k = tid; k < MP * 3; k += 256) zs[k] = (k < M * 3) ? a.z[k] : 0.0;
 
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(256, 4) void k_alpha_assoc(const DevParams prm, con
 				atomicOr(a.flags, PHD_FLAG_J_OVERFLOW);
 				J = a.Jcap;
 			}
-			s_J = J;
+			s_J = QUASI ? min(a.qJ, a.Jcap) : J;
 		}
 	}
 	PHD_STAMP(1);
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(256, 4) void k_alpha_assoc(const DevParams prm, con
 		}
 		__syncthreads();
 	}
-	else if (J > no) {
+	else if (!QUASI && J > no) {
 		// more landmarks than components: the whole list, bitonic sort on the weight's bit pattern, then runs of
 		// equal weights put back in map order
 		unsigned long long* sv = (unsigned long long*) sortw;   // [NS] sort words, then overwritten by the sorted weights
@@ -667,7 +669,8 @@ __global__ __launch_bounds__(256, 4) void k_alpha_assoc(const DevParams prm, con
 	// When the largest weight minus one does not exceed the J-th largest weight no appended entry can be
 	// picked among the first J: the estimate is simply the J heaviest components, in order.
 	const bool straight = J <= no && (J == 0 || !(sortw[0] - 1 > sortw[J - 1]));
-	if (straight) {
+	if (QUASI) {}
+	else if (straight) {
 		for (int j = tid; j < J; j += 256) pick[j] = sortsrc[j];
 	}
 	else if (tid == 0) {
@@ -693,11 +696,16 @@ __global__ __launch_bounds__(256, 4) void k_alpha_assoc(const DevParams prm, con
 	__threadfence_block();
 	__syncthreads();
 	for (int j = tid; j < J; j += 256) {
-		int c = pick[j];
-		double l0 = vout.m[0][sbo + c], l1 = vout.m[1][sbo + c], l2 = vout.m[2][sbo + c];
-		lm[j] = l0; lm[JS + j] = l1; lm[2 * JS + j] = l2;
-		double* glm = a.alm + (size_t) p * 3 * a.Jcap;   // for k_alpha_density
-		glm[j] = l0; glm[a.Jcap + j] = l1; glm[2 * a.Jcap + j] = l2;
+		if (QUASI) {
+			lm[j] = a.qlm[j * 3]; lm[JS + j] = a.qlm[j * 3 + 1]; lm[2 * JS + j] = a.qlm[j * 3 + 2];
+		}
+		else {
+			int c = pick[j];
+			double l0 = vout.m[0][sbo + c], l1 = vout.m[1][sbo + c], l2 = vout.m[2][sbo + c];
+			lm[j] = l0; lm[JS + j] = l1; lm[2 * JS + j] = l2;
+			double* glm = a.alm + (size_t) p * 3 * a.Jcap;   // for k_alpha_density
+			glm[j] = l0; glm[a.Jcap + j] = l1; glm[2 * a.Jcap + j] = l2;
+		}
 	}
 	__threadfence_block();
 	__syncthreads();
@@ -713,7 +721,7 @@ __global__ __launch_bounds__(256, 4) void k_alpha_assoc(const DevParams prm, con
 			double m[3] = {lm[j], lm[JS + j], lm[2 * JS + j]}, z[3], l[3];
 			measure_perfect(prm, pose, m, z, l);
 			zh[j] = z[0]; zh[JS + j] = z[1]; zh[2 * JS + j] = z[2];
-			const double pdv = detection_probability_m(prm, z);
+			const double pdv = QUASI ? prm.pd : detection_probability_m(prm, z);
 			lpd[j] = log(pdv);
 			lmd[j] = log(1 - pdv);
 #pragma unroll
@@ -732,7 +740,7 @@ __global__ __launch_bounds__(256, 4) void k_alpha_assoc(const DevParams prm, con
 		for (int e = tid; e < J * M; e += 256) {
 			const int j = e / M, k = e - j * M;
 			const double q = quad_gen(prm.Rinv, zh[j] - zs[k * 3], zh[JS + j] - zs[k * 3 + 1], zh[2 * JS + j] - zs[k * 3 + 2]);
-			if (q < prm.g2_assoc) {   // sqrt(q) < 5, :436
+			if (q < (QUASI ? prm.g2_quasi : prm.g2_assoc)) {   // sqrt(q) < 5, :436 (quasi: < 12, :615)
 				atomicOr(&adj[(size_t) j * MW + (k >> 6)], 1ull << (k & 63));
 				if (inlds) atomicOr(&adjT[(size_t) k * JW + (j >> 6)], 1ull << (j & 63));
 			}
@@ -1070,10 +1078,27 @@ __global__ __launch_bounds__(256, 4) void k_alpha_assoc(const DevParams prm, con
 	PHD_STAMP(7);
 	PHD_STAMP_FLUSH(3, 8);
 	if (tid == 0) {
-		a.setll[p]   = s_total;
-		a.aJ[p]      = J;
-		a.account[p] = s_ccount;
+		a.setll[p] = s_total;
+		if (!QUASI) {
+			a.aJ[p]      = J;
+			a.account[p] = s_ccount;
+		}
 	}
+}
+
+template <int ZB>
+__global__ __launch_bounds__(256, 4) void k_alpha_assoc(const DevParams prm, const StepBufs a, int ncap)
+{
+	extern __shared__ __align__(16) double smem[];
+	alpha_assoc_body<ZB, false>(prm, a, ncap, smem);
+}
+
+// one workgroup per candidate pose (the smoother's pose x landmark x measurement batches)
+template <int ZB>
+__global__ __launch_bounds__(256, 4) void k_quasi_setll(const DevParams prm, const StepBufs a, int ncap)
+{
+	extern __shared__ __align__(16) double smem[];
+	alpha_assoc_body<ZB, true>(prm, a, ncap, smem);
 }
 
 // =================================================================================================

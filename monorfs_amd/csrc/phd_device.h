@@ -38,6 +38,7 @@ struct DevParams {
 	double g2_explore;      // SQUARED distance; same for Map.Evaluate(x, 3 * DensityDistanceThreshold) (:958). Squared-
 	                        // Euclidean metric: the radius itself; Euclidean: radius^2; gate disabled: +inf
 	double merge_thr2;      // MergeThreshold^2                 (Gaussian.cs:245)
+	double g2_quasi;        // smallest q with sqrt(q) >= 12: the gate of QuasiSetLogLikelihood (:615)
 	double g2_assoc;        // smallest q with sqrt(q) >= 5: `Mahalanobis < 5` (PHDNavigator.cs:436) is q < g2_assoc exactly
 	double min_eff;
 	double emit_log_floor;  // log(minw * kappa): no emitted weight can come from below it

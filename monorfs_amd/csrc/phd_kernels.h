@@ -78,6 +78,10 @@ struct StepBufs {
 	double* alm;         // [P][3][Jcap] landmark means
 	int*    aJ;          // [P] landmarks
 	double* account;     // [P] expected size of the corrected map
+	// QuasiSetLogLikelihood batches (k_quasi_setll): candidate poses, the landmark set, its size
+	const double* qposes;   // [P][7]
+	const double* qlm;      // [qJ][3]
+	int     qJ;
 	double* stamps;      // [P][16] phase stamps of the diagnostic build (NULL otherwise)
 	int     stamp_kernel; // which kernel writes them (env PHD_STAMP_KERNEL): 2 prune, 3 assoc, 4 density, 1 correct
 };

@@ -58,6 +58,8 @@ struct phd_navigator {
 	double* d_stamps = nullptr;
 	double* d_srec = nullptr;
 	double* d_motion = nullptr;   // odometry[6] + noise[P][6] of phd_update_motion
+	double* d_quasi = nullptr;    // phd_quasi_set_loglik: poses[Pcap][7], landmarks[Jcap][3], z[256][3], out[Pcap]
+	std::vector<double> h_quasi;
 	double* d_gw = nullptr; int gwcap = 0;           // gathered weights of all ranks
 	double* d_stage = nullptr;                       // staging for uploads
 	// migration (multi-GPU resampling)
@@ -148,6 +150,8 @@ DevParams make_dev_params(const phd_params& p)
 	d.merge_thr2 = p.merge_threshold * p.merge_threshold;
 	d.g2_assoc = 25.0;
 	while (std::sqrt(std::nextafter(d.g2_assoc, 0.0)) >= 5.0) d.g2_assoc = std::nextafter(d.g2_assoc, 0.0);
+	d.g2_quasi = 144.0;
+	while (std::sqrt(std::nextafter(d.g2_quasi, 0.0)) >= 12.0) d.g2_quasi = std::nextafter(d.g2_quasi, 0.0);
 	d.min_eff    = p.min_effective_particle;
 	double floor = p.min_weight * p.clutter_density;
 	d.emit_log_floor = (floor > 0) ? std::log(floor) : -INFINITY;
@@ -159,7 +163,7 @@ DevParams make_dev_params(const phd_params& p)
 StepBufs make_bufs(phd_navigator* nav)
 {
 	StepBufs b;
-	b.P = nav->P; b.p0 = 0; b.cap = nav->cap; b.M = nav->M; b.Mcap = nav->Mcap; b.ecap = nav->ecap; b.Jcap = nav->Jcap;
+	b.P = nav->P; b.p0 = 0; b.qposes = nullptr; b.qlm = nullptr; b.qJ = 0; b.cap = nav->cap; b.M = nav->M; b.Mcap = nav->Mcap; b.ecap = nav->ecap; b.Jcap = nav->Jcap;
 	b.plane = (size_t) nav->Pcap * nav->cap;
 	for (int i = 0; i < 3; i++) b.bank[i] = nav->bank[i];
 	b.sel = nav->d_sel + nav->parity * 4;
@@ -264,6 +268,18 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha)
 		HC(hipEventRecord(nav->ev_join[s - 1], nav->aux[s - 1]));
 		HC(hipStreamWaitEvent(nav->stream, nav->ev_join[s - 1], 0));
 	}
+	HC(hipGetLastError());
+	return PHD_OK;
+}
+
+// PHDNavigator.QuasiSetLogLikelihood (PHDNavigator.cs:526-531) for a batch of candidate poses against one landmark
+// set and one measurement set: one workgroup per pose through the association kernel's own code.
+template <int ZB>
+int launch_quasi(phd_navigator* nav, const StepBufs& b, int nposes)
+{
+	const AlphaLds lay = alpha_lds(ZB * 64, nav->cutcap);
+	HC(hipFuncSetAttribute((const void*) k_quasi_setll<ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
+	hipLaunchKernelGGL(k_quasi_setll<ZB>, dim3(nposes), dim3(256), lay.bytes, nav->stream, nav->dp, b, nav->cutcap);
 	HC(hipGetLastError());
 	return PHD_OK;
 }
@@ -515,7 +531,7 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_sel); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
-	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_motion); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cm); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
+	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cm); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
 	if (nav->own_stream) hipStreamDestroy(nav->own_stream);
 	for (int i = 0; i < phd_navigator::MAXSPLIT - 1; i++) {
@@ -585,6 +601,42 @@ int phd_update_motion(phd_navigator* nav, const double* odometry6, const double*
 	HC(hipGetLastError());
 	HC(hipStreamSynchronize(nav->stream));   // the caller's buffers are free again
 	nav->stage_valid = false;
+	return PHD_OK;
+}
+
+int phd_quasi_set_loglik(phd_navigator* nav, const double* poses7, int nposes, const double* landmarks3, int nlandmarks,
+                         const double* z3, int nmeasurements, double* out)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nposes < 1 || nposes > nav->Pcap || nlandmarks < 0 || nlandmarks > nav->Jcap || nmeasurements < 0 ||
+	    nmeasurements > nav->prm.max_measurements || !poses7 || !out || (nlandmarks && !landmarks3) || (nmeasurements && !z3)) {
+		return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_quasi_set_loglik: sizes out of range (poses <= max_particles, landmarks <= min(1024, max_quantity), measurements <= max_measurements)");
+	}
+	hipSetDevice(nav->device);
+	const size_t op = 0, ol = op + (size_t) nav->Pcap * 7, oz = ol + (size_t) nav->Jcap * 3, oo = oz + 256 * 3, total = oo + nav->Pcap;
+	if (!nav->d_quasi) HC(hipMalloc((void**) &nav->d_quasi, total * 8));
+	HC(hipMemcpyAsync(nav->d_quasi + op, poses7, (size_t) nposes * 7 * 8, hipMemcpyHostToDevice, nav->stream));
+	if (nlandmarks) HC(hipMemcpyAsync(nav->d_quasi + ol, landmarks3, (size_t) nlandmarks * 3 * 8, hipMemcpyHostToDevice, nav->stream));
+	if (nmeasurements) HC(hipMemcpyAsync(nav->d_quasi + oz, z3, (size_t) nmeasurements * 3 * 8, hipMemcpyHostToDevice, nav->stream));
+	StepBufs b = make_bufs(nav);
+	b.P = nposes; b.M = nmeasurements; b.z = nav->d_quasi + oz;
+	b.qposes = nav->d_quasi + op; b.qlm = nav->d_quasi + ol; b.qJ = nlandmarks;
+	b.setll = nav->d_quasi + oo;
+	int rc;
+	switch (zb_of(nmeasurements)) {
+	case 1:  rc = launch_quasi<1>(nav, b, nposes); break;
+	case 2:  rc = launch_quasi<2>(nav, b, nposes); break;
+	default: rc = launch_quasi<4>(nav, b, nposes); break;
+	}
+	if (rc) return rc;
+	HC(hipMemcpyAsync(out, nav->d_quasi + oo, (size_t) nposes * 8, hipMemcpyDeviceToHost, nav->stream));
+	HC(hipStreamSynchronize(nav->stream));
+	int flags = 0;
+	HC(hipMemcpy(&flags, nav->d_flags, 4, hipMemcpyDeviceToHost));
+	if (flags & PHD_FLAG_BIG_CLUSTER) {
+		hipMemset(nav->d_flags, 0, 4);
+		return nav->fail(PHD_ERR_ASSOCIATION, "phd_quasi_set_loglik: an association cluster exceeds the on-device solver");
+	}
 	return PHD_OK;
 }
 

@@ -71,6 +71,17 @@ public:
 		check(phd_update_motion(nav_, reading.data(), noise.empty() ? nullptr : noise[0].data(), ParticleCount, perfectstill ? 1 : 0));
 	}
 
+	// ≙ static QuasiSetLogLikelihood(measurements, map, pose) (:526-531), for a batch of candidate poses (row f4)
+	std::vector<double> QuasiSetLogLikelihood(const std::vector<PixelRangeMeasurement>& measurements,
+	                                          const std::vector<std::array<double, 3>>& landmarks, const std::vector<Pose3D>& poses)
+	{
+		std::vector<double> out(poses.size());
+		check(phd_quasi_set_loglik(nav_, poses.empty() ? nullptr : poses[0].data(), (int) poses.size(),
+		                           landmarks.empty() ? nullptr : landmarks[0].data(), (int) landmarks.size(),
+		                           measurements.empty() ? nullptr : measurements[0].data(), (int) measurements.size(), out.data()));
+		return out;
+	}
+
 	// ≙ SlamUpdate (:323-362); `uniform` replaces (double) Util.Uniform.Next() of ResampleParticles (:727)
 	void SlamUpdate(const std::vector<PixelRangeMeasurement>& measurements, double uniform)
 	{

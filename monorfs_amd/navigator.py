@@ -149,6 +149,17 @@ class PHDNavigator:
         self._check(self._lib.phd_update_motion(self._h, _ptr(reading), _ptr(noise) if noise is not None else None,
                                                 self.particle_count, int(bool(perfect_still))))
 
+    def QuasiSetLogLikelihood(self, measurements, landmarks, poses):
+        """≙ static PHDNavigator.QuasiSetLogLikelihood(measurements, map, pose) (PHDNavigator.cs:526-531), batched over
+        candidate poses (phd_quasi_set_loglik): returns one value per pose."""
+        z = np.ascontiguousarray(measurements, np.float64).reshape(-1, 3)
+        lm = np.ascontiguousarray(landmarks, np.float64).reshape(-1, 3)
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+        out = np.zeros(len(poses))
+        self._check(self._lib.phd_quasi_set_loglik(self._h, _ptr(poses), len(poses), _ptr(lm) if len(lm) else None, len(lm),
+                                                   _ptr(z) if len(z) else None, len(z), _ptr(out)))
+        return out
+
     def SlamUpdate(self, time, measurements, u_resample=0.5):
         """≙ PHDNavigator.SlamUpdate (:323-362)."""
         z = np.ascontiguousarray(measurements, np.float64).reshape(-1, 3)

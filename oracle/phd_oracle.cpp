@@ -901,15 +901,18 @@ struct DSU {
 
 // SetLogLikelihood (PHDNavigator.cs:462-515) over SetLogLikeMatrix (:415-453).
 // `lm` = landmark means of the map estimate (J x 3).
+// quasi: QuasiSetLogLikelihood (:526-713, value only) — the same sum with everything fully visible: constant PD
+// (logPD / log1PD, :574-575), zprobs of weight 1 (:583) and the detection gate at 12 (:600, :615).
 double set_log_likelihood(const Model& md, const Pose& pose, const double* lm, int J, const double* z, int M,
-                          int* nclusters = nullptr, int* maxcluster = nullptr)
+                          int* nclusters = nullptr, int* maxcluster = nullptr, bool quasi = false)
 {
 	const int zd = md.zdim;
+	const double gate = quasi ? 12 : 5;
 	double logclutter = std::log(md.p->clutter_density);
 	std::vector<double> zhat(J * 3), pdj(J);
 	for (int i = 0; i < J; i++) {
 		measure_perfect(md, pose, lm + i * 3, &zhat[i * 3]);
-		pdj[i] = pd_m(md, &zhat[i * 3]);   // zprobs[i].Weight
+		pdj[i] = quasi ? md.p->pd : pd_m(md, &zhat[i * 3]);   // zprobs[i].Weight (quasi: pose.PD)
 	}
 
 	// detection block: defined iff Mahalanobis(z_k ; zhat_i, R) < 5 (:433-442)
@@ -923,7 +926,7 @@ double set_log_likelihood(const Model& md, const Pose& pose, const double* lm, i
 				d[a] = zhat[i * 3 + a] - z[k * zd + a];   // Mahalanobis: Mean - point (Gaussian.cs:354-358)
 			}
 			double dist = std::sqrt(quadform(md.Rinv, d, zd));
-			if (dist < 5) {
+			if (dist < gate) {
 				det[i].push_back(Edge{k, std::log(pdj[i]) + std::log(md.Rmult) - 0.5 * dist * dist});
 				dsu.join(i, J + k);
 			}
@@ -1165,6 +1168,14 @@ double orc_set_log_likelihood(const phd_params* p, const double* pose7, const do
 	Model md = make_model(p);
 	Pose  ps = make_pose(pose7);
 	return set_log_likelihood(md, ps, lm, J, z, M, nclusters, maxcluster);
+}
+
+// PHDNavigator.QuasiSetLogLikelihood(measurements, map, pose) (:526-531), SURVEY row f4
+double orc_quasi_set_log_likelihood(const phd_params* p, const double* pose7, const double* lm, int J, const double* z, int M)
+{
+	Model md = make_model(p);
+	Pose  ps = make_pose(pose7);
+	return set_log_likelihood(md, ps, lm, J, z, M, nullptr, nullptr, true);
 }
 
 double orc_weight_alpha(const phd_params* p, const double* pose7, const double* z, int M,

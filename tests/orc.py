@@ -105,6 +105,17 @@ def set_log_likelihood(p, pose7, lm, z):
     return v, ncl.value, mx.value
 
 
+def quasi_set_log_likelihood(p, pose7, lm, z):
+    """PHDNavigator.QuasiSetLogLikelihood (PHDNavigator.cs:526-531): everything fully visible, gate 12"""
+    lm = np.ascontiguousarray(lm, np.float64).reshape(-1, 3)
+    z = np.ascontiguousarray(z, np.float64).reshape(-1, p.zdim)
+    pose7 = np.ascontiguousarray(pose7, np.float64)
+    lib.orc_quasi_set_log_likelihood.restype = C.c_double
+    lmp = lm if len(lm) else np.zeros((1, 3))
+    return lib.orc_quasi_set_log_likelihood(C.byref(p), pose7.ctypes.data_as(dp), lmp.ctypes.data_as(dp), len(lm),
+                                            z.ctypes.data_as(dp), len(z))
+
+
 def weight_alpha(p, pose7, z, predicted, corrected):
     pw, pm, pc = pack(predicted)
     cw, cm, cc = pack(corrected)

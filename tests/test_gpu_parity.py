@@ -300,3 +300,25 @@ def test_motion_update_matches_oracle(nav_mod):
     nav.UpdateOdometry(None, [0.01, 0, 0, 0, 0.02, 0])                                # no noise vector at all
     assert np.allclose(nav.poses(), orc.update_motion(poses, [0.01, 0, 0, 0, 0.02, 0]), rtol=0, atol=1e-14)
     nav.close()
+
+
+@pytest.mark.parametrize("J,M,seed", [(3, 4, 81), (40, 30, 82), (12, 70, 83), (300, 64, 84), (0, 5, 85), (6, 0, 86)])
+def test_quasi_set_log_likelihood_batch(nav_mod, J, M, seed):
+    """QuasiSetLogLikelihood for a batch of candidate poses (phd_quasi_set_loglik) against the oracle:
+    small and large clusters (the gate of 12 joins more measurements than the gate of 5), a landmark set larger than
+    the LDS-resident limit, empty sets."""
+    rng = np.random.default_rng(seed)
+    f = Frame(48, max(J, 1), max(M, 1), seed, weight_profile="steady")
+    nav, p = make_nav(nav_mod, f)
+    lm = f.mean[0, :J].copy()
+    z = f.z[:M].copy()
+    if M > 3 and J > 3:
+        z[1] = z[0] + [3.0, -2.0, 0.01]          # measurements crowding one landmark: clusters beyond 5 rows
+        z[2] = z[0] + [-4.0, 1.0, -0.02]
+    poses = f.poses.copy()
+    poses[:, :3] += rng.normal(0, 5e-3, (f.P, 3))
+    poses[:, 3:] += rng.normal(0, 2e-3, (f.P, 4))
+    got = nav.QuasiSetLogLikelihood(z, lm, poses)
+    want = np.array([orc.quasi_set_log_likelihood(p, poses[i], lm, z) for i in range(f.P)])
+    assert np.allclose(got, want, rtol=1e-9, atol=1e-9), np.max(np.abs(got - want))
+    nav.close()

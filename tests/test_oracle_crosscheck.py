@@ -104,7 +104,7 @@ def best_map_estimate(mix):
 
 
 # ---- PHDNavigator.cs:415-515 by brute force --------------------------------------------------------------------
-def set_log_likelihood_bruteforce(p, pose7, lm, z):
+def set_log_likelihood_bruteforce(p, pose7, lm, z, quasi=False):
     J, M = len(lm), len(z)
     n = J + M
     R = np.array(p.R).reshape(3, 3)
@@ -114,10 +114,10 @@ def set_log_likelihood_bruteforce(p, pose7, lm, z):
     gated = np.zeros((J, M), bool)
     for j in range(J):
         zh = measure_perfect(p, pose7, lm[j])
-        pd[j] = detection_probability_m(p, zh)
+        pd[j] = p.pd if quasi else detection_probability_m(p, zh)
         for k in range(M):
             d = np.sqrt((z[k] - zh) @ Rinv @ (z[k] - zh))
-            if d < 5:
+            if d < (12 if quasi else 5):
                 gated[j, k] = True
                 mat[j, k] = np.log(pd[j]) + np.log(multiplier(R)) - 0.5 * d * d
         mat[j, M + j] = np.log(1 - pd[j])
@@ -175,6 +175,22 @@ def test_set_log_likelihood_against_all_permutations(seed):
         lm[1] = lm[0] + rng.normal(0, 1e-3, 3)
     want = set_log_likelihood_bruteforce(p, pose, lm, z)
     got = orc.set_log_likelihood(p, pose, lm, z)[0]
+    assert np.isclose(got, want, rtol=1e-10, atol=1e-10), (got, want)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_quasi_set_log_likelihood_against_all_permutations(seed):
+    """QuasiSetLogLikelihood (PHDNavigator.cs:526-713, value): constant PD, gate 12; landmarks near the border of the
+    field of view, where the plain set log-likelihood would fade them out, count fully"""
+    rng = np.random.default_rng(500 + seed)
+    p = prm3d_defaults(4, 600, 8)
+    J = int(rng.integers(1, 4))
+    M = int(rng.integers(1, 6 - J))
+    pose, lm, z = random_case(rng, p, J, M)
+    if seed % 2:                               # a measurement 8 sigma off: inside the gate of 12, outside the gate of 5
+        z[0] = measure_perfect(p, pose, lm[0]) + 8 * np.sqrt(np.diag(np.array(p.R).reshape(3, 3))) * [1, 0, 0]
+    want = set_log_likelihood_bruteforce(p, pose, lm, z, quasi=True)
+    got = orc.quasi_set_log_likelihood(p, pose, lm, z)
     assert np.isclose(got, want, rtol=1e-10, atol=1e-10), (got, want)
 
 
