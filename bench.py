@@ -93,6 +93,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the PHD path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
+    # Native libraries (RCCL prints a banner) write to file descriptor 1: keep it for the one JSON line and send
+    # everything else to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
@@ -204,7 +209,7 @@ def main():
             sample = args.cpu_sample or P
             out["cpu_baseline"] = cpu_baseline(frame, params, sample, threads)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     nav.close()
     if use_dist:
         dist.destroy_process_group()
