@@ -127,25 +127,35 @@ def main():
         rcounts = np.zeros(world, np.int32)
         ip = C.POINTER(C.c_int32)
 
+    cache = {}
+
+    def dev_tensor(ptr, n):
+        """torch view of a library-owned device buffer (cached: the pointers only change when a buffer grows)"""
+        key = (int(ptr), int(n))
+        if key not in cache:
+            cache[key] = torch.as_tensor(DevArray(ptr, n), device="cuda")
+        return cache[key]
+
+    empty = torch.empty(0, dtype=torch.float64, device="cuda") if use_dist else None
+
     def step(u=0.5):
         if not use_dist:
             nav.step_async(u)
             return
         nav._check(lib.phd_step_local_async(h, 0))
-        lw = torch.as_tensor(DevArray(lib.phd_device_local_weights(h), P), device="cuda")
-        dist.all_gather_into_tensor(gw, lw)
+        dist.all_gather_into_tensor(gw, dev_tensor(lib.phd_device_local_weights(h), P))
         nav._check(lib.phd_step_global_async(h, rank, world, u))
+        nav._check(lib.phd_migration_local_async(h, rank, world))   # local sources are copied while the host plans
         nav._check(lib.phd_migration_plan(h, rank, world, scounts.ctypes.data_as(ip), rcounts.ctypes.data_as(ip)))
-        if True:
-            nav._check(lib.phd_migration_pack_async(h))
-            bpp = C.c_int64(0)
-            sptr = lib.phd_migration_send_buffer(h, C.byref(bpp))
-            rptr = lib.phd_migration_recv_buffer(h)
-            rec = bpp.value // 8
-            ns, nr = int(scounts.sum()), int(rcounts.sum())
-            send = torch.as_tensor(DevArray(sptr, max(ns, 1) * rec), device="cuda")[:ns * rec] if sptr else torch.empty(0, dtype=torch.float64, device="cuda")
-            recv = torch.as_tensor(DevArray(rptr, max(nr, 1) * rec), device="cuda")[:nr * rec] if rptr else torch.empty(0, dtype=torch.float64, device="cuda")
-            dist.all_to_all_single(recv, send, (rcounts * rec).tolist(), (scounts * rec).tolist())
+        nav._check(lib.phd_migration_pack_async(h))
+        bpp = C.c_int64(0)
+        sptr = lib.phd_migration_send_buffer(h, C.byref(bpp))
+        rptr = lib.phd_migration_recv_buffer(h)
+        rec = bpp.value // 8
+        ns, nr = int(scounts.sum()), int(rcounts.sum())
+        send = dev_tensor(sptr, ns * rec) if ns else empty
+        recv = dev_tensor(rptr, nr * rec) if nr else empty
+        dist.all_to_all_single(recv, send, (rcounts * rec).tolist(), (scounts * rec).tolist())
         nav._check(lib.phd_migration_unpack_async(h))
 
     def barrier():

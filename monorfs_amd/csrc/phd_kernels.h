@@ -254,9 +254,33 @@ __global__ __launch_bounds__(256) void k_pack_particles(const StepBufs a, const 
 	}
 }
 
-// dstsrc[i] >= 0: local source slot in the OUT bank; < 0: record -(dstsrc[i] + 1) of the receive buffer
+// The slots of this rank whose resampling source is one of its own particles, copied OUT -> TMP straight from the
+// global source vector (no host plan needed): the bulk of a migration step, overlapped with the host's round trip.
+__global__ __launch_bounds__(256) void k_gather_local(const StepBufs a, const int* gsrc, const int* info, int first)
+{
+	if (!info[1]) return;   // no resampling this step
+	const int i = blockIdx.x, tid = threadIdx.x;
+	const int s = gsrc[first + i] - first;
+	if (s < 0 || s >= a.P) return;   // remote source: filled by k_unpack_gather from the receive buffer
+	const int O = a.sel[SEL_OUT], T = a.sel[SEL_TMP];
+	const MixView from = bank_view(a, SEL_OUT), dst = bank_view(a, SEL_TMP);
+	const int n = from.count[s];
+	const size_t db = (size_t) i * a.cap, fb = (size_t) s * a.cap;
+	for (int c = tid; c < n; c += 256) {
+		dst.w[db + c] = from.w[fb + c];
+#pragma unroll
+		for (int t = 0; t < 3; t++) dst.m[t][db + c] = from.m[t][fb + c];
+#pragma unroll
+		for (int t = 0; t < 6; t++) dst.P[t][db + c] = from.P[t][fb + c];
+	}
+	if (tid == 0) dst.count[i] = n;
+	if (tid < 7) a.bank[T].poses[(size_t) i * 7 + tid] = a.bank[O].poses[(size_t) s * 7 + tid];
+}
+
+// dstsrc[i] >= 0: local source slot in the OUT bank (skipped when k_gather_local already copied those);
+// < 0: record -(dstsrc[i] + 1) of the receive buffer
 __global__ __launch_bounds__(256) void k_unpack_gather(const StepBufs a, const int* dstsrc, const double* recvbuf,
-                                                       double weight, int* sel_next, int frozen)
+                                                       double weight, int* sel_next, int frozen, int local_done)
 {
 	const int i = blockIdx.x, tid = threadIdx.x;
 	const int I = a.sel[SEL_IN], O = a.sel[SEL_OUT], T = a.sel[SEL_TMP];
@@ -268,7 +292,8 @@ __global__ __launch_bounds__(256) void k_unpack_gather(const StepBufs a, const i
 	const MixView from = bank_view(a, SEL_OUT), dst = bank_view(a, SEL_TMP);
 	const size_t db = (size_t) i * a.cap;
 	const int code = dstsrc[i];
-	if (code >= 0) {
+	if (code >= 0 && local_done) {}
+	else if (code >= 0) {
 		const int n = from.count[code];
 		const size_t fb = (size_t) code * a.cap;
 		for (int c = tid; c < n; c += 256) {

@@ -67,6 +67,8 @@ struct phd_navigator {
 	std::vector<int> h_plan_send, h_plan_recv;       // particle lists
 	int* d_sendlist = nullptr; int sendlistcap = 0; int* d_code = nullptr;
 	int nsend = 0, nrecv = 0, last_world_particles = 1;
+	bool local_gather_done = false;                  // k_gather_local ran for the step being migrated
+	int* h_pin = nullptr; int h_pin_cap = 0;         // pinned: [2] resampling info + the global source vector
 
 	// host mirrors handed out by the getters
 	std::vector<double> h_weights, h_poses, h_mw, h_mm, h_mc, h_alpha, h_setll, h_tmp;
@@ -533,6 +535,7 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
 	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cm); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
+	if (nav->h_pin) hipHostFree(nav->h_pin);
 	if (nav->own_stream) hipStreamDestroy(nav->own_stream);
 	for (int i = 0; i < phd_navigator::MAXSPLIT - 1; i++) {
 		if (nav->aux[i]) hipStreamDestroy(nav->aux[i]);
@@ -1148,15 +1151,23 @@ int phd_migration_plan(phd_navigator* nav, int rank, int world_size, int32_t* se
 	int rc = PHD_OK;
 	if (!nav->sel_host_valid) rc = sync_state(nav);
 	if (rc) return rc;
-	HC(hipMemcpyAsync(nav->h_info, nav->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, nav->stream));
-	HC(hipStreamSynchronize(nav->stream));
 	const int Pl = nav->P, Pg = Pl * world_size, first = rank * Pl;
+	if (nav->h_pin_cap < Pg + 2) {
+		if (nav->h_pin) hipHostFree(nav->h_pin);
+		nav->h_pin = nullptr;
+		HC(hipHostMalloc((void**) &nav->h_pin, (size_t) (Pg + 2) * 4, hipHostMallocDefault));
+		nav->h_pin_cap = Pg + 2;
+	}
+	// one round trip: the resampling flag and the global source vector land in pinned memory together
+	HC(hipMemcpyAsync(nav->h_pin, nav->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, nav->stream));
+	HC(hipMemcpyAsync(nav->h_pin + 2, nav->d_plan, (size_t) Pg * 4, hipMemcpyDeviceToHost, nav->stream));
+	HC(hipStreamSynchronize(nav->stream));
+	nav->h_info[0] = nav->h_pin[0]; nav->h_info[1] = nav->h_pin[1];
 	for (int r = 0; r < world_size; r++) send_counts[r] = recv_counts[r] = 0;
 	nav->nsend = nav->nrecv = 0;
 	nav->h_plan_send.clear();
 	nav->h_plan_recv.assign(Pl, 0);
-	std::vector<int> gsrc(Pg);
-	HC(hipMemcpy(gsrc.data(), nav->d_plan, (size_t) Pg * 4, hipMemcpyDeviceToHost));
+	std::vector<int> gsrc(nav->h_pin + 2, nav->h_pin + 2 + Pg);
 	nav->h_src.assign(gsrc.begin() + first, gsrc.begin() + first + Pl);   // global source of each local slot
 	if (!nav->h_info[1]) {
 		for (int i = 0; i < Pl; i++) nav->h_plan_recv[i] = i;
@@ -1190,6 +1201,22 @@ void* phd_migration_send_buffer(phd_navigator* nav, int64_t* bytes_per_particle)
 }
 
 void* phd_migration_recv_buffer(phd_navigator* nav) { return nav ? nav->d_recv : nullptr; }
+
+// Optional, right after phd_step_global_async: copy the slots whose source particle lives on this rank (decided on the
+// device from the global source vector) while the host is still on its way to phd_migration_plan.
+int phd_migration_local_async(phd_navigator* nav, int rank, int world_size)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (world_size < 1 || rank < 0 || rank >= world_size) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_local: bad rank/world");
+	hipSetDevice(nav->device);
+	StepBufs b = make_bufs(nav);
+	timer_begin(nav, T_GR);
+	hipLaunchKernelGGL(k_gather_local, dim3(nav->P), dim3(256), 0, nav->stream, b, nav->d_plan, nav->d_info, rank * nav->P);
+	timer_end(nav, T_GR);
+	HC(hipGetLastError());
+	nav->local_gather_done = true;
+	return PHD_OK;
+}
 
 int phd_migration_pack_async(phd_navigator* nav)
 {
@@ -1228,10 +1255,11 @@ int phd_migration_unpack_async(phd_navigator* nav)
 		HC(hipMemcpyAsync(nav->d_code, nav->h_plan_recv.data(), (size_t) nav->P * 4, hipMemcpyHostToDevice, nav->stream));
 		timer_begin(nav, T_GR);
 		hipLaunchKernelGGL(k_unpack_gather, dim3(nav->P), dim3(256), 0, nav->stream, b, nav->d_code, nav->d_recv,
-		                   1.0 / (double) nav->last_world_particles, sel_next, nav->frozen ? 1 : 0);
+		                   1.0 / (double) nav->last_world_particles, sel_next, nav->frozen ? 1 : 0, nav->local_gather_done ? 1 : 0);
 		timer_end(nav, T_GR);
 		HC(hipGetLastError());
 	}
+	nav->local_gather_done = false;
 	nav->parity ^= 1;
 	nav->stage_valid = false;
 	if (nav->sel_host_valid && !nav->frozen) {   // same rotation as the kernels wrote to the device
