@@ -22,6 +22,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP64_SUSTAINED_TFLOPS = 53.0   # v_fma_f64 over the whole chip, measured (profiles/r01_mfma_f64_probe.txt); nominal 78.6
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 
 
@@ -214,6 +215,21 @@ def main():
                                "particles_per_launch": particles_per_launch, "launches_per_step": per_step[dom]}
             out["kernel_ms"] = kernels
             out["kernel_launches_per_step"] = per_step
+            # The step is bound by vector-ALU issue, not by HBM: the wave-level VALU instructions of one
+            # step (SQ_INSTS_VALU of the committed profile, per particle) against the rate at which the chip sustains
+            # FP64 FMAs (scripts/probes/mfma_f64_rate.hip: 53 TFLOP/s = 4.14e11 wave instructions/s).
+            vfile = os.path.join(ROOT, "profiles", "r01_valu_insts.json")
+            if os.path.exists(vfile):
+                try:
+                    valu = json.load(open(vfile)).get(args.config, {})
+                    insts = sum(v.get("per_particle", 0.0) * P + v.get("per_launch", 0.0) for v in valu.values())
+                    rate = FP64_SUSTAINED_TFLOPS * 1e12 / 128.0
+                    if insts > 0:
+                        out["valu_issue"] = {"wave_instructions_per_step": insts, "sustained_wave_instructions_per_s": rate,
+                                             "bound_ms": insts / rate * 1e3, "frac": insts / rate * 1e3 / ms,
+                                             "source": "profiles/r01_valu_insts.json (rocprofv3 SQ_INSTS_VALU), profiles/r01_mfma_f64_probe.txt"}
+                except Exception:
+                    pass
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 16)
             sample = args.cpu_sample or P

@@ -79,6 +79,17 @@ def main():
                                 if v["hbm_read_bytes"] is not None}
         traffic["_note"] = "HBM bytes per launch = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 (rocprofv3 --pmc, separate passes; gfx950 FETCH_SIZE correction)"
         json.dump(traffic, open(tfile, "w"), indent=1)
+        # vector-ALU instructions per launch (SQ_INSTS_VALU summed over the waves), read by bench.py for the issue-rate view
+        vfile = os.path.join(root, "profiles", "r01_valu_insts.json")
+        valu = json.load(open(vfile)) if os.path.exists(vfile) else {}
+        valu[sys.argv[3]] = {}
+        for k, v in out["kernels"].items():
+            n = v.get("pmc", {}).get("SQ_INSTS_VALU")
+            wgs = (v.get("resources", {}).get("grid") or 0) // max(v.get("resources", {}).get("wg") or 1, 1)
+            if n:   # one workgroup per particle in every kernel but the single-workgroup normalise
+                valu[sys.argv[3]][k] = {"per_particle": n / wgs} if wgs >= 64 else {"per_launch": n}
+        valu["_note"] = "wave-level vector-ALU instructions (rocprofv3 --pmc SQ_INSTS_VALU) per particle (= workgroup) or per launch"
+        json.dump(valu, open(vfile, "w"), indent=1)
     print("\n".join(lines))
 
 
