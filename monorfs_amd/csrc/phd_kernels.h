@@ -5,7 +5,7 @@
 // (w, mean x/y/z, covariance xx/xy/xz/yy/yz/zz), each [particle][slot], so a wavefront reads 64
 // consecutive components of one particle as one 512-B line per plane.
 //
-//   k_explore, k_measure, k_correct, k_emit_finish (phd_correct.h) : PredictConditional + CorrectConditional
+//   k_measure_prior, k_sweep (phd_sweep.h), k_emit_finish (phd_correct.h) : PredictConditional + CorrectConditional
 //                       (+ the MinWeight cut of PruneModel)
 //   k_prune_merge     : PruneModel (sort by weight, MaxQuantity cap, greedy merge)
 //   k_weight_alpha    : WeightAlpha = BestMapEstimate + mixture densities + SetLogLikelihood
@@ -64,11 +64,11 @@ struct StepBufs {
 	int*    flags;       // [1]
 	struct MurtyNodes* murty;   // [P] workspace of the big-cluster solver
 	double* jscratch;    // [P] landmark-indexed arrays of k_weight_alpha when the map estimate outgrows LDS
-	// per-component measurement quantities of the predicted mixture: CM_PLANES planes of [Pcap][cmcap]
+	// per-component measurement quantities of the prior mixture: SW_PLANES planes of [Pcap][cmcap]
 	double* cm;
 	size_t  cmplane;     // doubles per plane = Pcap * cmcap
 	int     cmcap;       // cap + Mcap
-	// (component, measurement) pairs that may reach MinWeight, queued by k_correct for k_emit_finish
+	// (component, measurement) pairs that may reach MinWeight, queued by k_sweep for k_emit_finish
 	int*    cand;        // [P][candcap]
 	int     candcap;
 	int*    cand_count;  // [P] (above candcap: the queue overflowed)
@@ -102,6 +102,8 @@ __device__ __forceinline__ MixView bank_view(const StepBufs& a, int role)
 #define TILE 256   // components staged per LDS tile
 
 #include "phd_correct.h"
+
+#include "phd_sweep.h"
 
 #include "phd_prune.h"
 

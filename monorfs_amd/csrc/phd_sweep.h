@@ -1,0 +1,301 @@
+// phd_sweep.h — PredictConditional and the weight sums of CorrectConditional in one pass over the prior mixture.
+//
+// Both steps visit every (prior component, measurement) pair around the same vector e = MeasureToMap(z) - m:
+//   Explored (PHDNavigator.cs:956-959)      density sum_c w_c N(x_z; m_c, P_c) over |e|^2 <= (3 DDT) gate   -> births
+//   CorrectConditional (:882-890)           weightsum[z] = sum_c PD_c w_c N(z; h(m_c), S_c) over |e|^2 <= DDT gate
+// so k_sweep evaluates both Gaussians per visit and shares e, |e|^2, the staging and the loop; the births it finds are
+// measured, emitted (their misdetection copies) and added to the weight sums in its tail. Per prior component it
+// stages two gauss_logw records: the measurement-space one from the 10 planes of k_measure_prior (h(m) [3], the
+// folded form G [6], lw = log(PD w mult_S)) and the map-space one (m, -P^-1/2 folded, log(w mult_P)) built on the spot.
+#pragma once
+#include "phd_device.h"
+
+#define SW_PLANES 10    // zh[3], G[6], lw: PD w N(z; zh, S) = exp(lw + d^T G d), d = z - zh
+#define SW_TILE   128   // prior components staged per LDS tile
+#define SW_REC    20    // doubles per staged component: zh[3] G[6] lw | m[3] Gm[6] lwm  (two gauss_logw records)
+
+// =================================================================================================
+__global__ __launch_bounds__(256, 3) void k_measure_prior(const DevParams prm, const StepBufs a)
+{
+	__shared__ int s_cnt;
+	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+	const MixView vin = bank_view(a, SEL_IN);
+	const Bank& bin  = a.bank[a.sel[SEL_IN]];
+	const Bank& bout = a.bank[a.sel[SEL_OUT]];
+	const int n = vin.count[p];
+	const PoseD pose = load_pose(bin.poses + (size_t) p * 7);
+	// the particle keeps its pose and (until the reweight kernel runs) its weight in the output bank
+	if (tid < 7) bout.poses[(size_t) p * 7 + tid] = bin.poses[(size_t) p * 7 + tid];
+	if (tid == 7) bout.weights[p] = bin.weights[p];
+	double rq[9];
+	conj_matrix(pose, rq);
+	if (tid == 0) s_cnt = 0;
+	__syncthreads();
+	const size_t cstride = a.cmplane;                       // doubles per plane
+	double* cm = a.cm + (size_t) p * a.cmcap;
+	for (int c0 = 0; c0 < n; c0 += 256) {
+		const int  c = c0 + tid;
+		const bool valid = c < n;
+		double w = 0, m[3] = {0, 0, 0}, P[6] = {1, 0, 0, 1, 0, 1}, wm = 0;
+		bool mis = false;
+		if (valid) {
+			load_predicted(prm, a, vin, p, n, c, w, m, P);
+			CompMeas q;
+			comp_measure(prm, pose, rq, m, P, q);
+			const double pdw = q.pd * w;
+#pragma unroll
+			for (int t = 0; t < 3; t++) cm[(size_t) t * cstride + c] = q.zh[t];
+			// G = -(S^-1 + S^-T) / 4 folded for the upper-triangle sum of gauss_logw
+			cm[(size_t) 3 * cstride + c] = -0.5 * q.Sinv[0];
+			cm[(size_t) 4 * cstride + c] = -0.5 * (q.Sinv[1] + q.Sinv[3]);
+			cm[(size_t) 5 * cstride + c] = -0.5 * (q.Sinv[2] + q.Sinv[6]);
+			cm[(size_t) 6 * cstride + c] = -0.5 * q.Sinv[4];
+			cm[(size_t) 7 * cstride + c] = -0.5 * (q.Sinv[5] + q.Sinv[7]);
+			cm[(size_t) 8 * cstride + c] = -0.5 * q.Sinv[8];
+			cm[(size_t) 9 * cstride + c] = log(pdw * q.qmult);
+			wm  = (1 - q.pd) * w;        // component.Reweight((1 - PD) w), :838-839
+			mis = !(wm < prm.minw);
+		}
+		unsigned long long bal = __ballot(mis);
+		if (bal) {
+			int base = 0, first = __ffsll((long long) bal) - 1;
+			if (lane == first) base = atomicAdd(&s_cnt, __popcll(bal));
+			base = __shfl(base, first, 64);
+			if (mis) {
+				int slot = base + __popcll(bal & lanemask_lt());
+				if (slot < a.ecap) {
+					size_t e = (size_t) p * a.ecap + slot;
+					a.emit_w[e]   = wm;
+					a.emit_idx[e] = c;
+					double* r = a.emit_rec + e * 9;
+					r[0] = m[0]; r[1] = m[1]; r[2] = m[2];
+#pragma unroll
+					for (int t = 0; t < 6; t++) r[3 + t] = P[t];
+				}
+			}
+		}
+	}
+	__syncthreads();
+	if (tid == 0) {
+		int ne = s_cnt;
+		if (ne > a.ecap) { atomicOr(a.flags, PHD_FLAG_EMIT_OVERFLOW); ne = a.ecap; }
+		a.emit_count[p] = ne;
+	}
+}
+
+// =================================================================================================
+template <int ZB>
+__global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const StepBufs a)
+{
+	constexpr int MP = ZB * 64;
+	constexpr int TD = (SW_TILE * SW_REC > MP * 13) ? SW_TILE * SW_REC : MP * 13;
+	__shared__ double zs[3 * MP], zmap[3 * MP];
+	__shared__ double part[4 * MP], part2[4 * MP];
+	__shared__ double tile[TD];                 // [SW_TILE][20] prior components | [births][13] in the tail
+	__shared__ double etab[EXPTAB_N];
+	__shared__ int    born[MP];
+	__shared__ int    s_ncand, s_nb, s_nmis;
+
+	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int M = a.M;
+	const MixView vin = bank_view(a, SEL_IN);
+	const Bank& bin = a.bank[a.sel[SEL_IN]];
+	const int n = vin.count[p];
+	const size_t sb = (size_t) p * a.cap;
+	const PoseD pose = load_pose(bin.poses + (size_t) p * 7);
+	exp_tab_init(etab, tid);
+	if (tid == 0) { s_ncand = 0; s_nb = 0; s_nmis = 0; }
+	for (int k = tid; k < MP; k += 256) {
+		double z[3] = {0, 0, 1}, x[3] = {0, 0, 0};
+		if (k < M) {
+			z[0] = a.z[k * 3]; z[1] = a.z[k * 3 + 1]; z[2] = a.z[k * 3 + 2];
+			measure_to_map(prm, pose, z, x);
+		}
+		zs[k * 3] = z[0]; zs[k * 3 + 1] = z[1]; zs[k * 3 + 2] = z[2];
+		zmap[k * 3] = x[0]; zmap[k * 3 + 1] = x[1]; zmap[k * 3 + 2] = x[2];
+	}
+	__syncthreads();
+	double zx[ZB], zy[ZB], zr[ZB], wx[ZB], wy[ZB], wz[ZB], wsum[ZB], dens[ZB];
+	bool   zv[ZB];
+#pragma unroll
+	for (int b = 0; b < ZB; b++) {
+		int k = b * 64 + lane;
+		zv[b] = k < M;
+		zx[b] = zs[k * 3]; zy[b] = zs[k * 3 + 1]; zr[b] = zs[k * 3 + 2];
+		wx[b] = zmap[k * 3]; wy[b] = zmap[k * 3 + 1]; wz[b] = zmap[k * 3 + 2];
+		wsum[b] = 0; dens[b] = 0;
+	}
+	const double g2c = prm.g2_correct, g2e = prm.g2_explore, thr = prm.expl_thr;
+	const size_t cstride = a.cmplane;
+	const double* cm = a.cm + (size_t) p * a.cmcap;
+	int2* cands = (int2*) a.cand + (size_t) p * a.candcap;   // (component << 8 | measurement, exponent as float32) of the pairs worth a second look
+
+	// a pair can only reach MinWeight when PD w q(z) >= MinWeight kappa, i.e. its exponent reaches emit_log_floor (half a
+	// unit of margin for the rounding of the folded form): those are queued for k_emit_finish
+	const double xcut = prm.emit_log_floor - 0.5;
+	// the weight-sum part of a visit: component record tt = [zh(3) G(6) lw], squared distance in map space sq
+	auto weigh = [&](const double* tt, int b, double sq, int c) {
+		double x = gauss_logw(tt, zx[b] - tt[0], zy[b] - tt[1], zr[b] - tt[2]);
+		double v = exp_neg(x, etab);   // PD w * mc.Evaluate(z)
+		const bool near = zv[b] && sq <= g2c;
+		if (near) wsum[b] += v;
+		const bool cand = near && x >= xcut;
+		unsigned long long bal = __ballot(cand);
+		if (bal) {
+			int base = 0, first = __ffsll((long long) bal) - 1;
+			if (lane == first) base = atomicAdd(&s_ncand, __popcll(bal));
+			base = __shfl(base, first, 64);
+			if (cand) {
+				int slot = base + __popcll(bal & lanemask_lt());
+				if (slot < a.candcap) cands[slot] = make_int2((c << 8) | (b * 64 + lane), __float_as_int((float) x));
+			}
+		}
+	};
+
+	// ---- prior components: Explored density and weight sums together. Every term of the density is >= 0, so a wave
+	// whose partial sums already reach the threshold for all of its measurements drops the density part.
+	bool explored = false;
+	for (int c0 = 0; c0 < n; c0 += SW_TILE) {
+		{   // two threads per component: waves 0-1 build its map-space record from (w, m, P), waves 2-3 fetch its planes
+			const int cl = tid & (SW_TILE - 1), c = c0 + cl;
+			if (c < n) {
+				double* tt = tile + cl * SW_REC;
+				if (tid < SW_TILE) {
+					double P[6], Pi[6], det;
+#pragma unroll
+					for (int t = 0; t < 6; t++) P[t] = vin.P[t][sb + c];
+					inv_sym3(P, Pi, det);
+					const double m[3] = {vin.m[0][sb + c], vin.m[1][sb + c], vin.m[2][sb + c]};
+					gauss_record(vin.w[sb + c], m, Pi, PHD_INV_2PI / sqrt(fabs(det)), tt + 10);
+				}
+				else {
+#pragma unroll
+					for (int t = 0; t < 10; t++) tt[t] = cm[(size_t) t * cstride + c];
+				}
+			}
+		}
+		__syncthreads();
+		const int cend = min(SW_TILE, n - c0);
+		auto visit = [&](int cc) {
+			const double* tt = tile + cc * SW_REC;
+#pragma unroll
+			for (int b = 0; b < ZB; b++) {
+				double e0 = wx[b] - tt[10], e1 = wy[b] - tt[11], e2 = wz[b] - tt[12];
+				double sq = e0 * e0 + e1 * e1 + e2 * e2;
+				if (!explored) {
+					// w * N(x; m, P) of the component at MeasureToMap(z), inside the radius gate (Map.cs:214-217)
+					double vm = exp_neg(gauss_logw(tt + 10, e0, e1, e2), etab);
+					if (zv[b] && sq <= g2e) dens[b] += vm;
+				}
+				weigh(tt, b, sq, c0 + cc);
+			}
+		};
+		int cc = wv;
+		for (; cc + 4 < cend; cc += 8) { visit(cc); visit(cc + 4); }
+		if (cc < cend) visit(cc);
+		if (!explored) {
+			bool open = false;
+#pragma unroll
+			for (int b = 0; b < ZB; b++) open |= zv[b] && !(dens[b] >= thr);
+			explored = __ballot(open) == 0;
+		}
+		__syncthreads();
+	}
+
+	// ---- births (:806-818): measurements whose density stays below the threshold, in measurement order
+#pragma unroll
+	for (int b = 0; b < ZB; b++) part2[wv * MP + b * 64 + lane] = dens[b];
+	__syncthreads();
+	for (int k = tid; k < MP; k += 256) {
+		double d = part2[k] + part2[MP + k] + part2[2 * MP + k] + part2[3 * MP + k];
+		born[k] = (k < M) && !(d >= thr);   // !Explored (:808, :958)
+	}
+	__syncthreads();
+	if (tid == 0) {
+		int nb = 0;
+		for (int k = 0; k < M; k++) {
+			if (born[k]) {
+				a.born_k[(size_t) p * a.Mcap + nb] = k;
+				a.born_mean[((size_t) p * a.Mcap + nb) * 3]     = zmap[k * 3];
+				a.born_mean[((size_t) p * a.Mcap + nb) * 3 + 1] = zmap[k * 3 + 1];
+				a.born_mean[((size_t) p * a.Mcap + nb) * 3 + 2] = zmap[k * 3 + 2];
+				born[nb] = k;   // nb <= k: entries below k are already consumed
+				nb++;
+			}
+		}
+		a.born_count[p] = nb;
+		s_nb = nb;
+	}
+	__syncthreads();
+	const int nb = s_nb;
+	// the births as components n .. n + nb - 1 of the predicted mixture: measured by one thread each (records in LDS),
+	// their misdetection copies emitted behind those of the prior components
+	const int nmis0 = a.emit_count[p];
+	{
+		double rq[9];
+		conj_matrix(pose, rq);
+		for (int b0 = 0; b0 < nb; b0 += 256) {
+			const int bi = b0 + tid;
+			bool mis = false;
+			double wm = 0, m[3] = {0, 0, 0};
+			if (bi < nb) {
+				const int k = born[bi];
+				m[0] = zmap[k * 3]; m[1] = zmap[k * 3 + 1]; m[2] = zmap[k * 3 + 2];
+				CompMeas q;
+				comp_measure(prm, pose, rq, m, prm.birthP, q);
+				double* tt = tile + bi * 13;
+				tt[0] = q.zh[0]; tt[1] = q.zh[1]; tt[2] = q.zh[2];
+				tt[3] = -0.5 * q.Sinv[0];
+				tt[4] = -0.5 * (q.Sinv[1] + q.Sinv[3]);
+				tt[5] = -0.5 * (q.Sinv[2] + q.Sinv[6]);
+				tt[6] = -0.5 * q.Sinv[4];
+				tt[7] = -0.5 * (q.Sinv[5] + q.Sinv[7]);
+				tt[8] = -0.5 * q.Sinv[8];
+				tt[9] = log(q.pd * prm.birthw * q.qmult);
+				tt[10] = m[0]; tt[11] = m[1]; tt[12] = m[2];
+				wm  = (1 - q.pd) * prm.birthw;
+				mis = !(wm < prm.minw);
+			}
+			unsigned long long bal = __ballot(mis);
+			if (bal) {
+				int base = 0, first = __ffsll((long long) bal) - 1;
+				if (lane == first) base = atomicAdd(&s_nmis, __popcll(bal));
+				base = __shfl(base, first, 64);
+				if (mis) {
+					int slot = nmis0 + base + __popcll(bal & lanemask_lt());
+					if (slot < a.ecap) {
+						size_t e = (size_t) p * a.ecap + slot;
+						a.emit_w[e]   = wm;
+						a.emit_idx[e] = n + bi;
+						double* r = a.emit_rec + e * 9;
+						r[0] = m[0]; r[1] = m[1]; r[2] = m[2];
+#pragma unroll
+						for (int t = 0; t < 6; t++) r[3 + t] = prm.birthP[t];
+					}
+				}
+			}
+		}
+	}
+	__syncthreads();
+	// the births' share of the weight sums (they were born from this frame's measurements: :804, :886-890)
+	for (int bi = (wv - n) & 3; bi < nb; bi += 4) {   // component n + bi belongs to wave (n + bi) mod 4, as the prior ones do
+		const double* tt = tile + bi * 13;
+#pragma unroll
+		for (int b = 0; b < ZB; b++) {
+			double e0 = wx[b] - tt[10], e1 = wy[b] - tt[11], e2 = wz[b] - tt[12];
+			weigh(tt, b, e0 * e0 + e1 * e1 + e2 * e2, n + bi);
+		}
+	}
+#pragma unroll
+	for (int b = 0; b < ZB; b++) part[wv * MP + b * 64 + lane] = wsum[b];
+	__syncthreads();
+	for (int k = tid; k < M; k += 256) {
+		a.denom[(size_t) p * a.Mcap + k] = prm.kappa + (part[k] + part[MP + k] + part[2 * MP + k] + part[3 * MP + k]);
+	}
+	if (tid == 0) {
+		a.cand_count[p] = s_ncand;
+		int ne = nmis0 + s_nmis;
+		if (ne > a.ecap) { atomicOr(a.flags, PHD_FLAG_EMIT_OVERFLOW); ne = a.ecap; }
+		a.emit_count[p] = ne;
+	}
+}

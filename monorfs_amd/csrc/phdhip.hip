@@ -20,6 +20,7 @@ thread_local std::string g_create_error;
 struct Timer {          // one record per kernel launch since the last phd_timing_reset
 	const char* name;
 	hipEvent_t  t0, t1;
+	int         t0_from;   // >= 0: the launch starts where record t0_from ended (back-to-back on one stream: one event, not two)
 };
 
 }  // namespace
@@ -183,8 +184,9 @@ StepBufs make_bufs(phd_navigator* nav)
 int zb_of(int M) { return M <= 64 ? 1 : (M <= 128 ? 2 : 4); }
 
 
-// HIP events around every kernel launch, on the stream the kernel is launched on
-void timer_begin(phd_navigator* nav, const char* name, hipStream_t st = nullptr)
+// HIP events around every kernel launch, on the stream the kernel is launched on. `chained`: the launch follows the
+// previous timed launch on the same stream with nothing in between, so that launch's end event is this one's start.
+void timer_begin(phd_navigator* nav, const char* name, hipStream_t st = nullptr, bool chained = false)
 {
 	if (!st) st = nav->stream;
 	if (!nav->timing) return;
@@ -192,12 +194,14 @@ void timer_begin(phd_navigator* nav, const char* name, hipStream_t st = nullptr)
 		if (nav->timers.size() >= 65536) { nav->timing = false; return; }
 		Timer t;
 		t.name = name;
+		t.t0_from = -1;
 		if (hipEventCreate(&t.t0) != hipSuccess || hipEventCreate(&t.t1) != hipSuccess) { nav->timing = false; return; }
 		nav->timers.push_back(t);
 	}
 	Timer& t = nav->timers[nav->ntimers];
 	t.name = name;
-	hipEventRecord(t.t0, st);
+	t.t0_from = (chained && nav->ntimers > 0) ? (int) nav->ntimers - 1 : -1;
+	if (t.t0_from < 0) hipEventRecord(t.t0, st);
 }
 
 void timer_end(phd_navigator* nav, const char* name, hipStream_t st = nullptr)
@@ -208,9 +212,8 @@ void timer_end(phd_navigator* nav, const char* name, hipStream_t st = nullptr)
 	nav->ntimers++;
 }
 
-const char* T_EX = "k_explore";
-const char* T_ME = "k_measure";
-const char* T_CO = "k_correct";
+const char* T_MP = "k_measure_prior";
+const char* T_SW = "k_sweep";
 const char* T_EF = "k_emit_finish";
 const char* T_PM = "k_prune_merge";
 const char* T_WA = "k_alpha_assoc";
@@ -242,26 +245,23 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha)
 		const int n = (int) ((long long) P * (s + 1) / S) - b.p0;
 		if (n <= 0) continue;
 		hipStream_t st = s == 0 ? nav->stream : nav->aux[s - 1];
-		timer_begin(nav, T_EX, st);
-		hipLaunchKernelGGL(k_explore<ZB>, dim3(n), dim3(256), 0, st, nav->dp, b);
-		timer_end(nav, T_EX, st);
-		timer_begin(nav, T_ME, st);
-		hipLaunchKernelGGL(k_measure, dim3(n), dim3(256), 0, st, nav->dp, b);
-		timer_end(nav, T_ME, st);
-		timer_begin(nav, T_CO, st);
-		hipLaunchKernelGGL(k_correct<ZB>, dim3(n), dim3(256), 0, st, nav->dp, b);
-		timer_end(nav, T_CO, st);
-		timer_begin(nav, T_EF, st);
+		timer_begin(nav, T_MP, st);
+		hipLaunchKernelGGL(k_measure_prior, dim3(n), dim3(256), 0, st, nav->dp, b);
+		timer_end(nav, T_MP, st);
+		timer_begin(nav, T_SW, st, true);
+		hipLaunchKernelGGL(k_sweep<ZB>, dim3(n), dim3(256), 0, st, nav->dp, b);
+		timer_end(nav, T_SW, st);
+		timer_begin(nav, T_EF, st, true);
 		hipLaunchKernelGGL(k_emit_finish, dim3(n), dim3(256), 0, st, nav->dp, b);
 		timer_end(nav, T_EF, st);
-		timer_begin(nav, T_PM, st);
+		timer_begin(nav, T_PM, st, true);
 		hipLaunchKernelGGL(k_prune_merge, dim3(n), dim3(256), lp, st, nav->dp, b, nav->cutcap);
 		timer_end(nav, T_PM, st);
 		if (with_alpha) {
-			timer_begin(nav, T_WA, st);
+			timer_begin(nav, T_WA, st, true);
 			hipLaunchKernelGGL(k_alpha_assoc<ZB>, dim3(n), dim3(256), lay.bytes, st, nav->dp, b, nav->cutcap);
 			timer_end(nav, T_WA, st);
-				timer_begin(nav, T_WD, st);
+				timer_begin(nav, T_WD, st, true);
 			hipLaunchKernelGGL(k_alpha_density, dim3(n), dim3(256), 0, st, nav->dp, b);
 			timer_end(nav, T_WD, st);
 		}
@@ -497,7 +497,7 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	ok = ok && dalloc((void**) &nav->d_src, (size_t) nav->Pcap * 4);
 	ok = ok && dalloc((void**) &nav->d_murty, (size_t) nav->Pcap * sizeof(MurtyNodes));
 	nav->cmcap = nav->cap + nav->Mcap;
-	ok = ok && dalloc((void**) &nav->d_cm, (size_t) CM_PLANES * nav->Pcap * nav->cmcap * 8);
+	ok = ok && dalloc((void**) &nav->d_cm, (size_t) SW_PLANES * nav->Pcap * nav->cmcap * 8);
 	ok = ok && dalloc((void**) &nav->d_cand_count, (size_t) nav->Pcap * 4) && dalloc((void**) &nav->d_denom, (size_t) nav->Pcap * nav->Mcap * 8);
 	nav->candcap = 16 * nav->cmcap;   // a quarter of all pairs at 64 measurements; beyond it the full second sweep runs
 	ok = ok && dalloc((void**) &nav->d_cand, (size_t) nav->Pcap * nav->candcap * 8);
@@ -749,7 +749,7 @@ int phd_step_async(phd_navigator* nav, uint8_t onlymapping, double u_resample)
 	timer_end(nav, T_NR);
 	if (rc) return rc;
 	int* sel_next = nav->d_sel + (nav->parity ^ 1) * 4;
-	timer_begin(nav, T_GR);
+	timer_begin(nav, T_GR, nullptr, true);
 	hipLaunchKernelGGL(k_gather_rotate, dim3(nav->P), dim3(256), 0, nav->stream, b, nav->d_src, nav->d_info, 0, sel_next,
 	                   nav->frozen ? 1 : 0);
 	timer_end(nav, T_GR);
@@ -1026,7 +1026,7 @@ int phd_last_timings(phd_navigator* nav, const char*** names, const double** ms)
 	for (size_t r = 0; r < nav->ntimers; r++) {
 		Timer& t = nav->timers[r];
 		float f = 0;
-		if (hipEventElapsedTime(&f, t.t0, t.t1) != hipSuccess) continue;
+		if (hipEventElapsedTime(&f, t.t0_from >= 0 ? nav->timers[t.t0_from].t1 : t.t0, t.t1) != hipSuccess) continue;
 		size_t k = 0;
 		for (; k < nav->tnames.size(); k++) {
 			if (nav->tnames[k] == t.name) break;

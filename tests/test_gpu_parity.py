@@ -72,7 +72,7 @@ CASES = [
     (3, 50, 10, 16, "steady", {"gate_metric": PHD_GATE_DISABLED}),
     (3, 0, 9, 17, "steady", {}),                         # empty map: every measurement is born
     (3, 33, 0, 18, "steady", {}),                        # no measurements
-    # MinWeight 0: every gated pair is a candidate, the candidate queue of k_correct overflows and its
+    # MinWeight 0: every gated pair is a candidate, the candidate queue of k_sweep overflows and the
     # all-pairs fallback runs; nothing is cut before the merge
     (2, 30, 24, 19, "steady", {"min_weight": 0.0, "emit_capacity": 4096}),
 ]
