@@ -64,10 +64,6 @@ struct StepBufs {
 	int*    flags;       // [1]
 	struct MurtyNodes* murty;   // [P] workspace of the big-cluster solver
 	double* jscratch;    // [P] landmark-indexed arrays of k_weight_alpha when the map estimate outgrows LDS
-	// per-component measurement quantities of the prior mixture: SW_PLANES planes of [Pcap][cmcap]
-	double* cm;
-	size_t  cmplane;     // doubles per plane = Pcap * cmcap
-	int     cmcap;       // cap + Mcap
 	// (component, measurement) pairs that may reach MinWeight, queued by k_sweep for k_emit_finish
 	int*    cand;        // [P][candcap]
 	int     candcap;

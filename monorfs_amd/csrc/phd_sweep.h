@@ -3,85 +3,17 @@
 // Both steps visit every (prior component, measurement) pair around the same vector e = MeasureToMap(z) - m:
 //   Explored (PHDNavigator.cs:956-959)      density sum_c w_c N(x_z; m_c, P_c) over |e|^2 <= (3 DDT) gate   -> births
 //   CorrectConditional (:882-890)           weightsum[z] = sum_c PD_c w_c N(z; h(m_c), S_c) over |e|^2 <= DDT gate
-// so k_sweep evaluates both Gaussians per visit and shares e, |e|^2, the staging and the loop; the births it finds are
-// measured, emitted (their misdetection copies) and added to the weight sums in its tail. Per prior component it
-// stages two gauss_logw records: the measurement-space one from the 10 planes of k_measure_prior (h(m) [3], the
-// folded form G [6], lw = log(PD w mult_S)) and the map-space one (m, -P^-1/2 folded, log(w mult_P)) built on the spot.
+// so k_sweep evaluates both Gaussians per visit and shares e, |e|^2, the staging and the loop. Per prior component it
+// stages two gauss_logw records, both built on the spot from (w, m, P): the map-space one (m, -P^-1/2 folded,
+// log(w mult_P)) by waves 0-1 and the measurement-space one (h(m), -(S^-1 + S^-T)/4 folded, log(PD w mult_S); :857-870)
+// by waves 2-3, which also emit the component's misdetection copy w (1 - PD) (:837-840) when it reaches MinWeight.
+// The births it finds are measured, emitted and added to the weight sums in its tail. Nothing per component goes
+// through HBM between the prior mixture and the emitted list.
 #pragma once
 #include "phd_device.h"
 
-#define SW_PLANES 10    // zh[3], G[6], lw: PD w N(z; zh, S) = exp(lw + d^T G d), d = z - zh
 #define SW_TILE   128   // prior components staged per LDS tile
 #define SW_REC    20    // doubles per staged component: zh[3] G[6] lw | m[3] Gm[6] lwm  (two gauss_logw records)
-
-// =================================================================================================
-__global__ __launch_bounds__(256, 3) void k_measure_prior(const DevParams prm, const StepBufs a)
-{
-	__shared__ int s_cnt;
-	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-	const MixView vin = bank_view(a, SEL_IN);
-	const Bank& bin  = a.bank[a.sel[SEL_IN]];
-	const Bank& bout = a.bank[a.sel[SEL_OUT]];
-	const int n = vin.count[p];
-	const PoseD pose = load_pose(bin.poses + (size_t) p * 7);
-	// the particle keeps its pose and (until the reweight kernel runs) its weight in the output bank
-	if (tid < 7) bout.poses[(size_t) p * 7 + tid] = bin.poses[(size_t) p * 7 + tid];
-	if (tid == 7) bout.weights[p] = bin.weights[p];
-	double rq[9];
-	conj_matrix(pose, rq);
-	if (tid == 0) s_cnt = 0;
-	__syncthreads();
-	const size_t cstride = a.cmplane;                       // doubles per plane
-	double* cm = a.cm + (size_t) p * a.cmcap;
-	for (int c0 = 0; c0 < n; c0 += 256) {
-		const int  c = c0 + tid;
-		const bool valid = c < n;
-		double w = 0, m[3] = {0, 0, 0}, P[6] = {1, 0, 0, 1, 0, 1}, wm = 0;
-		bool mis = false;
-		if (valid) {
-			load_predicted(prm, a, vin, p, n, c, w, m, P);
-			CompMeas q;
-			comp_measure(prm, pose, rq, m, P, q);
-			const double pdw = q.pd * w;
-#pragma unroll
-			for (int t = 0; t < 3; t++) cm[(size_t) t * cstride + c] = q.zh[t];
-			// G = -(S^-1 + S^-T) / 4 folded for the upper-triangle sum of gauss_logw
-			cm[(size_t) 3 * cstride + c] = -0.5 * q.Sinv[0];
-			cm[(size_t) 4 * cstride + c] = -0.5 * (q.Sinv[1] + q.Sinv[3]);
-			cm[(size_t) 5 * cstride + c] = -0.5 * (q.Sinv[2] + q.Sinv[6]);
-			cm[(size_t) 6 * cstride + c] = -0.5 * q.Sinv[4];
-			cm[(size_t) 7 * cstride + c] = -0.5 * (q.Sinv[5] + q.Sinv[7]);
-			cm[(size_t) 8 * cstride + c] = -0.5 * q.Sinv[8];
-			cm[(size_t) 9 * cstride + c] = log(pdw * q.qmult);
-			wm  = (1 - q.pd) * w;        // component.Reweight((1 - PD) w), :838-839
-			mis = !(wm < prm.minw);
-		}
-		unsigned long long bal = __ballot(mis);
-		if (bal) {
-			int base = 0, first = __ffsll((long long) bal) - 1;
-			if (lane == first) base = atomicAdd(&s_cnt, __popcll(bal));
-			base = __shfl(base, first, 64);
-			if (mis) {
-				int slot = base + __popcll(bal & lanemask_lt());
-				if (slot < a.ecap) {
-					size_t e = (size_t) p * a.ecap + slot;
-					a.emit_w[e]   = wm;
-					a.emit_idx[e] = c;
-					double* r = a.emit_rec + e * 9;
-					r[0] = m[0]; r[1] = m[1]; r[2] = m[2];
-#pragma unroll
-					for (int t = 0; t < 6; t++) r[3 + t] = P[t];
-				}
-			}
-		}
-	}
-	__syncthreads();
-	if (tid == 0) {
-		int ne = s_cnt;
-		if (ne > a.ecap) { atomicOr(a.flags, PHD_FLAG_EMIT_OVERFLOW); ne = a.ecap; }
-		a.emit_count[p] = ne;
-	}
-}
 
 // =================================================================================================
 template <int ZB>
@@ -102,7 +34,13 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 	const Bank& bin = a.bank[a.sel[SEL_IN]];
 	const int n = vin.count[p];
 	const size_t sb = (size_t) p * a.cap;
+	const Bank& bout = a.bank[a.sel[SEL_OUT]];
 	const PoseD pose = load_pose(bin.poses + (size_t) p * 7);
+	// the particle keeps its pose and (until the reweight kernel runs) its weight in the output bank
+	if (tid < 7) bout.poses[(size_t) p * 7 + tid] = bin.poses[(size_t) p * 7 + tid];
+	if (tid == 7) bout.weights[p] = bin.weights[p];
+	double rq[9];
+	conj_matrix(pose, rq);
 	exp_tab_init(etab, tid);
 	if (tid == 0) { s_ncand = 0; s_nb = 0; s_nmis = 0; }
 	for (int k = tid; k < MP; k += 256) {
@@ -126,8 +64,6 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 		wsum[b] = 0; dens[b] = 0;
 	}
 	const double g2c = prm.g2_correct, g2e = prm.g2_explore, thr = prm.expl_thr;
-	const size_t cstride = a.cmplane;
-	const double* cm = a.cm + (size_t) p * a.cmcap;
 	int2* cands = (int2*) a.cand + (size_t) p * a.candcap;   // (component << 8 | measurement, exponent as float32) of the pairs worth a second look
 
 	// a pair can only reach MinWeight when PD w q(z) >= MinWeight kappa, i.e. its exponent reaches emit_log_floor (half a
@@ -156,21 +92,55 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 	// whose partial sums already reach the threshold for all of its measurements drops the density part.
 	bool explored = false;
 	for (int c0 = 0; c0 < n; c0 += SW_TILE) {
-		{   // two threads per component: waves 0-1 build its map-space record from (w, m, P), waves 2-3 fetch its planes
+		{   // two threads per component: waves 0-1 build its map-space record, waves 2-3 its measurement-space record
 			const int cl = tid & (SW_TILE - 1), c = c0 + cl;
+			bool mis = false;
+			double wm = 0, m[3] = {0, 0, 0}, P[6] = {1, 0, 0, 1, 0, 1};
 			if (c < n) {
 				double* tt = tile + cl * SW_REC;
-				if (tid < SW_TILE) {
-					double P[6], Pi[6], det;
 #pragma unroll
-					for (int t = 0; t < 6; t++) P[t] = vin.P[t][sb + c];
+				for (int t = 0; t < 6; t++) P[t] = vin.P[t][sb + c];
+#pragma unroll
+				for (int t = 0; t < 3; t++) m[t] = vin.m[t][sb + c];
+				const double w = vin.w[sb + c];
+				if (tid < SW_TILE) {
+					double Pi[6], det;
 					inv_sym3(P, Pi, det);
-					const double m[3] = {vin.m[0][sb + c], vin.m[1][sb + c], vin.m[2][sb + c]};
-					gauss_record(vin.w[sb + c], m, Pi, PHD_INV_2PI / sqrt(fabs(det)), tt + 10);
+					gauss_record(w, m, Pi, PHD_INV_2PI / sqrt(fabs(det)), tt + 10);
 				}
 				else {
+					CompMeas q;
+					comp_measure(prm, pose, rq, m, P, q);
+					tt[0] = q.zh[0]; tt[1] = q.zh[1]; tt[2] = q.zh[2];
+					tt[3] = -0.5 * q.Sinv[0];
+					tt[4] = -0.5 * (q.Sinv[1] + q.Sinv[3]);
+					tt[5] = -0.5 * (q.Sinv[2] + q.Sinv[6]);
+					tt[6] = -0.5 * q.Sinv[4];
+					tt[7] = -0.5 * (q.Sinv[5] + q.Sinv[7]);
+					tt[8] = -0.5 * q.Sinv[8];
+					tt[9] = log(q.pd * w * q.qmult);
+					wm  = (1 - q.pd) * w;        // component.Reweight((1 - PD) w), :838-839
+					mis = !(wm < prm.minw);
+				}
+			}
+			if (tid >= SW_TILE) {   // (wave-uniform) the misdetection copies that survive MinWeight
+				unsigned long long bal = __ballot(mis);
+				if (bal) {
+					int base = 0, first = __ffsll((long long) bal) - 1;
+					if (lane == first) base = atomicAdd(&s_nmis, __popcll(bal));
+					base = __shfl(base, first, 64);
+					if (mis) {
+						int slot = base + __popcll(bal & lanemask_lt());
+						if (slot < a.ecap) {
+							size_t e = (size_t) p * a.ecap + slot;
+							a.emit_w[e]   = wm;
+							a.emit_idx[e] = c;
+							double* r = a.emit_rec + e * 9;
+							r[0] = m[0]; r[1] = m[1]; r[2] = m[2];
 #pragma unroll
-					for (int t = 0; t < 10; t++) tt[t] = cm[(size_t) t * cstride + c];
+							for (int t = 0; t < 6; t++) r[3 + t] = P[t];
+						}
+					}
 				}
 			}
 		}
@@ -230,10 +200,11 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 	const int nb = s_nb;
 	// the births as components n .. n + nb - 1 of the predicted mixture: measured by one thread each (records in LDS),
 	// their misdetection copies emitted behind those of the prior components
-	const int nmis0 = a.emit_count[p];
+	const int nmis0 = s_nmis;   // copies of the prior components (every thread reads it before the births add theirs)
+	__syncthreads();
+	if (tid == 0) s_nmis = 0;
+	__syncthreads();
 	{
-		double rq[9];
-		conj_matrix(pose, rq);
 		for (int b0 = 0; b0 < nb; b0 += 256) {
 			const int bi = b0 + tid;
 			bool mis = false;

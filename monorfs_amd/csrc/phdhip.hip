@@ -52,7 +52,7 @@ struct phd_navigator {
 	int*    d_flags = nullptr; int* d_src = nullptr; int* d_info = nullptr;
 	MurtyNodes* d_murty = nullptr;
 	double* d_jscratch = nullptr;
-	double* d_cm = nullptr; int cmcap = 0;
+	int cmcap = 0;
 	int* d_cand_count = nullptr; double* d_denom = nullptr;
 	int* d_cand = nullptr; int candcap = 0;
 	double* d_alm = nullptr; int* d_aJ = nullptr; double* d_account = nullptr;
@@ -174,7 +174,6 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.emit_w = nav->d_emit_w; b.emit_idx = nav->d_emit_idx; b.emit_rec = nav->d_emit_rec; b.emit_count = nav->d_emit_count;
 	b.born_count = nav->d_born_count; b.born_k = nav->d_born_k; b.born_mean = nav->d_born_mean;
 	b.alpha = nav->d_alpha; b.setll = nav->d_setll; b.flags = nav->d_flags; b.murty = nav->d_murty; b.jscratch = nav->d_jscratch;
-	b.cm = nav->d_cm; b.cmcap = nav->cmcap; b.cmplane = (size_t) nav->Pcap * nav->cmcap;
 	b.cand_count = nav->d_cand_count; b.denom = nav->d_denom;
 	b.cand = nav->d_cand; b.candcap = nav->candcap;
 	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account; b.srec = nav->d_srec; b.stamps = nav->d_stamps; b.stamp_kernel = getenv("PHD_STAMP_KERNEL") ? atoi(getenv("PHD_STAMP_KERNEL")) : 2;
@@ -212,7 +211,6 @@ void timer_end(phd_navigator* nav, const char* name, hipStream_t st = nullptr)
 	nav->ntimers++;
 }
 
-const char* T_MP = "k_measure_prior";
 const char* T_SW = "k_sweep";
 const char* T_EF = "k_emit_finish";
 const char* T_PM = "k_prune_merge";
@@ -245,10 +243,7 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha)
 		const int n = (int) ((long long) P * (s + 1) / S) - b.p0;
 		if (n <= 0) continue;
 		hipStream_t st = s == 0 ? nav->stream : nav->aux[s - 1];
-		timer_begin(nav, T_MP, st);
-		hipLaunchKernelGGL(k_measure_prior, dim3(n), dim3(256), 0, st, nav->dp, b);
-		timer_end(nav, T_MP, st);
-		timer_begin(nav, T_SW, st, true);
+		timer_begin(nav, T_SW, st);
 		hipLaunchKernelGGL(k_sweep<ZB>, dim3(n), dim3(256), 0, st, nav->dp, b);
 		timer_end(nav, T_SW, st);
 		timer_begin(nav, T_EF, st, true);
@@ -497,7 +492,6 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	ok = ok && dalloc((void**) &nav->d_src, (size_t) nav->Pcap * 4);
 	ok = ok && dalloc((void**) &nav->d_murty, (size_t) nav->Pcap * sizeof(MurtyNodes));
 	nav->cmcap = nav->cap + nav->Mcap;
-	ok = ok && dalloc((void**) &nav->d_cm, (size_t) SW_PLANES * nav->Pcap * nav->cmcap * 8);
 	ok = ok && dalloc((void**) &nav->d_cand_count, (size_t) nav->Pcap * 4) && dalloc((void**) &nav->d_denom, (size_t) nav->Pcap * nav->Mcap * 8);
 	nav->candcap = 16 * nav->cmcap;   // a quarter of all pairs at 64 measurements; beyond it the full second sweep runs
 	ok = ok && dalloc((void**) &nav->d_cand, (size_t) nav->Pcap * nav->candcap * 8);
@@ -533,7 +527,7 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_sel); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
-	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cm); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
+	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
 	if (nav->h_pin) hipHostFree(nav->h_pin);
 	if (nav->own_stream) hipStreamDestroy(nav->own_stream);
