@@ -1,17 +1,15 @@
-// phd_correct.h — PredictConditional + CorrectConditional (+ the MinWeight cut of PruneModel) as three kernels with
-// small live state each (one workgroup per particle):
+// phd_correct.h — PredictConditional + CorrectConditional (+ the MinWeight cut of PruneModel) as two kernels (one
+// workgroup per particle):
 //
-//   k_measure_prior (phd_sweep.h)  per component of the prior mixture: h(m), S^-1, PD (:857-870) reduced to the 10
-//                   planes the pair sweep needs, and the misdetection copies w (1 - PD) (:837-840) >= MinWeight.
 //   k_sweep<ZB>     (phd_sweep.h)  every (component, measurement) pair once: the Explored density of
-//                   PredictConditional (:793-819, births) and the weight sums of CorrectConditional (:886-890); the
-//                   pairs that can reach MinWeight are queued.
+//                   PredictConditional (:793-819, births), the per-component measurement quantities (:857-870), the
+//                   misdetection copies (:837-840) and the weight sums of CorrectConditional (:886-890); the pairs
+//                   that can reach MinWeight are queued.
 //   k_emit_finish   the queued pairs: w' = PD w q / (kappa + weightsum) (:899) in the reference's own arithmetic
 //                   and, for those that reach MinWeight, the Kalman update (:895-897) m' = m + K nu,
 //                   P' = (I - K H) P.
 //
-// Splitting keeps the hot pair loop free of the register-hungry per-component algebra (a fully fused version
-// needed 252 VGPRs and spilled ~100 SGPRs); the price is the plane scratch, written once and read once.
+// The Kalman algebra stays out of the pair loop: a version with everything in one kernel needed 252 VGPRs.
 #pragma once
 #include "phd_device.h"
 

@@ -5,7 +5,7 @@
 // (w, mean x/y/z, covariance xx/xy/xz/yy/yz/zz), each [particle][slot], so a wavefront reads 64
 // consecutive components of one particle as one 512-B line per plane.
 //
-//   k_measure_prior, k_sweep (phd_sweep.h), k_emit_finish (phd_correct.h) : PredictConditional + CorrectConditional
+//   k_sweep (phd_sweep.h), k_emit_finish (phd_correct.h) : PredictConditional + CorrectConditional
 //                       (+ the MinWeight cut of PruneModel)
 //   k_prune_merge     : PruneModel (sort by weight, MaxQuantity cap, greedy merge)
 //   k_weight_alpha    : WeightAlpha = BestMapEstimate + mixture densities + SetLogLikelihood
