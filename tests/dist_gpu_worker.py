@@ -1,0 +1,102 @@
+"""Worker of tests/test_gpu_multiproc.py: one rank of a sharded SlamUpdate sequence on a real device. All ranks share
+cuda:0 (RCCL refuses two ranks on one GPU), so the two collectives of the step — the all-gather of the particle weights
+and the all-to-all of the migrating particles — run on gloo through host copies of the library's device buffers, with
+exactly the call sequence and split-size conventions bench.py uses over RCCL. Rank 0 also runs the whole particle set in
+one handle and compares."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from monorfs_amd import navigator
+from monorfs_amd.abi import prm3d_defaults
+from monorfs_amd.synth import Frame
+
+
+class Dev:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def dev(ptr, n):
+    return torch.as_tensor(Dev(ptr, n), device="cuda")
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    Pl, Cc, M, steps = 40, 60, 16, 3
+    Pg = Pl * world
+    f = Frame(Pg, Cc, M, 77, weight_profile="steady")
+    planes = f.planes()
+    sl = slice(rank * Pl, (rank + 1) * Pl)
+    p = prm3d_defaults(max_particles=Pl, max_components=600, max_measurements=M)
+    nav = navigator.PHDNavigator(p, particlecount=Pl)
+    nav.upload_state(planes[:, sl], f.counts[sl], f.poses[sl], f.weights[sl])
+    nav.set_measurements(f.z)
+    lib, h = nav._lib, nav._h
+    nav._check(lib.phd_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream), 1))
+    ip = C.POINTER(C.c_int32)
+    scounts, rcounts = np.zeros(world, np.int32), np.zeros(world, np.int32)
+    one = None
+    if rank == 0:
+        p1 = prm3d_defaults(max_particles=Pg, max_components=600, max_measurements=M)
+        one = navigator.PHDNavigator(p1, particlecount=Pg)
+        one.upload_state(planes, f.counts, f.poses, f.weights)
+    nresampled = 0
+    for step in range(steps):
+        u = 0.3 + 0.2 * step
+        nav._check(lib.phd_step_local_async(h, 0))
+        lw = dev(lib.phd_device_local_weights(h), Pl).cpu()
+        gw_host = torch.empty(Pg, dtype=torch.float64)
+        dist.all_gather_into_tensor(gw_host, lw)
+        dev(lib.phd_device_global_weights(h, Pg), Pg).copy_(gw_host)
+        nav._check(lib.phd_step_global_async(h, rank, world, C.c_double(u)))
+        if step % 2 == 0:
+            nav._check(lib.phd_migration_local_async(h, rank, world))
+        nav._check(lib.phd_migration_plan(h, rank, world, scounts.ctypes.data_as(ip), rcounts.ctypes.data_as(ip)))
+        nav._check(lib.phd_migration_pack_async(h))
+        bpp = C.c_int64(0)
+        sptr = lib.phd_migration_send_buffer(h, C.byref(bpp))
+        rptr = lib.phd_migration_recv_buffer(h)
+        rec = bpp.value // 8
+        ns, nr = int(scounts.sum()), int(rcounts.sum())
+        send = dev(sptr, ns * rec).cpu() if ns else torch.empty(0, dtype=torch.float64)
+        recv = torch.empty(nr * rec, dtype=torch.float64)
+        dist.all_to_all_single(recv, send, (rcounts * rec).tolist(), (scounts * rec).tolist())
+        if nr:
+            dev(rptr, nr * rec).copy_(recv)
+        nav._check(lib.phd_migration_unpack_async(h))
+        nav.sync()
+        # everything of the sharded state goes to rank 0
+        w_all = [None] * world
+        dist.gather_object((nav.VehicleWeights, nav.poses(), [nav.MapModel(i) for i in (0, Pl // 2, Pl - 1)], int(ns), int(nr)),
+                           w_all if rank == 0 else None, dst=0)
+        if rank == 0:
+            one.SlamUpdate(None, f.z, u_resample=u)
+            nresampled += bool(one.resample_sources()[1])
+            assert np.array_equal(one.VehicleWeights, np.concatenate([x[0] for x in w_all])), "step %d: weights differ" % step
+            assert np.array_equal(one.poses(), np.concatenate([x[1] for x in w_all])), "step %d: poses differ" % step
+            for r in range(world):
+                for j, i in enumerate((0, Pl // 2, Pl - 1)):
+                    a_, b_ = one.MapModel(r * Pl + i), w_all[r][2][j]
+                    assert all(np.array_equal(x, y) for x, y in zip(a_, b_)), "step %d rank %d particle %d" % (step, r, i)
+            moved = sum(x[3] for x in w_all)
+            assert moved == sum(x[4] for x in w_all)
+            print("step %d ok: %d particles migrated between ranks" % (step, moved), flush=True)
+    if rank == 0:
+        assert nresampled > 0, "no step resampled: the migration path was not exercised"
+        print("multiproc ok")
+        one.close()
+    nav.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
