@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="particles in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP events")
+    ap.add_argument("--events-every", type=int, default=4, help="time the launches of every n-th step of the timed region (each event costs the device a few microseconds)")
     ap.add_argument("--force-dist", action="store_true", help="take the sharded (RCCL) step path even with one rank (rehearsal)")
     return ap.parse_args()
 
@@ -169,7 +170,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    nav.timing_reset(not args.no_events)
+    nav.timing_reset(0 if args.no_events else max(1, min(args.events_every, 255)))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -197,7 +198,8 @@ def main():
         if kernels:
             # the step's per-particle kernels run once per particle sub-range (phd_set_split): a kernel's cost per
             # step is its mean launch duration x launches per step, and the dominant kernel is the largest of those
-            per_step = {k: launches[k] / args.steps for k in kernels}
+            timed_steps = len(range(0, args.steps, max(1, min(args.events_every, 255))))
+            per_step = {k: launches[k] / timed_steps for k in kernels}
             dom = max(kernels, key=lambda k: kernels[k] * per_step[k])
             particles_per_launch = P / per_step[dom]
             alg_bytes = 160.0 * particles_per_launch * Cc   # 80 B/component read + 80 B written, per particle
@@ -215,6 +217,7 @@ def main():
                                "particles_per_launch": particles_per_launch, "launches_per_step": per_step[dom]}
             out["kernel_ms"] = kernels
             out["kernel_launches_per_step"] = per_step
+            out["kernel_ms_sampling"] = "HIP events on every %d-th step of the timed region (%d of %d steps)" % (max(1, min(args.events_every, 255)), timed_steps, args.steps)
             # The step is bound by vector-ALU issue, not by HBM: the wave-level VALU instructions of one
             # step (SQ_INSTS_VALU of the committed profile, per particle) against the rate at which the chip sustains
             # FP64 FMAs (scripts/probes/mfma_f64_rate.hip: 53 TFLOP/s = 4.14e11 wave instructions/s).

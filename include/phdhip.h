@@ -224,7 +224,8 @@ int phd_quasi_set_loglik(phd_navigator* nav, const double* poses7, int nposes, c
 
 /* Per-kernel device time in milliseconds, from HIP events recorded around every launch on the
  * handle's stream: the mean over the launches since the last phd_timing_reset; names[i] -> ms[i];
- * returns the number of entries. phd_timing_reset(nav, 0) switches the events off.               */
+ * returns the number of entries. phd_timing_reset(nav, 0) switches the events off; (nav, n) times every n-th
+ * step only (an event costs the device a few microseconds).                                      */
 int phd_timing_reset(phd_navigator* nav, uint8_t enabled);
 int phd_last_timings(phd_navigator* nav, const char*** names, const double** ms);
 /* Launches behind each mean of the last phd_last_timings call, same order (a split step launches a kernel

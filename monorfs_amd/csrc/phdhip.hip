@@ -81,6 +81,9 @@ struct phd_navigator {
 	std::vector<Timer>       timers;    // event pool; [0, ntimers) are live records
 	size_t                   ntimers = 0;
 	bool                     timing = true;
+	int                      timing_period = 1;   // launches are timed on every timing_period-th step
+	long long                timing_step = 0;
+	bool                     timing_now = true;
 	std::vector<const char*> tnames;
 	std::vector<double>      tms;
 	std::vector<int>         tcounts;
@@ -188,7 +191,7 @@ int zb_of(int M) { return M <= 64 ? 1 : (M <= 128 ? 2 : 4); }
 void timer_begin(phd_navigator* nav, const char* name, hipStream_t st = nullptr, bool chained = false)
 {
 	if (!st) st = nav->stream;
-	if (!nav->timing) return;
+	if (!nav->timing || !nav->timing_now) return;
 	if (nav->ntimers == nav->timers.size()) {
 		if (nav->timers.size() >= 65536) { nav->timing = false; return; }
 		Timer t;
@@ -206,7 +209,7 @@ void timer_begin(phd_navigator* nav, const char* name, hipStream_t st = nullptr,
 void timer_end(phd_navigator* nav, const char* name, hipStream_t st = nullptr)
 {
 	if (!st) st = nav->stream;
-	if (!nav->timing || nav->ntimers >= nav->timers.size()) return;
+	if (!nav->timing || !nav->timing_now || nav->ntimers >= nav->timers.size()) return;
 	hipEventRecord(nav->timers[nav->ntimers].t1, st);
 	nav->ntimers++;
 }
@@ -735,6 +738,7 @@ int phd_step_async(phd_navigator* nav, uint8_t onlymapping, double u_resample)
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	if (nav->P < 1) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step: no particles (call phd_reset first)");
 	hipSetDevice(nav->device);
+	nav->timing_now = (nav->timing_step++ % nav->timing_period) == 0;
 	StepBufs b = make_bufs(nav);
 	int rc = launch_map(nav, b, !onlymapping);
 	if (rc) return rc;
@@ -1006,6 +1010,9 @@ int phd_timing_reset(phd_navigator* nav, uint8_t enabled)
 	hipStreamSynchronize(nav->stream);
 	nav->ntimers = 0;
 	nav->timing = enabled != 0;
+	nav->timing_period = enabled ? enabled : 1;   // 1: every step; n: every n-th step (sampling keeps the events' own cost small)
+	nav->timing_step = 0;
+	nav->timing_now = true;
 	return PHD_OK;
 }
 
@@ -1055,6 +1062,7 @@ int phd_step_local_async(phd_navigator* nav, uint8_t onlymapping)
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	if (nav->P < 1) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step_local: no particles");
 	hipSetDevice(nav->device);
+	nav->timing_now = (nav->timing_step++ % nav->timing_period) == 0;
 	StepBufs b = make_bufs(nav);
 	return launch_map(nav, b, !onlymapping);
 }

@@ -266,7 +266,8 @@ class PHDNavigator:
         self._check(self._lib.phd_set_split(self._h, int(nsplit)))
 
     def timing_reset(self, enabled=True):
-        self._check(self._lib.phd_timing_reset(self._h, int(bool(enabled))))
+        """enabled: False / 0 off, True / 1 every step, n > 1 every n-th step"""
+        self._check(self._lib.phd_timing_reset(self._h, int(enabled)))
 
     def last_timings(self):
         names = C.POINTER(C.c_char_p)()
