@@ -75,7 +75,20 @@ def cpu_baseline(frame, params, sample, threads):
         elapsed += time.perf_counter() - t0
         stages += stt
         steps += 1
+    # the same step on 1 thread and on 8 (the reference's Parallel.For runs on NParallel = 8 threads, Config.cs:46), on
+    # proportionally smaller particle samples (about a second each)
+    by_threads = {}
+    for t in (1, 8):
+        if t >= threads:
+            continue
+        n = min(P, 48 * t)
+        st = state(n)
+        t0 = time.perf_counter()
+        orc.slam_update(params, st, frame.z, u=0.5, threads=t)
+        by_threads[str(t)] = n * frame.C * frame.M / (time.perf_counter() - t0)
+    by_threads[str(threads)] = steps * P * frame.C * frame.M / elapsed
     return {"value": steps * P * frame.C * frame.M / elapsed, "unit": "PHD updates/s", "cores": threads, "kind": "port",
+            "by_threads": by_threads,
             "sample": "%d steps of %d of the %d particles (C=%d, M=%d), oracle/phd_oracle.cpp with OpenMP over particles, %.1f s"
                       % (steps, P, frame.P, frame.C, frame.M, elapsed),
             "stage_share": {k: float(v / stages.sum()) for k, v in zip(("predict", "correct", "prune", "reweight"), stages)}}
