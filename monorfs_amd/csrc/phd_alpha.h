@@ -736,13 +736,27 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 		if (tid == 0) { s_nroots = 0; s_big = 0; }
 		__threadfence_block();
 		__syncthreads();
-		// detection block: defined iff Mahalanobis(z_k; h(m_j), R) < 5 (:433-442), every pair in parallel
-		for (int e = tid; e < J * M; e += 256) {
-			const int j = e / M, k = e - j * M;
-			const double q = quad_gen(prm.Rinv, zh[j] - zs[k * 3], zh[JS + j] - zs[k * 3 + 1], zh[2 * JS + j] - zs[k * 3 + 2]);
-			if (q < (QUASI ? prm.g2_quasi : prm.g2_assoc)) {   // sqrt(q) < 5, :436 (quasi: < 12, :615)
-				atomicOr(&adj[(size_t) j * MW + (k >> 6)], 1ull << (k & 63));
-				if (inlds) atomicOr(&adjT[(size_t) k * JW + (j >> 6)], 1ull << (j & 63));
+		// detection block: defined iff Mahalanobis(z_k; h(m_j), R) < 5 (:433-442). Measurement per lane, wave w takes the
+		// landmarks w, w + 4, ...: a landmark's adjacency words are the ballots of its gate tests (no atomics); only the
+		// transposed copy is built from the set bits.
+		{
+			double kx[ZB], ky[ZB], kz[ZB];
+#pragma unroll
+			for (int b = 0; b < ZB; b++) {
+				const int k = b * 64 + lane;
+				kx[b] = zs[k * 3]; ky[b] = zs[k * 3 + 1]; kz[b] = zs[k * 3 + 2];
+			}
+			const double g2 = QUASI ? prm.g2_quasi : prm.g2_assoc;   // sqrt(q) < 5, :436 (quasi: < 12, :615)
+			for (int j = wv; j < J; j += 4) {
+				const double h0 = zh[j], h1 = zh[JS + j], h2 = zh[2 * JS + j];
+#pragma unroll
+				for (int b = 0; b < ZB; b++) {
+					const int k = b * 64 + lane;
+					const bool gated = k < M && quad_gen(prm.Rinv, h0 - kx[b], h1 - ky[b], h2 - kz[b]) < g2;
+					const unsigned long long bal = __ballot(gated);
+					if (lane == 0) adj[(size_t) j * MW + b] = bal;
+					if (gated && inlds) atomicOr(&adjT[(size_t) k * JW + (j >> 6)], 1ull << (j & 63));
+				}
 			}
 		}
 		__threadfence_block();
