@@ -20,6 +20,24 @@ dp = _lib.dp
 ip = _lib.ip
 
 
+def pose3d_add(pose7, delta6):
+    """Pose3D.Add (Pose3D.cs:282-291): x + q dx q*, q Exp(dr / 2) normalised"""
+    x, q = np.asarray(pose7[:3], float), np.asarray(pose7[3:], float)
+    lie = 0.5 * np.asarray(delta6[3:], float)
+    phi = np.linalg.norm(lie)
+    dq = np.array([1.0, 0, 0, 0]) if phi < 1e-12 else np.concatenate([[np.cos(phi)], np.sin(phi) * (lie / phi)])
+
+    def mul(a, b):
+        return np.array([a[0] * b[0] - (a[1] * b[1] + a[2] * b[2] + a[3] * b[3]),
+                         a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                         a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3],
+                         a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1]])
+    nq = mul(q, dq)
+    nq = nq / np.linalg.norm(nq)
+    dl = mul(mul(q, np.concatenate([[0.0], np.asarray(delta6[:3], float)])), q * [1, -1, -1, -1])
+    return np.concatenate([x + dl[1:], nq])
+
+
 class PHDError(RuntimeError):
     """≙ the InvalidOperationException with Data["module"] that Simulation.Update catches
     (Simulation.cs:655-670); `module` is "association" for PHD_ERR_ASSOCIATION."""
@@ -159,6 +177,23 @@ class PHDNavigator:
         self._check(self._lib.phd_quasi_set_loglik(self._h, _ptr(poses), len(poses), _ptr(lm) if len(lm) else None, len(lm),
                                                    _ptr(z) if len(z) else None, len(z), _ptr(out)))
         return out
+
+    def LogLikeGradient(self, pose, measurements, landmarks, linearpoint):
+        """≙ LoopyPHDNavigator.LogLikeGradient (LoopyPHDNavigator.cs:876-909): central differences (eps = 1e-5) of the
+        quasi set log-likelihood at linearpoint.Add(pose +- eps e_i) — the 12 evaluations go to the device as one batch.
+        `pose` may hold several linear poses [n][6]: the 12 n evaluations are still one batch."""
+        pose = np.ascontiguousarray(pose, np.float64).reshape(-1, 6)
+        eps = 1e-5
+        cand = np.empty((len(pose), 6, 2, 7))
+        for a in range(len(pose)):
+            for i in range(6):
+                for s, sign in enumerate((1.0, -1.0)):
+                    d = pose[a].copy()
+                    d[i] += sign * eps
+                    cand[a, i, s] = pose3d_add(linearpoint, d)
+        ll = self.QuasiSetLogLikelihood(measurements, landmarks, cand.reshape(-1, 7)).reshape(len(pose), 6, 2)
+        g = (ll[:, :, 0] - ll[:, :, 1]) / (2 * eps)
+        return g[0] if len(g) == 1 else g
 
     def SlamUpdate(self, time, measurements, u_resample=0.5):
         """≙ PHDNavigator.SlamUpdate (:323-362)."""

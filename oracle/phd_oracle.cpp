@@ -1170,6 +1170,28 @@ double orc_set_log_likelihood(const phd_params* p, const double* pose7, const do
 	return set_log_likelihood(md, ps, lm, J, z, M, nclusters, maxcluster);
 }
 
+void orc_pose_add(const double* pose7, const double* delta6, double* out7);
+
+// LoopyPHDNavigator.LogLikeGradient (LoopyPHDNavigator.cs:876-909): central differences of QuasiSetLogLikelihood
+// at linearpoint.Add(pose +- eps e_i), eps = 1e-5
+void orc_loglike_gradient(const phd_params* p, const double* pose6, const double* linearpoint7, const double* lm, int J,
+                          const double* z, int M, double* gradient6)
+{
+	Model md = make_model(p);
+	const double eps = 1e-5;
+	for (int i = 0; i < 6; i++) {
+		double l[2];
+		for (int s = 0; s < 2; s++) {
+			double d[6], q7[7];
+			for (int t = 0; t < 6; t++) d[t] = pose6[t];
+			d[i] += s == 0 ? eps : -eps;
+			orc_pose_add(linearpoint7, d, q7);
+			l[s] = set_log_likelihood(md, make_pose(q7), lm, J, z, M, nullptr, nullptr, true);
+		}
+		gradient6[i] = (l[0] - l[1]) / (2 * eps);
+	}
+}
+
 // PHDNavigator.QuasiSetLogLikelihood(measurements, map, pose) (:526-531), SURVEY row f4
 double orc_quasi_set_log_likelihood(const phd_params* p, const double* pose7, const double* lm, int J, const double* z, int M)
 {
@@ -1457,6 +1479,17 @@ void orc_add_odometry(const double* pose7, const double* delta6, double* out7)
 	Quat o  = qnormalize(neworientation);
 	out7[0] = pose7[0] + dl.x; out7[1] = pose7[1] + dl.y; out7[2] = pose7[2] + dl.z;
 	out7[3] = o.w; out7[4] = o.x; out7[5] = o.y; out7[6] = o.z;
+}
+
+// Pose3D.Add (Pose3D.cs:282-291): a linear vector in semi-Lie space added around the pose
+void orc_pose_add(const double* pose7, const double* delta6, double* out7)
+{
+	const Quat q{pose7[3], pose7[4], pose7[5], pose7[6]};
+	const double half[3] = {0.5 * delta6[3], 0.5 * delta6[4], 0.5 * delta6[5]};   // Quaternion.Add, Quaternion.cs:165-168
+	Quat nq = qnormalize(qmul(q, qexp(half)));
+	Quat dl = qmul(qmul(q, Quat{0, delta6[0], delta6[1], delta6[2]}), qconj(q));
+	out7[0] = pose7[0] + dl.x; out7[1] = pose7[1] + dl.y; out7[2] = pose7[2] + dl.z;
+	out7[3] = nq.w; out7[4] = nq.x; out7[5] = nq.y; out7[6] = nq.z;
 }
 
 // Pose3D.DiffOdometry (Pose3D.cs:338-356): the delta that takes `origin` to `pose`

@@ -116,6 +116,26 @@ def quasi_set_log_likelihood(p, pose7, lm, z):
                                             z.ctypes.data_as(dp), len(z))
 
 
+def pose_add(pose7, delta6):
+    """Pose3D.Add (Pose3D.cs:282-291)"""
+    a, ap = _d(np.asarray(pose7, float).reshape(7))
+    d, dptr = _d(np.asarray(delta6, float).reshape(6))
+    out, op = _d(np.zeros(7))
+    lib.orc_pose_add(ap, dptr, op)
+    return out
+
+
+def loglike_gradient(p, pose6, linearpoint7, lm, z):
+    """LoopyPHDNavigator.LogLikeGradient (LoopyPHDNavigator.cs:876-909)"""
+    lm, lmp = _d(np.asarray(lm, float).reshape(-1, 3))
+    z, zp = _d(np.asarray(z, float).reshape(-1, p.zdim))
+    a, ap = _d(np.asarray(pose6, float).reshape(6))
+    l, lp = _d(np.asarray(linearpoint7, float).reshape(7))
+    g, gp = _d(np.zeros(6))
+    lib.orc_loglike_gradient(C.byref(p), ap, lp, lmp, len(lm), zp, len(z), gp)
+    return g
+
+
 def weight_alpha(p, pose7, z, predicted, corrected):
     pw, pm, pc = pack(predicted)
     cw, cm, cc = pack(corrected)

@@ -322,3 +322,21 @@ def test_quasi_set_log_likelihood_batch(nav_mod, J, M, seed):
     want = np.array([orc.quasi_set_log_likelihood(p, poses[i], lm, z) for i in range(f.P)])
     assert np.allclose(got, want, rtol=1e-9, atol=1e-9), np.max(np.abs(got - want))
     nav.close()
+
+
+def test_loglike_gradient_through_the_batch(nav_mod):
+    """LoopyPHDNavigator.LogLikeGradient (LoopyPHDNavigator.cs:876-909): the 12 finite-difference evaluations of a pose
+    (here of 5 poses at once) as one device batch, against the oracle's restatement"""
+    from monorfs_amd.navigator import pose3d_add
+    rng = np.random.default_rng(91)
+    f = Frame(64, 30, 20, 91, weight_profile="steady")
+    nav, p = make_nav(nav_mod, f)
+    lm, z, lin = f.mean[0, :25].copy(), f.z.copy(), f.poses[0].copy()
+    assert np.allclose(pose3d_add(lin, [0.01, -0.02, 0.03, 0.02, -0.01, 0.015]), orc.pose_add(lin, [0.01, -0.02, 0.03, 0.02, -0.01, 0.015]), atol=1e-15)
+    poses = rng.normal(0, 1, (5, 6)) * [2e-3, 2e-3, 2e-3, 1e-3, 1e-3, 1e-3]
+    got = nav.LogLikeGradient(poses, z, lm, lin)
+    for a in range(5):
+        want = orc.loglike_gradient(p, poses[a], lin, lm, z)
+        assert np.allclose(got[a], want, rtol=1e-4, atol=0.5), (got[a], want)
+    assert np.max(np.abs(got)) > 10          # the gradients are far from zero: the comparison means something
+    nav.close()
