@@ -40,6 +40,7 @@
 #include "../include/phdhip.h"
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -256,6 +257,42 @@ void jacobian_l(const Model& md, const Pose& pose, const double* lm, double* H)
 				s += jp[i * 3 + k] * jr[k * 3 + j];
 			}
 			H[i * 3 + j] = s;
+		}
+	}
+}
+
+// MeasurementJacobianP: PRM3DMeasurer.cs:185-211 / Linear2DMeasurer.cs:133-137. Jp is zdim x odo (odo = 6 / 2).
+void jacobian_p(const Model& md, const Pose& pose, const double* lm, double* Jp)
+{
+	if (md.p->model == PHD_MODEL_LINEAR2D) {
+		Jp[0] = -1; Jp[1] = 0;
+		Jp[2] = 0;  Jp[3] = -1;
+		return;
+	}
+	double f = md.p->measurer[0];
+	double diff[3] = {lm[0] - pose.t[0], lm[1] - pose.t[1], lm[2] - pose.t[2]};
+	Quat l = qmul(qmul(qconj(pose.q), Quat{0, diff[0], diff[1], diff[2]}), pose.q);
+	double mag = ((l.z > 0) ? 1 : -1) * std::sqrt(l.x * l.x + l.y * l.y + l.z * l.z);
+	double jp[9] = {f / l.z, 0,       -f * l.x / (l.z * l.z),
+	                0,       f / l.z, -f * l.y / (l.z * l.z),
+	                l.x / mag, l.y / mag, l.z / mag};
+	// jlocation = -R(q*) ; jrotation = jlocation [diff]_x ; jlocal = [jlocation | jrotation]   (:202-207)
+	double rc[9], jloc[9], cross[9] = {0, -diff[2], diff[1],  diff[2], 0, -diff[0],  -diff[1], diff[0], 0}, jlocal[18];
+	qmatrix(qconj(pose.q), rc);
+	for (int i = 0; i < 9; i++) jloc[i] = -1.0 * rc[i];
+	for (int i = 0; i < 3; i++) {
+		for (int j = 0; j < 3; j++) {
+			double s = 0;
+			for (int k = 0; k < 3; k++) s += jloc[i * 3 + k] * cross[k * 3 + j];
+			jlocal[i * 6 + j]     = jloc[i * 3 + j];
+			jlocal[i * 6 + 3 + j] = s;
+		}
+	}
+	for (int i = 0; i < 3; i++) {
+		for (int j = 0; j < 6; j++) {
+			double s = 0;
+			for (int k = 0; k < 3; k++) s += jp[i * 3 + k] * jlocal[k * 6 + j];
+			Jp[i * 6 + j] = s;
 		}
 	}
 }
@@ -903,10 +940,24 @@ struct DSU {
 // `lm` = landmark means of the map estimate (J x 3).
 // quasi: QuasiSetLogLikelihood (:526-713, value only) — the same sum with everything fully visible: constant PD
 // (logPD / log1PD, :574-575), zprobs of weight 1 (:583) and the detection gate at 12 (:600, :615).
+// gradient (quasi only; :543-548 with calcgradient): d/dpose of the value, `odo` doubles (6 for Pose3D, 2 for
+// LinearPose2D): per defined detection entry dlldp[i,k] = (z_k - zhat_i)' R^-1 Jp_i (:605-608), per enumerated pairing the
+// sum of its entries' vectors (:676-678), per component TemperedAverage(dlogcompdp, logcomp, 0, m) (:707). That
+// function (MatrixExtensions.cs:400-440) works IN PLACE on logcomp: entries [0, m) are replaced by exp(l - max) and
+// stay that way, so in gradient mode the stale values the Murty cut (:672) reads are these, not log values; and its
+// `weights.Normalize()` is Accord.Math's vector Normalize over the WHOLE 200-entry array — division by the Euclidean
+// norm (not by the sum), stale entries beyond m included. Accord 3.0.2 is not in the tree: that reading is unpinned;
+// `average_mode` 1 switches to weights / sum over [0, m) (what the summary comment of TemperedAverage describes) for
+// the comparison the KAT file makes, 0 is what the source says and what the device implements.
 double set_log_likelihood(const Model& md, const Pose& pose, const double* lm, int J, const double* z, int M,
-                          int* nclusters = nullptr, int* maxcluster = nullptr, bool quasi = false)
+                          int* nclusters = nullptr, int* maxcluster = nullptr, bool quasi = false,
+                          double* gradient = nullptr, int average_mode = 0)
 {
 	const int zd = md.zdim;
+	const int odo = (md.p->model == PHD_MODEL_LINEAR2D) ? 2 : 6;
+	if (gradient) {
+		for (int t = 0; t < odo; t++) gradient[t] = 0;
+	}
 	const double gate = quasi ? 12 : 5;
 	double logclutter = std::log(md.p->clutter_density);
 	std::vector<double> zhat(J * 3), pdj(J);
@@ -916,10 +967,14 @@ double set_log_likelihood(const Model& md, const Pose& pose, const double* lm, i
 	}
 
 	// detection block: defined iff Mahalanobis(z_k ; zhat_i, R) < 5 (:433-442)
-	struct Edge { int k; double v; };
+	struct Edge { int k; double v; double g[6]; };
 	std::vector<std::vector<Edge>> det(J);
 	DSU dsu(J + M);   // node i < J: landmark i ; node J + k: measurement k
 	for (int i = 0; i < J; i++) {
+		double Jp[18];
+		if (gradient) {
+			jacobian_p(md, pose, lm + i * 3, Jp);   // :591
+		}
 		for (int k = 0; k < M; k++) {
 			double d[3];
 			for (int a = 0; a < zd; a++) {
@@ -927,7 +982,21 @@ double set_log_likelihood(const Model& md, const Pose& pose, const double* lm, i
 			}
 			double dist = std::sqrt(quadform(md.Rinv, d, zd));
 			if (dist < gate) {
-				det[i].push_back(Edge{k, std::log(pdj[i]) + std::log(md.Rmult) - 0.5 * dist * dist});
+				Edge e{k, std::log(pdj[i]) + std::log(md.Rmult) - 0.5 * dist * dist, {0, 0, 0, 0, 0, 0}};
+				if (gradient) {   // (m - mean)' CovarianceInverse, then times the jacobian (:605-608)
+					double u[3];
+					for (int b = 0; b < zd; b++) {
+						double sacc = 0;
+						for (int a = 0; a < zd; a++) sacc += (z[k * zd + a] - zhat[i * 3 + a]) * md.Rinv[a * zd + b];
+						u[b] = sacc;
+					}
+					for (int t = 0; t < odo; t++) {
+						double sacc = 0;
+						for (int b = 0; b < zd; b++) sacc += u[b] * Jp[b * odo + t];
+						e.g[t] = sacc;
+					}
+				}
+				det[i].push_back(e);
 				dsu.join(i, J + k);
 			}
 		}
@@ -948,6 +1017,7 @@ double set_log_likelihood(const Model& md, const Pose& pose, const double* lm, i
 	std::vector<char> done(J + M, 0);
 	double logcomp[200];
 	std::memset(logcomp, 0, sizeof(logcomp));   // new double[200]
+	std::vector<std::array<double, 6>> dlogcomp(gradient ? 200 : 0);
 	double total = 0;
 	int    ncl = 0, maxcl = 0;
 
@@ -982,12 +1052,26 @@ double set_log_likelihood(const Model& md, const Pose& pose, const double* lm, i
 			}
 		}
 
+		// dcomp = dlldp.Submatrix(rows, cols) (:643): the vector of a defined detection entry, zeros elsewhere
+		auto pairing_gradient = [&](const std::vector<int>& asg, double* out) {   // :676-678
+			for (int t = 0; t < odo; t++) out[t] = 0;
+			for (int a = 0; a < nl; a++) {
+				if (asg[a] >= nz) continue;
+				for (const Edge& e : det[L[a]]) {
+					if (e.k == Z[asg[a]]) {
+						for (int t = 0; t < odo; t++) out[t] += e.g[t];
+					}
+				}
+			}
+		};
+
 		int m = 0;
 		if (n <= 5) {
-			lexicographical_pairing(comp, J, [&](const std::vector<int>&, double value) {
+			lexicographical_pairing(comp, J, [&](const std::vector<int>& perm, double value) {
 				if (m >= 200) {
 					return false;
 				}
+				if (gradient) pairing_gradient(perm, dlogcomp[m].data());
 				logcomp[m++] = value;
 				return true;
 			});
@@ -998,13 +1082,36 @@ double set_log_likelihood(const Model& md, const Pose& pose, const double* lm, i
 			double value;
 			bool   solved;
 			while (murty.next(&asg, &value, &solved)) {
-				if (m >= 200 || (logcomp[m] - logcomp[0] < -10)) {   // stale read, :503
+				if (m >= 200 || (logcomp[m] - logcomp[0] < -10)) {   // stale read, :503 / :672
 					break;
 				}
+				if (gradient) pairing_gradient(asg, dlogcomp[m].data());
 				logcomp[m++] = value;
 			}
 		}
 		total += log_sum_exp(logcomp, 0, m);
+
+		if (gradient) {   // TemperedAverage(dlogcompdp, logcomp, 0, m), MatrixExtensions.cs:400-440
+			double mx = -INF;
+			for (int i = 0; i < m; i++) mx = std::max(mx, logcomp[i]);
+			if (!(std::isinf(mx) && mx < 0)) {
+				for (int i = 0; i < m; i++) logcomp[i] = std::exp(logcomp[i] - mx);   // in place (:429-431)
+				double norm = 0;
+				if (average_mode == 0) {
+					for (int i = 0; i < 200; i++) norm += logcomp[i] * logcomp[i];     // weights.Normalize(), :433
+					norm = std::sqrt(norm);
+				}
+				else {
+					for (int i = 0; i < m; i++) norm += logcomp[i];
+				}
+				double value[6] = {0, 0, 0, 0, 0, 0};
+				for (int i = 0; i < m; i++) {
+					double wn = (norm == 0) ? logcomp[i] : logcomp[i] / norm;
+					for (int t = 0; t < odo; t++) value[t] += wn * dlogcomp[i][t];
+				}
+				for (int t = 0; t < odo; t++) gradient[t] += value[t];
+			}
+		}
 	}
 	if (nclusters)  *nclusters  = ncl;
 	if (maxcluster) *maxcluster = maxcl;
@@ -1198,6 +1305,21 @@ double orc_quasi_set_log_likelihood(const phd_params* p, const double* pose7, co
 	Model md = make_model(p);
 	Pose  ps = make_pose(pose7);
 	return set_log_likelihood(md, ps, lm, J, z, M, nullptr, nullptr, true);
+}
+
+// PHDNavigator.QuasiSetLogLikelihood(measurements, map, pose, out gradient) (:543-548). gradient: 6 doubles (Pose3D) or
+// 2 (LinearPose2D, whose pose is (x, y) of pose7). average_mode: see set_log_likelihood.
+double orc_quasi_set_log_likelihood_grad(const phd_params* p, const double* pose7, const double* lm, int J, const double* z,
+                                         int M, double* gradient, int average_mode)
+{
+	Model md = make_model(p);
+	return set_log_likelihood(md, make_pose(pose7), lm, J, z, M, nullptr, nullptr, true, gradient, average_mode);
+}
+
+void orc_jacobian_p(const phd_params* p, const double* pose7, const double* lm, double* Jp)
+{
+	Model md = make_model(p);
+	jacobian_p(md, make_pose(pose7), lm, Jp);
 }
 
 double orc_weight_alpha(const phd_params* p, const double* pose7, const double* z, int M,

@@ -334,3 +334,26 @@ def slam_update(p, st, z, onlymapping=False, u=0.5, threads=1, stage_times=None)
     if stage_times is not None:
         stage_times[:] = stt
     return best, src, bool(res.value), alpha
+
+
+def quasi_set_log_likelihood_grad(p, pose7, lm, z, average_mode=0):
+    """PHDNavigator.QuasiSetLogLikelihood(..., out gradient) (PHDNavigator.cs:543-548). average_mode 0 = TemperedAverage
+    as its source reads (Accord Normalize = Euclidean norm over the whole 200-entry array), 1 = weights / their sum."""
+    lm = np.ascontiguousarray(lm, np.float64).reshape(-1, 3)
+    z = np.ascontiguousarray(z, np.float64).reshape(-1, p.zdim)
+    pose7 = np.ascontiguousarray(pose7, np.float64)
+    lib.orc_quasi_set_log_likelihood_grad.restype = C.c_double
+    lmp = lm if len(lm) else np.zeros((1, 3))
+    g = np.zeros(6)
+    v = lib.orc_quasi_set_log_likelihood_grad(C.byref(p), pose7.ctypes.data_as(dp), lmp.ctypes.data_as(dp), len(lm),
+                                              z.ctypes.data_as(dp), len(z), g.ctypes.data_as(dp), int(average_mode))
+    return v, (g[:2].copy() if p.model == 0 else g)
+
+
+def jacobian_p(p, pose7, lm):
+    """PRM3DMeasurer.MeasurementJacobianP (PRM3DMeasurer.cs:185-211): 3 x 6"""
+    a, ap = _d(np.asarray(pose7, float).reshape(7))
+    l, lp = _d(np.asarray(lm, float).reshape(3))
+    out, op = _d(np.zeros(18))
+    lib.orc_jacobian_p(C.byref(p), ap, lp, op)
+    return out.reshape(3, 6)

@@ -282,3 +282,66 @@ def test_prm3d_correct_against_second_reading(seed):
         assert np.isclose(ow[i], w, rtol=1e-9, atol=1e-300), (i, ow[i], w)
         assert np.allclose(om[i], m, rtol=1e-9, atol=1e-12)
         assert np.allclose(oc[i], P, rtol=1e-8, atol=1e-14)
+
+
+def _qexp(w):
+    a = np.linalg.norm(w)
+    return np.array([1.0, 0, 0, 0]) if a == 0 else np.concatenate([[np.cos(a)], np.sin(a) * w / a])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_quasi_gradient_is_the_derivative_the_jacobian_describes(seed):
+    """QuasiSetLogLikelihood(..., out gradient) (PHDNavigator.cs:543-713) with MeasurementJacobianP
+    (PRM3DMeasurer.cs:185-211): [-R(q*) | -R(q*) [l - t]x] is the derivative of the local landmark coordinates wrt. a
+    GLOBAL translation and wrt. a global-frame rotation applied as q' = exp(-w/2) q (not the convention of Pose3D.Add,
+    which the restatement does not repair). With weights that sum to one (average_mode 1) the gradient of a case whose
+    components are all enumerated must therefore equal central differences of the value along exactly those paths."""
+    rng = np.random.default_rng(900 + seed)
+    p = prm3d_defaults(4, 600, 8)
+    J = int(rng.integers(1, 4))
+    M = int(rng.integers(1, 6 - J))
+    pose, lm, z = random_case(rng, p, J, M)
+    pose[3:] /= np.linalg.norm(pose[3:])
+    if seed % 2 and J >= 2:
+        lm[1] = lm[0] + rng.normal(0, 1e-3, 3)         # a shared measurement: several pairings carry weight
+    value, grad = orc.quasi_set_log_likelihood_grad(p, pose, lm, z, average_mode=1)
+    assert np.isclose(value, orc.quasi_set_log_likelihood(p, pose, lm, z), rtol=0, atol=1e-12)
+    eps = 1e-6
+    num = np.zeros(6)
+    for i in range(6):
+        l = []
+        for s in (1, -1):
+            d = np.zeros(6)
+            d[i] = s * eps
+            q = np.array(qmul(_qexp(-d[3:] / 2), pose[3:]))
+            l.append(set_log_likelihood_bruteforce(p, np.concatenate([pose[:3] + d[:3], q]), lm, z, quasi=True))
+        num[i] = (l[0] - l[1]) / (2 * eps)
+    assert np.allclose(grad, num, rtol=2e-5, atol=2e-4), (grad, num)
+
+
+def test_tempered_average_as_written():
+    """TemperedAverage (MatrixExtensions.cs:400-440) divides the exponentiated weights by the Euclidean norm of the whole
+    200-entry array (Accord's vector Normalize), not by their sum, and the entries a previous component left behind
+    enter the norm. One landmark between two measurements."""
+    p = prm3d_defaults(4, 600, 8)
+    pose = np.array([0, 0, 0, 1.0, 0, 0, 0])
+    zc = np.array([10.0, -20.0, 1.0])
+    # three more landmarks far outside every gate: components of their own, and a map of 4 >= the 3 rows of the
+    # component under test, so that LexicographicalPairing walks all of its pairings (`modelsize`, :293-299)
+    lm = np.array([measure_to_map(p, pose, zc)] + [measure_to_map(p, pose, zc + [100.0 * (i + 1), 50, 0.2]) for i in range(3)])
+    z = np.array([zc + [1.0, 0, 0], zc + [-1.0, 0.5, 0.01]])
+    _, g_sum = orc.quasi_set_log_likelihood_grad(p, pose, lm, z, average_mode=1)
+    _, g_src = orc.quasi_set_log_likelihood_grad(p, pose, lm, z, average_mode=0)
+    # pairings: (lm-z0), (lm-z1), (lm missed)
+    Jp = orc.jacobian_p(p, pose, lm[0])
+    Rinv = np.linalg.inv(np.array(p.R).reshape(3, 3))
+    zh = measure_perfect(p, pose, lm[0])
+    d = [(zk - zh) @ Rinv @ Jp for zk in z]
+    R = np.array(p.R).reshape(3, 3)
+    lv = [np.log(p.pd) + np.log(multiplier(R)) - 0.5 * (zk - zh) @ Rinv @ (zk - zh) + np.log(p.clutter_density) for zk in z]
+    lmiss = np.log(1 - p.pd) + 2 * np.log(p.clutter_density)
+    e = np.exp(np.array(lv + [lmiss]) - max(lv + [lmiss]))
+    want_sum = (e[0] * d[0] + e[1] * d[1]) / e.sum()
+    want_src = (e[0] * d[0] + e[1] * d[1]) / np.sqrt((e ** 2).sum())
+    assert np.allclose(g_sum, want_sum, rtol=1e-9, atol=1e-9)
+    assert np.allclose(g_src, want_src, rtol=1e-9, atol=1e-9)

@@ -280,3 +280,38 @@ def test_pose3d_add_odometry_properties():
         assert np.allclose(moved[i], orc.add_odometry(orc.add_odometry(poses[i], odometry2), noise[i]), atol=1e-15)
     assert np.allclose(orc.update_motion(poses, np.zeros(6), noise, perfect_still=True), poses, atol=1e-15)
     assert not np.allclose(orc.update_motion(poses, np.zeros(6), noise, perfect_still=False), poses, atol=1e-6)
+
+
+# ---------------------------------------------------------------- LoopyPHDNavigatorTest.LogLike2D (:351-419)
+def test_loglike2d_gradient_against_differences():
+    """The reference's only test of QuasiSetLogLikelihood and its analytic gradient: Linear2D, R = 5e-2 I (Setup,
+    :345-346), measurements (0, 1), (0.2, 0.6), landmarks (0, 1.45), (0, 0.65), (1, 0), pose on a 201 x 201 grid over
+    [-1, 1]^2; at every inner grid point central differences of the value must equal the gradient within 0.5.
+
+    The assertion holds at every point when TemperedAverage's weights are divided by their sum. As its source reads —
+    `weights.Normalize()`, Accord's division by the Euclidean norm (the meaning the reference relies on for its unit
+    3-vectors) — it fails at about a quarter of the grid: wherever two pairings carry weight. Accord 3.0.2 is not in the
+    tree and the test cannot be run here, so which of the two the C# build computes is unpinned; both are restated
+    (average_mode) and the device takes the same flag."""
+    p = params_from_dict(KAT["params"])
+    assert p.model == 0 and p.pd == 0.9 and p.clutter_density == 3e-7
+    p.R[:] = [5e-2, 0, 0, 5e-2, 0, 0, 0, 0, 0]
+    z = [[0, 1], [0.2, 0.6]]
+    lm = [[0, 1.45, 0], [0, 0.65, 0], [1.0, 0, 0]]
+    n = 201
+    x = np.array([((i / (n - 1)) - 0.5) / 0.5 for i in range(n)])
+    failures = {}
+    for mode in (1, 0):
+        L = np.zeros((n, n))
+        G = np.zeros((n, n, 2))
+        for i in range(n):
+            for k in range(n):
+                L[i, k], G[i, k] = orc.quasi_set_log_likelihood_grad(p, [x[i], x[k], 0, 1, 0, 0, 0], lm, z, mode)
+        xnum = (L[2:, 1:-1] - L[:-2, 1:-1]) / (x[2:] - x[:-2])[:, None]
+        ynum = (L[1:-1, 2:] - L[1:-1, :-2]) / (x[2:] - x[:-2])[None, :]
+        bad = (np.abs(xnum - G[1:-1, 1:-1, 0]) > 0.5) | (np.abs(ynum - G[1:-1, 1:-1, 1]) > 0.5)
+        failures[mode] = int(bad.sum())
+        # the value does not depend on the flag, nor on asking for the gradient (one component, all pairings)
+        assert L[100, 100] == orc.quasi_set_log_likelihood(p, [x[100], x[100], 0, 1, 0, 0, 0], lm, z)
+    assert failures[1] == 0
+    assert 0.15 * (n - 2) ** 2 < failures[0] < 0.35 * (n - 2) ** 2
