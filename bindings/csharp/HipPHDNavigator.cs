@@ -44,6 +44,7 @@ public class PhdHipLib
 	[DllImport(Lib)] public extern static int    phd_reset(HandleRef nav, int nparticles, IntPtr pose7, IntPtr w, IntPtr mean3, IntPtr cov9, int ncomp);
 	[DllImport(Lib)] public extern static int    phd_set_poses(HandleRef nav, IntPtr poses7, int nparticles);
 	[DllImport(Lib)] public extern static int    phd_update_motion(HandleRef nav, IntPtr odometry6, IntPtr noise6, int nparticles, [MarshalAs(UnmanagedType.U1)] bool perfectstill);
+	[DllImport(Lib)] public extern static int    phd_quasi_set_loglik_grad(HandleRef nav, IntPtr poses7, int nposes, IntPtr landmarks3, int nlandmarks, IntPtr z3, int nmeasurements, int averagemode, IntPtr result, IntPtr gradients6);
 	[DllImport(Lib)] public extern static int    phd_quasi_set_loglik(HandleRef nav, IntPtr poses7, int nposes, IntPtr landmarks3, int nlandmarks, IntPtr z3, int nmeasurements, IntPtr result);
 	[DllImport(Lib)] public extern static int    phd_slam_update(HandleRef nav, IntPtr z3, int nmeasurements, [MarshalAs(UnmanagedType.U1)] bool onlymapping, double uresample);
 	[DllImport(Lib)] public extern static IntPtr phd_weights(HandleRef nav, out int length);
@@ -181,6 +182,25 @@ public unsafe class HipPHDNavigator : Navigator<PRM3DMeasurer, Pose3D, PixelRang
 		fixed (double* pz = z) fixed (double* pl = lm) fixed (double* pp = p7) fixed (double* pr = result) {
 			Check(PhdHipLib.phd_quasi_set_loglik(nav, (IntPtr) pp, poses.Length, (IntPtr) pl, map.Count, (IntPtr) pz, measurements.Count, (IntPtr) pr));
 		}
+		return result;
+	}
+
+	/// <summary>≙ static PHDNavigator.QuasiSetLogLikelihood(measurements, map, pose, out gradient) (PHDNavigator.cs:543-548)
+	/// for a batch of candidate poses: what LogLikeGradientAscent and LogLikeFitCovariance evaluate
+	/// (LoopyPHDNavigator.cs:916-1021). averagemode 0 follows TemperedAverage as written, 1 divides its weights by their sum.</summary>
+	public double[] QuasiSetLogLikelihood(List<PixelRangeMeasurement> measurements, IMap map, Pose3D[] poses, out double[][] gradients, int averagemode = 0)
+	{
+		double[] z = new double[3 * measurements.Count], lm = new double[3 * map.Count], p7 = new double[7 * poses.Length];
+		for (int i = 0; i < measurements.Count; i++) { measurements[i].ToLinear().CopyTo(z, 3 * i); }
+		int j = 0;
+		foreach (Gaussian landmark in map) { landmark.Mean.CopyTo(lm, 3 * j++); }
+		for (int i = 0; i < poses.Length; i++) { poses[i].State.CopyTo(p7, 7 * i); }
+		double[] result = new double[poses.Length], g = new double[6 * poses.Length];
+		fixed (double* pz = z) fixed (double* pl = lm) fixed (double* pp = p7) fixed (double* pr = result) fixed (double* pg = g) {
+			Check(PhdHipLib.phd_quasi_set_loglik_grad(nav, (IntPtr) pp, poses.Length, (IntPtr) pl, map.Count, (IntPtr) pz, measurements.Count, averagemode, (IntPtr) pr, (IntPtr) pg));
+		}
+		gradients = new double[poses.Length][];
+		for (int i = 0; i < poses.Length; i++) { gradients[i] = new double[6]; Array.Copy(g, 6 * i, gradients[i], 0, 6); }
 		return result;
 	}
 

@@ -222,6 +222,18 @@ int   phd_set_stream(phd_navigator* nav, void* stream, uint8_t lend);
 int phd_quasi_set_loglik(phd_navigator* nav, const double* poses7, int nposes, const double* landmarks3, int nlandmarks,
                          const double* z3, int nmeasurements, double* out);
 
+/* The same with the pose gradient: QuasiSetLogLikelihood(measurements, map, pose, out gradient) (PHDNavigator.cs:543-548,
+ * calcgradient branches of :556-713) — what LoopyPHDNavigator.LogLikeGradientAscent (:916-965) and LogLikeFitCovariance
+ * (:976-1021) call. gradients6[nposes][6]: d/d(translation, rotation) as MeasurementJacobianP (PRM3DMeasurer.cs:185-211)
+ * defines them. Every component is enumerated in the reference's order because TemperedAverage (MatrixExtensions.cs:
+ * 400-440) rewrites the shared logcomp array in place; in this mode the value can differ from phd_quasi_set_loglik's
+ * where a component of more than 5 rows meets those rewritten entries in the cut of :672 — as in the reference.
+ * average_mode 0: TemperedAverage as its source reads (weights.Normalize() = division by the Euclidean norm of the whole
+ * 200-entry array, Accord.Math 3.0.2, not in the reference tree); 1: weights divided by their sum (the only one of the
+ * two under which the reference's own LoopyPHDNavigatorTest.LogLike2D assertion holds; tests/test_oracle_kat.py).     */
+int phd_quasi_set_loglik_grad(phd_navigator* nav, const double* poses7, int nposes, const double* landmarks3, int nlandmarks,
+                              const double* z3, int nmeasurements, int average_mode, double* out, double* gradients6);
+
 /* Per-kernel device time in milliseconds, from HIP events recorded around every launch on the
  * handle's stream: the mean over the launches since the last phd_timing_reset; names[i] -> ms[i];
  * returns the number of entries. phd_timing_reset(nav, 0) switches the events off; (nav, n) times every n-th

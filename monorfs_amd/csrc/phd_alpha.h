@@ -106,6 +106,8 @@ struct MurtyNodes {       // per-particle workspace in HBM, touched only when su
 	unsigned int  forced[MURTY_POOL];             // forced rows; a forced edge is (row, asg[row])
 	double        profit[MURTY_NMAX * MURTY_NMAX];    // the cluster's matrix
 	double        reduced[MURTY_NMAX * MURTY_NMAX];   // and the copy a child node solves on
+	double        dvec[MURTY_OUT][6];                 // gradient mode: dlogcompdp of the enumerated pairings (PHDNavigator.cs:675)
+	double        jp[MURTY_NMAX][18];                 // gradient mode: MeasurementJacobianP of the cluster's landmarks
 };
 
 __device__ __forceinline__ double wave_min(double v)
@@ -206,7 +208,8 @@ struct MurtyLds {
 // Enumerate the pairings of one cluster best-first and record their values into logcomp exactly as
 // the loop of SetLogLikelihood does (PHDNavigator.cs:501-509), including its read of the stale
 // logcomp[m] left by earlier clusters. Returns the number of values written. Wave-uniform.
-__device__ __noinline__ int wave_murty(const MurtyLds& ws, MurtyNodes* nodes, int n, int lane)
+template <class Hook>
+__device__ __noinline__ int wave_murty(const MurtyLds& ws, MurtyNodes* nodes, int n, int lane, Hook hook)
 {
 	const double* profit = ws.profit;
 	int nfree = 0;
@@ -299,6 +302,7 @@ __device__ __noinline__ int wave_murty(const MurtyLds& ws, MurtyNodes* nodes, in
 		// foreach body of SetLogLikelihood (PHDNavigator.cs:502-509)
 		if (m >= MURTY_OUT || (ws.logcomp[m] - ws.logcomp[0] < -10)) break;
 		if (lane == 0) ws.logcomp[m] = value;
+		hook(m, code);                  // the pairing recorded at index m: nodes->asg[code] (code & 0x10000: unsolved)
 		m++;
 		lds_fence();
 		if (code & 0x10000) continue;   // unsolved: no children
@@ -359,6 +363,76 @@ __device__ __noinline__ int wave_murty(const MurtyLds& ws, MurtyNodes* nodes, in
 		nfree++;
 		lds_fence();
 	}
+	return m;
+}
+
+// ---- gradient mode of QuasiSetLogLikelihood (PHDNavigator.cs:543-713 with calcgradient) ----
+// MeasurementJacobianP (PRM3DMeasurer.cs:185-211): jprojection (3 x 3) times [-R(q*) | -R(q*) [m - t]x], row-major 3 x 6
+__device__ void jacobian_p(const DevParams& prm, const PoseD& pose, const double m[3], double* Jp)
+{
+	const double diff[3] = {m[0] - pose.t[0], m[1] - pose.t[1], m[2] - pose.t[2]};
+	double l[3];
+	to_local(pose, diff, l);
+	const double f = prm.focal;
+	const double mag = ((l[2] > 0) ? 1.0 : -1.0) * sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
+	const double jp[9] = {f / l[2], 0, -f * l[0] / (l[2] * l[2]),  0, f / l[2], -f * l[1] / (l[2] * l[2]),
+	                      l[0] / mag, l[1] / mag, l[2] / mag};
+	double rc[9], jlocal[18];
+	conj_matrix(pose, rc);
+	const double cross[9] = {0, -diff[2], diff[1],  diff[2], 0, -diff[0],  -diff[1], diff[0], 0};
+	for (int i = 0; i < 3; i++) {
+		for (int j = 0; j < 3; j++) {
+			double acc = 0;
+			for (int k = 0; k < 3; k++) acc += (-1.0 * rc[i * 3 + k]) * cross[k * 3 + j];
+			jlocal[i * 6 + j]     = -1.0 * rc[i * 3 + j];
+			jlocal[i * 6 + 3 + j] = acc;
+		}
+	}
+	for (int i = 0; i < 3; i++) {
+		for (int j = 0; j < 6; j++) {
+			double acc = 0;
+			for (int k = 0; k < 3; k++) acc += jp[i * 3 + k] * jlocal[k * 6 + j];
+			Jp[i * 6 + j] = acc;
+		}
+	}
+}
+
+// component t of dlldp[i, k] = (z_k - zhat_i)' R^-1 Jp_i (:605-608)
+__device__ __forceinline__ double pair_gradient(const DevParams& prm, const double* nu, const double* Jp, int t)
+{
+	double acc = 0;
+	for (int b = 0; b < 3; b++) {
+		double u = 0;
+		for (int e = 0; e < 3; e++) u += nu[e] * prm.Rinv[e * 3 + b];
+		acc += u * Jp[b * 6 + t];
+	}
+	return acc;
+}
+
+// The pairings of a cluster with n <= 5 rows in the order of LexicographicalPairing (GraphCombinatorics.cs:280-334),
+// by a whole wave: every lane walks the same permutations and computes the same value (AssignmentValue, rows in order);
+// `hook(m, perm)` lets the lanes add what they keep per pairing. mat: n x n, row stride 5. Returns the count.
+template <class Hook>
+__device__ int cluster_enumerate_wave(const double* mat, int n, int modelsize, double* logcomp, int lane, Hook hook)
+{
+	int measurestart = n;
+	for (int i = 0; i < n; i++) {
+		if (i >= modelsize) { measurestart = i; break; }
+	}
+	unsigned int perm = pk_reverse(0x43210u, measurestart, n);
+	int m = 0;
+	for (;;) {
+		double v = 0;
+		for (int i = 0; i < n; i++) v += mat[i * 5 + pk_get(perm, i)];
+		if (m < MURTY_OUT) {                       // m >= logcomp.Length ends the loop (:672); 5! = 120 never gets there
+			if (lane == 0) logcomp[m] = v;
+			hook(m, perm);
+			m++;
+		}
+		if (pk_last(perm, n)) break;
+		perm = pk_next(perm, n, measurestart);
+	}
+	lds_fence();
 	return m;
 }
 
@@ -424,7 +498,10 @@ __host__ __device__ inline size_t alpha_jscratch_doubles(int Jcap)
 // QUASI = true : QuasiSetLogLikelihood (PHDNavigator.cs:526-713, value) of candidate pose p against one
 //                given landmark set — the same association sum with everything fully visible: constant PD (:574-575),
 //                unit-weight measurement Gaussians (:583), detection gate 12 (:615). The map estimate is an input here.
-template <int ZB, bool QUASI>
+// GRAD (with QUASI): also the pose gradient (:543-548). Every cluster is then enumerated literally and in the
+//                reference's order by wave 0 — TemperedAverage rewrites logcomp in place (MatrixExtensions.cs:429-431)
+//                and normalises over the whole array, so each cluster sees what the previous ones left.
+template <int ZB, bool QUASI, bool GRAD = false>
 __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const StepBufs& a, int ncap, double* smem)
 {
 	constexpr int MP = ZB * 64;
@@ -846,7 +923,10 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 
 		PHD_STAMP(5);
 		// clusters with n <= 5 rows: every pairing (PHDNavigator.cs:492-494)
-		if (J >= 5) {
+		if (GRAD) {
+			if (tid == 0) s_big = 1;   // all clusters go through the ordered replay below
+		}
+		else if (J >= 5) {
 			// `modelsize` = J >= n, so LexicographicalPairing walks all n! pairings once and their log-sum-exp is
 			// the log of the permanent of exp(matrix). One thread per cluster; the 5 x 5 matrix sits in registers
 			// with every index static: landmark x -> row x and misdetection column x, measurement y -> clutter
@@ -989,10 +1069,13 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 				ws.Z = ws.L + MURTY_NMAX;
 				for (int i = lane; i < MURTY_OUT; i += 64) ws.logcomp[i] = 0;   // new double[200], :469
 				lds_fence();
-				int lastbig = -1;
-				for (int r = 0; r < nroots; r++) {
+				int lastbig = GRAD ? nroots - 1 : -1;
+				for (int r = 0; r < nroots && !GRAD; r++) {
 					if (isnan(res[r])) lastbig = r;
 				}
+				MurtyNodes* nodes = a.murty + p;
+				const int gt = (lane < 6) ? lane : 0;   // gradient component of this lane
+				double gacc = 0;
 				for (int ri = 0; ri <= lastbig; ri++) {
 					const int root = roots[ri];
 					int nl = 0, nz = 0;
@@ -1044,13 +1127,51 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 						mat[x * stride + y] = v;
 					}
 					lds_fence();
-					if (nrow <= 5) {
-						// only its logcomp entries matter here (res[ri] is already known)
-						if (lane == 0) cluster_enumerate(mat, 1, nrow, J, ws.logcomp);
+					// gradient mode: dlogcompdp[m] = sum over the rows of dcomp[row, pairing[row]] (:676-678); lane t keeps
+					// component t. Only landmark rows paired with a gated measurement hold a vector (the rest is the default 0).
+					if (GRAD) {
+						if (lane < nl) {
+							const int j = ws.L[lane];
+							const double m3[3] = {lm[j], lm[JS + j], lm[2 * JS + j]};
+							jacobian_p(prm, pose, m3, nodes->jp[lane]);   // :591
+						}
 						lds_fence();
 					}
+					auto pairing_gradient = [&](auto colof) {
+						double acc = 0;
+						for (int x = 0; x < nl; x++) {
+							const int y = colof(x);
+							if (y >= nz) continue;
+							const int j = ws.L[x], k = ws.Z[y];
+							if (!((adj[(size_t) j * MW + (k >> 6)] >> (k & 63)) & 1ull)) continue;
+							const double nu[3] = {zs[k * 3] - zh[j], zs[k * 3 + 1] - zh[JS + j], zs[k * 3 + 2] - zh[2 * JS + j]};
+							acc += pair_gradient(prm, nu, nodes->jp[x], gt);
+						}
+						return acc;
+					};
+					int mcount = -1;
+					if (nrow <= 5) {
+						if (GRAD) {
+							mcount = cluster_enumerate_wave(mat, nrow, J, ws.logcomp, lane, [&](int m, unsigned int perm) {
+								const double g = pairing_gradient([&](int x) { return pk_get(perm, x); });
+								if (lane < 6) nodes->dvec[m][lane] = g;
+							});
+						}
+						else {
+							// only its logcomp entries matter here (res[ri] is already known)
+							if (lane == 0) cluster_enumerate(mat, 1, nrow, J, ws.logcomp);
+							lds_fence();
+						}
+					}
 					else {
-						int mcount = wave_murty(ws, a.murty + p, nrow, lane);
+						mcount = wave_murty(ws, nodes, nrow, lane, [&](int m, int code) {
+							if (!GRAD) return;
+							double g = 0;
+							if (!(code & 0x10000)) g = pairing_gradient([&](int x) { return (int) nodes->asg[code][x]; });
+							if (lane < 6) nodes->dvec[m][lane] = g;
+						});
+					}
+					if (mcount >= 0) {
 						// LogSumExp(logcomp, 0, m), MatrixExtensions.cs:361-389
 						double mx = -INFINITY, value = 0;
 						for (int i = 0; i < mcount; i++) mx = fmax(mx, ws.logcomp[i]);
@@ -1062,8 +1183,32 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 						}
 						if (lane == 0) res[ri] = lse;
 						lds_fence();
+						if (GRAD && !(isinf(mx) && mx < 0)) {
+							// TemperedAverage(dlogcompdp, logcomp, 0, m) (:707; MatrixExtensions.cs:400-440): logcomp[0, m) becomes
+							// exp(l - max) for good; a.qavg 0: divided by the Euclidean norm of all 200 entries (Accord's vector
+							// Normalize, as the source reads), 1: by their sum over [0, m)
+							for (int i = lane; i < mcount; i += 64) ws.logcomp[i] = exp(ws.logcomp[i] - mx);
+							lds_fence();
+							double part = 0;
+							if (a.qavg == 0) {
+								for (int i = lane; i < MURTY_OUT; i += 64) part += ws.logcomp[i] * ws.logcomp[i];
+							}
+							else {
+								for (int i = lane; i < mcount; i += 64) part += ws.logcomp[i];
+							}
+#pragma unroll
+							for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+							const double norm = (a.qavg == 0) ? sqrt(part) : part;
+							double val = 0;
+							for (int i = 0; i < mcount; i++) {
+								const double wn = (norm == 0) ? ws.logcomp[i] : ws.logcomp[i] / norm;
+								val += wn * nodes->dvec[i][gt];
+							}
+							gacc += val;
+						}
 					}
 				}
+				if (GRAD && lane < 6) a.qgrad[(size_t) p * 6 + lane] = gacc;
 			}
 			__syncthreads();
 		}
@@ -1108,6 +1253,13 @@ __global__ __launch_bounds__(256, 4) void k_alpha_assoc(const DevParams prm, con
 }
 
 // one workgroup per candidate pose (the smoother's pose x landmark x measurement batches)
+template <int ZB>
+__global__ __launch_bounds__(256, 4) void k_quasi_setll_grad(const DevParams prm, const StepBufs a, int ncap)
+{
+	extern __shared__ __align__(16) double smem[];
+	alpha_assoc_body<ZB, true, true>(prm, a, ncap, smem);
+}
+
 template <int ZB>
 __global__ __launch_bounds__(256, 4) void k_quasi_setll(const DevParams prm, const StepBufs a, int ncap)
 {

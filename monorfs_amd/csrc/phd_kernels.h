@@ -78,6 +78,8 @@ struct StepBufs {
 	const double* qposes;   // [P][7]
 	const double* qlm;      // [qJ][3]
 	int     qJ;
+	double* qgrad;       // [P][6] pose gradients (k_quasi_setll_grad)
+	int     qavg;        // TemperedAverage normalisation: 0 as the source reads, 1 weights / their sum
 	double* stamps;      // [P][16] phase stamps of the diagnostic build (NULL otherwise)
 	int     stamp_kernel; // which kernel writes them (env PHD_STAMP_KERNEL): 2 prune, 3 assoc, 4 density, 1 correct
 };

@@ -275,11 +275,17 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha)
 // PHDNavigator.QuasiSetLogLikelihood (PHDNavigator.cs:526-531) for a batch of candidate poses against one landmark
 // set and one measurement set: one workgroup per pose through the association kernel's own code.
 template <int ZB>
-int launch_quasi(phd_navigator* nav, const StepBufs& b, int nposes)
+int launch_quasi(phd_navigator* nav, const StepBufs& b, int nposes, bool gradient)
 {
 	const AlphaLds lay = alpha_lds(ZB * 64, nav->cutcap);
-	HC(hipFuncSetAttribute((const void*) k_quasi_setll<ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
-	hipLaunchKernelGGL(k_quasi_setll<ZB>, dim3(nposes), dim3(256), lay.bytes, nav->stream, nav->dp, b, nav->cutcap);
+	if (gradient) {
+		HC(hipFuncSetAttribute((const void*) k_quasi_setll_grad<ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
+		hipLaunchKernelGGL(k_quasi_setll_grad<ZB>, dim3(nposes), dim3(256), lay.bytes, nav->stream, nav->dp, b, nav->cutcap);
+	}
+	else {
+		HC(hipFuncSetAttribute((const void*) k_quasi_setll<ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
+		hipLaunchKernelGGL(k_quasi_setll<ZB>, dim3(nposes), dim3(256), lay.bytes, nav->stream, nav->dp, b, nav->cutcap);
+	}
 	HC(hipGetLastError());
 	return PHD_OK;
 }
@@ -604,8 +610,8 @@ int phd_update_motion(phd_navigator* nav, const double* odometry6, const double*
 	return PHD_OK;
 }
 
-int phd_quasi_set_loglik(phd_navigator* nav, const double* poses7, int nposes, const double* landmarks3, int nlandmarks,
-                         const double* z3, int nmeasurements, double* out)
+static int quasi_batch(phd_navigator* nav, const double* poses7, int nposes, const double* landmarks3, int nlandmarks,
+                       const double* z3, int nmeasurements, double* out, double* gradients6, int average_mode)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	if (nposes < 1 || nposes > nav->Pcap || nlandmarks < 0 || nlandmarks > nav->Jcap || nmeasurements < 0 ||
@@ -613,7 +619,8 @@ int phd_quasi_set_loglik(phd_navigator* nav, const double* poses7, int nposes, c
 		return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_quasi_set_loglik: sizes out of range (poses <= max_particles, landmarks <= min(1024, max_quantity), measurements <= max_measurements)");
 	}
 	hipSetDevice(nav->device);
-	const size_t op = 0, ol = op + (size_t) nav->Pcap * 7, oz = ol + (size_t) nav->Jcap * 3, oo = oz + 256 * 3, total = oo + nav->Pcap;
+	const size_t op = 0, ol = op + (size_t) nav->Pcap * 7, oz = ol + (size_t) nav->Jcap * 3, oo = oz + 256 * 3, og = oo + nav->Pcap,
+	             total = og + (size_t) nav->Pcap * 6;
 	if (!nav->d_quasi) HC(hipMalloc((void**) &nav->d_quasi, total * 8));
 	HC(hipMemcpyAsync(nav->d_quasi + op, poses7, (size_t) nposes * 7 * 8, hipMemcpyHostToDevice, nav->stream));
 	if (nlandmarks) HC(hipMemcpyAsync(nav->d_quasi + ol, landmarks3, (size_t) nlandmarks * 3 * 8, hipMemcpyHostToDevice, nav->stream));
@@ -622,14 +629,18 @@ int phd_quasi_set_loglik(phd_navigator* nav, const double* poses7, int nposes, c
 	b.P = nposes; b.M = nmeasurements; b.z = nav->d_quasi + oz;
 	b.qposes = nav->d_quasi + op; b.qlm = nav->d_quasi + ol; b.qJ = nlandmarks;
 	b.setll = nav->d_quasi + oo;
+	b.qgrad = nav->d_quasi + og;
+	b.qavg  = average_mode;
+	const bool gradient = gradients6 != nullptr;
 	int rc;
 	switch (zb_of(nmeasurements)) {
-	case 1:  rc = launch_quasi<1>(nav, b, nposes); break;
-	case 2:  rc = launch_quasi<2>(nav, b, nposes); break;
-	default: rc = launch_quasi<4>(nav, b, nposes); break;
+	case 1:  rc = launch_quasi<1>(nav, b, nposes, gradient); break;
+	case 2:  rc = launch_quasi<2>(nav, b, nposes, gradient); break;
+	default: rc = launch_quasi<4>(nav, b, nposes, gradient); break;
 	}
 	if (rc) return rc;
 	HC(hipMemcpyAsync(out, nav->d_quasi + oo, (size_t) nposes * 8, hipMemcpyDeviceToHost, nav->stream));
+	if (gradient) HC(hipMemcpyAsync(gradients6, nav->d_quasi + og, (size_t) nposes * 6 * 8, hipMemcpyDeviceToHost, nav->stream));
 	HC(hipStreamSynchronize(nav->stream));
 	int flags = 0;
 	HC(hipMemcpy(&flags, nav->d_flags, 4, hipMemcpyDeviceToHost));
@@ -638,6 +649,21 @@ int phd_quasi_set_loglik(phd_navigator* nav, const double* poses7, int nposes, c
 		return nav->fail(PHD_ERR_ASSOCIATION, "phd_quasi_set_loglik: an association cluster exceeds the on-device solver");
 	}
 	return PHD_OK;
+}
+
+int phd_quasi_set_loglik(phd_navigator* nav, const double* poses7, int nposes, const double* landmarks3, int nlandmarks,
+                         const double* z3, int nmeasurements, double* out)
+{
+	return quasi_batch(nav, poses7, nposes, landmarks3, nlandmarks, z3, nmeasurements, out, nullptr, 0);
+}
+
+int phd_quasi_set_loglik_grad(phd_navigator* nav, const double* poses7, int nposes, const double* landmarks3, int nlandmarks,
+                              const double* z3, int nmeasurements, int average_mode, double* out, double* gradients6)
+{
+	if (nav && (!gradients6 || average_mode < 0 || average_mode > 1)) {
+		return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_quasi_set_loglik_grad: gradients6 is NULL or average_mode is not 0 / 1");
+	}
+	return quasi_batch(nav, poses7, nposes, landmarks3, nlandmarks, z3, nmeasurements, out, gradients6, average_mode);
 }
 
 int phd_set_weights(phd_navigator* nav, const double* weights, int nparticles)

@@ -82,6 +82,21 @@ public:
 		return out;
 	}
 
+	// ≙ static QuasiSetLogLikelihood(measurements, map, pose, out gradient) (:543-548) for a batch of candidate poses;
+	// averagemode: TemperedAverage as its source reads (0) or with weights that sum to one (1), see phdhip.h
+	std::vector<double> QuasiSetLogLikelihood(const std::vector<PixelRangeMeasurement>& measurements,
+	                                          const std::vector<std::array<double, 3>>& landmarks, const std::vector<Pose3D>& poses,
+	                                          std::vector<std::array<double, 6>>& gradients, int averagemode = 0)
+	{
+		std::vector<double> out(poses.size());
+		gradients.assign(poses.size(), std::array<double, 6>{});
+		check(phd_quasi_set_loglik_grad(nav_, poses.empty() ? nullptr : poses[0].data(), (int) poses.size(),
+		                                landmarks.empty() ? nullptr : landmarks[0].data(), (int) landmarks.size(),
+		                                measurements.empty() ? nullptr : measurements[0].data(), (int) measurements.size(), averagemode,
+		                                out.data(), gradients.empty() ? nullptr : gradients[0].data()));
+		return out;
+	}
+
 	// ≙ SlamUpdate (:323-362); `uniform` replaces (double) Util.Uniform.Next() of ResampleParticles (:727)
 	void SlamUpdate(const std::vector<PixelRangeMeasurement>& measurements, double uniform)
 	{

@@ -178,6 +178,18 @@ class PHDNavigator:
                                                    _ptr(z) if len(z) else None, len(z), _ptr(out)))
         return out
 
+    def QuasiSetLogLikelihoodGradient(self, measurements, landmarks, poses, average_mode=0):
+        """≙ static PHDNavigator.QuasiSetLogLikelihood(measurements, map, pose, out gradient) (PHDNavigator.cs:543-548),
+        batched over candidate poses (phd_quasi_set_loglik_grad): returns (values[n], gradients[n][6]).
+        average_mode: TemperedAverage as its source reads (0) or with weights that sum to one (1), see include/phdhip.h."""
+        z = np.ascontiguousarray(measurements, np.float64).reshape(-1, 3)
+        lm = np.ascontiguousarray(landmarks, np.float64).reshape(-1, 3)
+        poses = np.ascontiguousarray(poses, np.float64).reshape(-1, 7)
+        out, grad = np.zeros(len(poses)), np.zeros((len(poses), 6))
+        self._check(self._lib.phd_quasi_set_loglik_grad(self._h, _ptr(poses), len(poses), _ptr(lm) if len(lm) else None, len(lm),
+                                                        _ptr(z) if len(z) else None, len(z), int(average_mode), _ptr(out), _ptr(grad)))
+        return out, grad
+
     def LogLikeGradient(self, pose, measurements, landmarks, linearpoint):
         """≙ LoopyPHDNavigator.LogLikeGradient (LoopyPHDNavigator.cs:876-909): central differences (eps = 1e-5) of the
         quasi set log-likelihood at linearpoint.Add(pose +- eps e_i) — the 12 evaluations go to the device as one batch.

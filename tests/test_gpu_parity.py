@@ -324,6 +324,34 @@ def test_quasi_set_log_likelihood_batch(nav_mod, J, M, seed):
     nav.close()
 
 
+@pytest.mark.parametrize("J,M,seed", [(3, 4, 181), (40, 30, 182), (12, 70, 183), (300, 64, 184), (0, 5, 185), (6, 0, 186), (2, 3, 187)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_quasi_set_log_likelihood_gradient_batch(nav_mod, J, M, seed, mode):
+    """Row f4, gradient part: QuasiSetLogLikelihood(..., out gradient) (PHDNavigator.cs:543-713) for a batch of poses
+    (phd_quasi_set_loglik_grad) against the oracle, in both readings of TemperedAverage: clusters of every size (the
+    literal enumeration up to 5 rows, Murty beyond, whose cut reads the entries TemperedAverage rewrote), a map below 5
+    landmarks (`modelsize` cuts the enumeration), a landmark set beyond the LDS-resident limit, empty sets."""
+    rng = np.random.default_rng(seed)
+    f = Frame(48, max(J, 1), max(M, 1), seed, weight_profile="steady")
+    nav, p = make_nav(nav_mod, f)
+    lm = f.mean[0, :J].copy()
+    z = f.z[:M].copy()
+    if M > 3 and J > 3:
+        z[1] = z[0] + [3.0, -2.0, 0.01]
+        z[2] = z[0] + [-4.0, 1.0, -0.02]
+    poses = f.poses.copy()
+    poses[:, :3] += rng.normal(0, 5e-3, (f.P, 3))
+    poses[:, 3:] += rng.normal(0, 2e-3, (f.P, 4))
+    got, ggot = nav.QuasiSetLogLikelihoodGradient(z, lm, poses, average_mode=mode)
+    want = [orc.quasi_set_log_likelihood_grad(p, poses[i], lm, z, mode) for i in range(f.P)]
+    wv, wg = np.array([w[0] for w in want]), np.array([w[1] for w in want])
+    assert np.allclose(got, wv, rtol=1e-9, atol=1e-9), np.max(np.abs(got - wv))
+    assert np.allclose(ggot, wg, rtol=1e-8, atol=1e-7), np.max(np.abs(ggot - wg))
+    if J and M:
+        assert np.max(np.abs(wg)) > 1
+    nav.close()
+
+
 def test_loglike_gradient_through_the_batch(nav_mod):
     """LoopyPHDNavigator.LogLikeGradient (LoopyPHDNavigator.cs:876-909): the 12 finite-difference evaluations of a pose
     (here of 5 poses at once) as one device batch, against the oracle's restatement"""
