@@ -1,0 +1,81 @@
+"""SURVEY row f4 on the device: the smoother's pose searches (monorfs_amd/loopy.py) driven by the HIP batches against
+the same host code driven by the oracle (tests/loopy_stub.py), and Filter / FilterMissing against the oracle's filter."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import orc
+from loopy_stub import OracleNav, scene
+from monorfs_amd import loopy
+from monorfs_amd.abi import prm3d_defaults
+from monorfs_amd.navigator import pose3d_add
+from monorfs_amd.synth import Frame
+
+
+@pytest.fixture(scope="module")
+def nav():
+    from monorfs_amd import navigator
+    p = prm3d_defaults(max_particles=256, max_components=600, max_measurements=16)
+    n = navigator.PHDNavigator(p, particlecount=1)
+    yield n
+    n.close()
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_gradient_ascent_device_against_oracle(nav, mode):
+    rng = np.random.default_rng(21 + mode)
+    lin, lm, z = scene(rng, nav.params, 10, 7)
+    starts = rng.normal(0, 1, (6, 6)) * [4e-3, 4e-3, 4e-3, 2e-3, 2e-3, 2e-3]
+    got, gotv = loopy.LogLikeGradientAscent(nav, starts, z, lm, lin, mode)
+    want, wantv = loopy.LogLikeGradientAscent(OracleNav(nav.params), starts, z, lm, lin, mode)
+    assert np.allclose(gotv, wantv, rtol=1e-9, atol=1e-8), np.max(np.abs(gotv - wantv))
+    assert np.allclose(got, want, rtol=0, atol=1e-9), np.max(np.abs(got - want))
+    assert np.any(np.abs(got - starts) > 1e-5)                      # some estimate did climb
+
+
+def test_fit_gaussian_and_guided_mixture_device_against_oracle(nav):
+    rng = np.random.default_rng(31)
+    lin, lm, z = scene(rng, nav.params, 6, 5, sigma=0.3)
+    stub = OracleNav(nav.params)
+    mean, cov = loopy.FitGaussian(nav, np.zeros(6), z, lm, lin, 1)
+    wmean, wcov = loopy.FitGaussian(stub, np.zeros(6), z, lm, lin, 1)
+    assert np.allclose(mean, wmean, atol=1e-9)
+    assert np.allclose(cov, wcov, rtol=1e-4, atol=1e-12)            # pinv of a finite-difference Hessian (eps 1e-5)
+    model = (np.full(len(lm), 1.0001), lm, np.broadcast_to(1e-4 * np.eye(3), (len(lm), 3, 3)))
+    empty, comps = loopy.GuidedFitMixture(nav, np.zeros(6), z, model, lin, 1)
+    wempty, wcomps = loopy.GuidedFitMixture(stub, np.zeros(6), z, model, lin, 1)
+    assert np.isclose(empty, wempty, rtol=1e-12)
+    assert len(comps) == len(wcomps) >= 1
+    for (w, m, c), (ww, wm, wc) in zip(comps, wcomps):
+        assert np.allclose(m, wm, atol=1e-9) and np.allclose(c, wc, rtol=1e-4, atol=1e-12)
+        assert np.isclose(w, ww, rtol=1e-3)
+
+
+def test_filter_missing_against_oracle(nav):
+    """LoopyPHDNavigator.FilterMissing (:729-762): one-particle mapping-only filter over a trajectory with one factor
+    left out, against the oracle's SlamUpdate run over the same frames"""
+    rng = np.random.default_rng(41)
+    f = Frame(1, 40, 12, 41, weight_profile="steady")
+    T = 6
+    trajectory, factors = [], []
+    for t in range(T):
+        pose = pose3d_add(f.poses[0], rng.normal(0, 1, 6) * [3e-3, 3e-3, 3e-3, 1e-3, 1e-3, 1e-3])
+        zt = f.z + rng.normal(0, 1, f.z.shape) * [0.5, 0.5, 0.01]
+        trajectory.append((0.1 * t, pose))
+        factors.append((0.1 * t, zt))
+    for index, to in ((2, T), (T, T), (-1, 4)):
+        got = loopy.FilterMissing(nav, trajectory, factors, index, to)
+        st = orc.State(1, 900)
+        to_ = min(T, to)
+        idx = to_ if index < 0 else min(to_, index)
+        for i in list(range(idx)) + list(range(idx + 1, to_)):
+            st.poses[0] = trajectory[i][1]
+            orc.slam_update(nav.params, st, factors[i][1], onlymapping=True)
+        w, m, c = st.map(0)
+        gw, gm, gc = got
+        assert len(gw) == len(w) > 0
+        o, og = np.argsort(-w, kind="stable"), np.argsort(-gw, kind="stable")
+        assert np.allclose(gw[og], w[o], rtol=1e-7) and np.allclose(gm[og], m[o], rtol=1e-7, atol=1e-10)
+        assert np.allclose(gc[og], c[o], rtol=1e-6, atol=1e-12)
+    assert np.array_equal(loopy.Filter(nav, trajectory, factors)[0], loopy.FilterMissing(nav, trajectory, factors, T, T)[0])
