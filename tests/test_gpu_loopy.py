@@ -79,3 +79,45 @@ def test_filter_missing_against_oracle(nav):
         assert np.allclose(gw[og], w[o], rtol=1e-7) and np.allclose(gm[og], m[o], rtol=1e-7, atol=1e-10)
         assert np.allclose(gc[og], c[o], rtol=1e-6, atol=1e-12)
     assert np.array_equal(loopy.Filter(nav, trajectory, factors)[0], loopy.FilterMissing(nav, trajectory, factors, T, T)[0])
+
+
+def test_cpp_mirror_matches_python(nav, tmp_path):
+    """monorfs_amd/host/Loopy.hpp (tests/loopy_check.cpp) against monorfs_amd/loopy.py on the same scene: the same device
+    batches behind the same host arithmetic"""
+    import os
+    import subprocess
+    from monorfs_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = _lib.build()
+    exe = str(tmp_path / "loopy_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(root, "tests", "loopy_check.cpp"), so,
+                           "-Wl,-rpath," + os.path.dirname(so), "-Wl,-rpath,/opt/rocm/lib"])
+    rng = np.random.default_rng(51)
+    lin, lm, z = scene(rng, nav.params, 9, 6)
+    lin = pose3d_add(lin, [0.01, -0.02, 0.005, 0.02, 0.01, -0.03])
+    starts = rng.normal(0, 1, (5, 6)) * [4e-3, 4e-3, 4e-3, 2e-3, 2e-3, 2e-3]
+    f = Frame(1, 30, 10, 52, weight_profile="steady")
+    T = 4
+    trajectory = [(0.1 * t, pose3d_add(f.poses[0], rng.normal(0, 1, 6) * 2e-3)) for t in range(T)]
+    factors = [(0.1 * t, f.z + rng.normal(0, 1, f.z.shape) * [0.5, 0.5, 0.01]) for t in range(T)]
+    path = tmp_path / "scene.txt"
+    with open(path, "w") as fh:
+        num = lambda a: " ".join("%.17g" % v for v in np.asarray(a, float).ravel())
+        fh.write("%d %d %d %d\n%s\n%s\n%s\n%s\n" % (len(lm), len(z), len(starts), T, num(lm), num(z), num(lin), num(starts)))
+        for (t, pose), (_, zt) in zip(trajectory, factors):
+            fh.write("%.17g %s %d %s\n" % (t, num(pose), len(zt), num(zt)))
+    for mode in (0, 1):
+        r = subprocess.run([exe, str(path), str(mode)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        rows = [ln.split() for ln in r.stdout.splitlines()]
+        asc = np.array([[float(v) for v in row[1:]] for row in rows if row[0] == "ascent"])
+        poses, values = loopy.LogLikeGradientAscent(nav, starts, z, lm, lin, mode)
+        assert np.allclose(asc[:, 0], values, rtol=1e-12, atol=1e-12) and np.allclose(asc[:, 1:], poses, rtol=0, atol=1e-13)
+        grad = np.array([float(v) for row in rows if row[0] == "gradient" for v in row[1:]])
+        assert np.allclose(grad, nav.LogLikeGradient(starts[0], z, lm, lin), rtol=1e-6, atol=1e-3)
+        rt = np.array([float(v) for row in rows if row[0] == "roundtrip" for v in row[1:]])
+        assert np.allclose(rt, starts[0], atol=1e-12)
+        comp = np.array([[float(v) for v in row[1:]] for row in rows if row[0] == "component"])
+        w, m, c = loopy.FilterMissing(nav, trajectory, factors, 1, T)
+        assert len(comp) == len(w) > 0
+        assert np.array_equal(comp[:, 0], w) and np.array_equal(comp[:, 1:4], m) and np.array_equal(comp[:, 4:], c.reshape(-1, 9))
