@@ -1,6 +1,7 @@
 // Ospa.hpp — the map-error metric of the reference's post-analysis, host side, C++.
 //
 //   Plot.OSPA(a, b, out cardinalityerror)   postanalysis/Plot.cs:531-581     (LandmarkDistance :583-586)
+//   Plot.MapError, Plot.VisitedMap           postanalysis/Plot.cs:478-529, :230-248   (at the end of this file)
 //
 // OSPA of order P with cut-off C between two landmark sets: with m = |a| <= n = |b|,
 //     ( ( min over assignments of sum_i min(C, |a_i - b_pi(i)|)^P  +  C^P (n - m) ) / n )^(1/P)
@@ -84,6 +85,85 @@ inline double OSPA(const std::vector<std::array<double, 3>>& a, const std::vecto
 	}
 	if (cardinalityerror) *cardinalityerror = C * std::pow((double) (n - m) / n, 1.0 / P);
 	return std::pow(AssignmentMinCost(cost, n) / n, 1.0 / P);
+}
+
+// ---- Plot.MapError (postanalysis/Plot.cs:478-529) and Plot.VisitedMap (:230-248) ----
+
+// VisitedMap: the landmarks seen (weight > 0) in any frame so far, each once — a landmark is new when nothing already
+// kept lies within 1e-5 of it (`cumulative.Near(landmark.Mean, 1e-5)`; the KD-tree's metric is outside the reference
+// tree, at this radius only exact repeats matter). frames[i] = visible landmarks of frame i as (x, y, z, weight).
+inline std::vector<std::array<double, 3>> VisitedMap(const std::vector<std::vector<std::array<double, 4>>>& frames)
+{
+	std::vector<std::array<double, 3>> cumulative;
+	for (const auto& frame : frames) {
+		for (const auto& l : frame) {
+			if (!(l[3] > 0)) continue;
+			bool near = false;
+			for (const auto& c : cumulative) {
+				double d0 = c[0] - l[0], d1 = c[1] - l[1], d2 = c[2] - l[2];
+				if (std::sqrt(d0 * d0 + d1 * d1 + d2 * d2) <= 1e-5) { near = true; break; }
+			}
+			if (!near) cumulative.push_back({l[0], l[1], l[2]});
+		}
+	}
+	return cumulative;
+}
+
+// One frame of MapError: the map estimate (means of Map.BestMapEstimate) is first moved by the difference between
+// the estimated and the true pose at the reference time — delta = FromLinear(estimate.Subtract(truth)) (:502-503),
+// p' = R(delta.q*) (p - c) + c - delta.x with c the estimated location (:505-507, :514-515) — then compared with the
+// visited map by OSPA; the spatial part is (ospa^P - cardinality^P)^(1/P) (:521). Poses are x y z qw qx qy qz.
+// hasreference = false (the estimate is shorter than RefTime, :500): no alignment.
+inline double MapError(const std::vector<std::array<double, 3>>& visited, const std::vector<std::array<double, 3>>& estimate,
+                       bool hasreference, const std::array<double, 7>& estimatedpose, const std::array<double, 7>& truepose,
+                       double C, double P, double* spatialerror = nullptr)
+{
+	std::vector<std::array<double, 3>> refmap = estimate;
+	if (hasreference) {
+		auto mul = [](const std::array<double, 4>& a, const std::array<double, 4>& b) {   // Quaternion.cs:295-301
+			return std::array<double, 4>{a[0] * b[0] - (a[1] * b[1] + a[2] * b[2] + a[3] * b[3]),
+			                             a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+			                             a[0] * b[2] + a[2] * b[0] + a[3] * b[1] - a[1] * b[3],
+			                             a[0] * b[3] + a[3] * b[0] + a[1] * b[2] - a[2] * b[1]};
+		};
+		auto normalized = [](std::array<double, 4> q) {
+			double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+			for (double& x : q) x /= n;
+			return q;
+		};
+		// estimate.Subtract(truth) (Pose3D.cs:296-308)
+		const std::array<double, 4> qe = normalized({estimatedpose[3], estimatedpose[4], estimatedpose[5], estimatedpose[6]});
+		const std::array<double, 4> qt = normalized({truepose[3], truepose[4], truepose[5], truepose[6]});
+		const std::array<double, 4> qtc = {qt[0], -qt[1], -qt[2], -qt[3]};
+		const std::array<double, 4> dq = normalized(mul(qtc, qe));
+		const std::array<double, 4> dx = mul(mul(qtc, {0, estimatedpose[0] - truepose[0], estimatedpose[1] - truepose[1],
+		                                                estimatedpose[2] - truepose[2]}), qt);
+		const double phi = std::acos(std::min(1.0, std::max(-1.0, dq[0])));   // Quaternion.Log, Quaternion.cs:204-218
+		const double mag = std::sqrt(dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]);
+		double lie[3] = {0, 0, 0};                                             // dq.ToLinear() / 2
+		if (!(mag < 1e-12)) { lie[0] = phi * dq[1] / mag; lie[1] = phi * dq[2] / mag; lie[2] = phi * dq[3] / mag; }
+		// FromLinear = Identity.Add (Pose3D.cs:248-251, :282-291): location = the translation part, orientation = Exp(lie)
+		const double ang = std::sqrt(lie[0] * lie[0] + lie[1] * lie[1] + lie[2] * lie[2]);
+		std::array<double, 4> dori = {1, 0, 0, 0};
+		if (!(ang < 1e-12)) {
+			const double sn = std::sin(ang);
+			dori = normalized({std::cos(ang), sn * (lie[0] / ang), sn * (lie[1] / ang), sn * (lie[2] / ang)});
+		}
+		const double X = -dori[1], Y = -dori[2], Z = -dori[3], W = dori[0];    // Conjugate().ToMatrix(), Quaternion.cs:327-342
+		const double R[9] = {1 - 2 * (Y * Y + Z * Z), 2 * (X * Y - Z * W), 2 * (X * Z + Y * W),
+		                     2 * (X * Y + Z * W), 1 - 2 * (X * X + Z * Z), 2 * (Y * Z - X * W),
+		                     2 * (X * Z - Y * W), 2 * (Y * Z + X * W), 1 - 2 * (X * X + Y * Y)};
+		for (auto& m : refmap) {
+			const double d[3] = {m[0] - estimatedpose[0], m[1] - estimatedpose[1], m[2] - estimatedpose[2]};
+			for (int i = 0; i < 3; i++) {
+				m[i] = (R[i * 3] * d[0] + R[i * 3 + 1] * d[1] + R[i * 3 + 2] * d[2]) + estimatedpose[i] + (-1.0) * dx[i + 1];
+			}
+		}
+	}
+	double card = 0;
+	const double ospa = OSPA(visited, refmap, C, P, &card);
+	if (spatialerror) *spatialerror = std::pow(std::pow(ospa, P) - std::pow(card, P), 1.0 / P);
+	return ospa;
 }
 
 }  // namespace monorfs

@@ -1680,4 +1680,37 @@ double orc_ospa(const double* a3, int na, const double* b3, int nb, double C, do
 	return std::pow(assignment_value(t, best) / nb, 1.0 / P);
 }
 
+// Plot.MapError, one frame (postanalysis/Plot.cs:489-524): the map estimate aligned by the pose error at the reference
+// time, then OSPA against the visited map and its spatial part.
+double orc_map_error(const double* visited3, int nv, const double* estimate3, int ne, int hasreference,
+                     const double* estimatedpose7, const double* truepose7, double C, double P, double* spatial)
+{
+	std::vector<double> ref(estimate3, estimate3 + (size_t) ne * 3);
+	if (hasreference) {
+		// delta = dummy.FromLinear(estimate.Subtract(truth)) (:502-503); Subtract: Pose3D.cs:296-308
+		const Pose e = make_pose(estimatedpose7), t = make_pose(truepose7);
+		Quat dq = qnormalize(qmul(qconj(t.q), e.q));
+		Quat dx = qmul(qmul(qconj(t.q), Quat{0, e.t[0] - t.t[0], e.t[1] - t.t[1], e.t[2] - t.t[2]}), t.q);
+		double phi = std::acos(std::min(1.0, std::max(-1.0, dq.w)));
+		double mag = std::sqrt(dq.x * dq.x + dq.y * dq.y + dq.z * dq.z);
+		double lin[6] = {dx.x, dx.y, dx.z, 0, 0, 0};   // ToLinear = 2 Log (Quaternion.cs:176-179, :204-218)
+		if (!(mag < 1e-12)) { lin[3] = 2 * phi * dq.x / mag; lin[4] = 2 * phi * dq.y / mag; lin[5] = 2 * phi * dq.z / mag; }
+		const double identity[7] = {0, 0, 0, 1, 0, 0, 0};
+		double delta[7];
+		orc_pose_add(identity, lin, delta);            // FromLinear = Identity.Add (Pose3D.cs:248-251)
+		double R[9];
+		qmatrix(qconj(Quat{delta[3], delta[4], delta[5], delta[6]}), R);   // drotation (:506)
+		for (int j = 0; j < ne; j++) {                 // :514-515
+			double d[3] = {ref[j * 3] - e.t[0], ref[j * 3 + 1] - e.t[1], ref[j * 3 + 2] - e.t[2]};
+			for (int i = 0; i < 3; i++) {
+				ref[j * 3 + i] = (R[i * 3] * d[0] + R[i * 3 + 1] * d[1] + R[i * 3 + 2] * d[2]) + e.t[i] + (-1.0) * delta[i];
+			}
+		}
+	}
+	double card = 0;
+	double ospa = orc_ospa(visited3, nv, ref.data(), ne, C, P, &card);
+	if (spatial) *spatial = std::pow(std::pow(ospa, P) - std::pow(card, P), 1.0 / P);   // :521
+	return ospa;
+}
+
 }  // extern "C"

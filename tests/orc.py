@@ -357,3 +357,17 @@ def jacobian_p(p, pose7, lm):
     out, op = _d(np.zeros(18))
     lib.orc_jacobian_p(C.byref(p), ap, lp, op)
     return out.reshape(3, 6)
+
+
+def map_error(visited, estimate, estimated_pose=None, true_pose=None, cutoff=1.0, order=1.0):
+    """Plot.MapError, one frame (postanalysis/Plot.cs:489-524): (ospa, spatial part); poses None = no reference frame"""
+    v, vp = _d(np.asarray(visited, float).reshape(-1, 3))
+    e, ep = _d(np.asarray(estimate, float).reshape(-1, 3))
+    has = estimated_pose is not None
+    a, ap = _d(np.asarray(estimated_pose if has else [0, 0, 0, 1, 0, 0, 0], float))
+    b, bp = _d(np.asarray(true_pose if has else [0, 0, 0, 1, 0, 0, 0], float))
+    lib.orc_map_error.restype = C.c_double
+    lib.orc_map_error.argtypes = [dp, C.c_int, dp, C.c_int, C.c_int, dp, dp, C.c_double, C.c_double, dp]
+    sp, spp = _d(np.zeros(1))
+    d = lib.orc_map_error(vp, len(v), ep, len(e), int(has), ap, bp, float(cutoff), float(order), spp)
+    return d, sp[0]
