@@ -517,8 +517,8 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int M = a.M, cap = a.cap;
 	const MixView vin = bank_view(a, SEL_IN), vout = bank_view(a, SEL_OUT);
-	const Bank& bin  = a.bank[a.sel[SEL_IN]];
-	const Bank& bout = a.bank[a.sel[SEL_OUT]];
+	const Bank bin = bank_of(a, SEL_IN);
+	const Bank bout = bank_of(a, SEL_OUT);
 	const int no = QUASI ? 0 : vout.count[p];
 	const size_t sbo = (size_t) p * cap;
 	const PoseD pose = load_pose(QUASI ? a.qposes + (size_t) p * 7 : bin.poses + (size_t) p * 7);
@@ -1284,8 +1284,8 @@ __global__ __launch_bounds__(256) void k_alpha_density(const DevParams prm, cons
 	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int cap = a.cap;
 	const MixView vin = bank_view(a, SEL_IN), vout = bank_view(a, SEL_OUT);
-	const Bank& bin  = a.bank[a.sel[SEL_IN]];
-	const Bank& bout = a.bank[a.sel[SEL_OUT]];
+	const Bank bin = bank_of(a, SEL_IN);
+	const Bank bout = bank_of(a, SEL_OUT);
 	const int n = vin.count[p], nb = a.born_count[p], no = vout.count[p];
 	const int np = n + nb;
 	const size_t sbi = (size_t) p * cap, sbo = (size_t) p * cap;

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_emit_finish(const DevParams prm, const 
 	const int p = a.p0 + blockIdx.x, tid = threadIdx.x;
 	const int M = a.M;
 	const MixView vin = bank_view(a, SEL_IN);
-	const Bank& bin = a.bank[a.sel[SEL_IN]];
+	const Bank bin = bank_of(a, SEL_IN);
 	const int n = vin.count[p], np = n + a.born_count[p];
 	const int nmis = a.emit_count[p];
 	const int ncand = a.cand_count[p];

@@ -84,9 +84,23 @@ struct StepBufs {
 	int     stamp_kernel; // which kernel writes them (env PHD_STAMP_KERNEL): 2 prune, 3 assoc, 4 density, 1 correct
 };
 
+// The bank playing `role`. The roles rotate on the device (a.sel lives in device memory), so the index is not known
+// at launch; choosing among the three kernel-argument entries by comparison keeps them in scalar registers — indexing
+// the array dynamically makes the compiler copy the argument block to scratch memory.
+__device__ __forceinline__ Bank bank_of(const StepBufs& a, int role)
+{
+	const int s = a.sel[role];
+	Bank b;
+	b.mix     = (s == 0) ? a.bank[0].mix     : ((s == 1) ? a.bank[1].mix     : a.bank[2].mix);
+	b.count   = (s == 0) ? a.bank[0].count   : ((s == 1) ? a.bank[1].count   : a.bank[2].count);
+	b.poses   = (s == 0) ? a.bank[0].poses   : ((s == 1) ? a.bank[1].poses   : a.bank[2].poses);
+	b.weights = (s == 0) ? a.bank[0].weights : ((s == 1) ? a.bank[1].weights : a.bank[2].weights);
+	return b;
+}
+
 __device__ __forceinline__ MixView bank_view(const StepBufs& a, int role)
 {
-	const Bank& b = a.bank[a.sel[role]];
+	const Bank b = bank_of(a, role);
 	MixView v;
 	v.w = b.mix;
 #pragma unroll
@@ -140,9 +154,9 @@ __global__ __launch_bounds__(256) void k_gather_rotate(const StepBufs a, const i
 	}
 	if (tid == 0) {
 		dst.count[i] = n;
-		a.bank[T].weights[i] = a.bank[O].weights[i];
+		bank_of(a, SEL_TMP).weights[i] = bank_of(a, SEL_OUT).weights[i];
 	}
-	if (tid < 7) a.bank[T].poses[(size_t) i * 7 + tid] = a.bank[O].poses[(size_t) s * 7 + tid];
+	if (tid < 7) bank_of(a, SEL_TMP).poses[(size_t) i * 7 + tid] = bank_of(a, SEL_OUT).poses[(size_t) s * 7 + tid];
 }
 
 // Particle motion: TrackVehicle.UpdateNoisy (TrackVehicle.cs:89-102) = Pose3D.AddOdometry
@@ -213,8 +227,8 @@ __global__ __launch_bounds__(256) void k_replicate(const StepBufs a, double weig
 #pragma unroll
 		for (int t = 0; t < 6; t++) dst.P[t][db + c] = from.P[t][c];
 	}
-	const Bank& bi = a.bank[a.sel[SEL_IN]];
-	const Bank& bo = a.bank[a.sel[SEL_OUT]];
+	const Bank bi = bank_of(a, SEL_IN);
+	const Bank bo = bank_of(a, SEL_OUT);
 	if (tid == 0) {
 		dst.count[i]  = n;
 		bo.weights[i] = weight;
@@ -230,7 +244,7 @@ __global__ __launch_bounds__(256) void k_replicate(const StepBufs a, double weig
 __global__ __launch_bounds__(256) void k_scatter_weights(const StepBufs a, const double* gw, int first)
 {
 	int i = blockIdx.x * 256 + threadIdx.x;
-	if (i < a.P) a.bank[a.sel[SEL_OUT]].weights[i] = gw[first + i];
+	if (i < a.P) bank_of(a, SEL_OUT).weights[i] = gw[first + i];
 }
 
 __global__ __launch_bounds__(256) void k_pack_particles(const StepBufs a, const int* sendlist, double* sendbuf)
@@ -238,7 +252,7 @@ __global__ __launch_bounds__(256) void k_pack_particles(const StepBufs a, const 
 	const int r = blockIdx.x, tid = threadIdx.x;
 	const int s = sendlist[r];
 	const MixView from = bank_view(a, SEL_OUT);
-	const Bank& bo = a.bank[a.sel[SEL_OUT]];
+	const Bank bo = bank_of(a, SEL_OUT);
 	const size_t rec = (size_t) 8 + (size_t) 10 * a.cap;
 	double* o = sendbuf + (size_t) r * rec;
 	const int n = from.count[s];
@@ -262,7 +276,6 @@ __global__ __launch_bounds__(256) void k_gather_local(const StepBufs a, const in
 	const int i = blockIdx.x, tid = threadIdx.x;
 	const int s = gsrc[first + i] - first;
 	if (s < 0 || s >= a.P) return;   // remote source: filled by k_unpack_gather from the receive buffer
-	const int O = a.sel[SEL_OUT], T = a.sel[SEL_TMP];
 	const MixView from = bank_view(a, SEL_OUT), dst = bank_view(a, SEL_TMP);
 	const int n = from.count[s];
 	const size_t db = (size_t) i * a.cap, fb = (size_t) s * a.cap;
@@ -274,7 +287,7 @@ __global__ __launch_bounds__(256) void k_gather_local(const StepBufs a, const in
 		for (int t = 0; t < 6; t++) dst.P[t][db + c] = from.P[t][fb + c];
 	}
 	if (tid == 0) dst.count[i] = n;
-	if (tid < 7) a.bank[T].poses[(size_t) i * 7 + tid] = a.bank[O].poses[(size_t) s * 7 + tid];
+	if (tid < 7) bank_of(a, SEL_TMP).poses[(size_t) i * 7 + tid] = bank_of(a, SEL_OUT).poses[(size_t) s * 7 + tid];
 }
 
 // dstsrc[i] >= 0: local source slot in the OUT bank (skipped when k_gather_local already copied those);
@@ -304,7 +317,7 @@ __global__ __launch_bounds__(256) void k_unpack_gather(const StepBufs a, const i
 			for (int t = 0; t < 6; t++) dst.P[t][db + c] = from.P[t][fb + c];
 		}
 		if (tid == 0) dst.count[i] = n;
-		if (tid < 7) a.bank[T].poses[(size_t) i * 7 + tid] = a.bank[O].poses[(size_t) code * 7 + tid];
+		if (tid < 7) bank_of(a, SEL_TMP).poses[(size_t) i * 7 + tid] = bank_of(a, SEL_OUT).poses[(size_t) code * 7 + tid];
 	}
 	else {
 		const size_t rec = (size_t) 8 + (size_t) 10 * a.cap;
@@ -318,7 +331,7 @@ __global__ __launch_bounds__(256) void k_unpack_gather(const StepBufs a, const i
 			for (int t = 0; t < 6; t++) dst.P[t][db + c] = r[8 + (size_t) (4 + t) * a.cap + c];
 		}
 		if (tid == 0) dst.count[i] = n;
-		if (tid < 7) a.bank[T].poses[(size_t) i * 7 + tid] = r[1 + tid];
+		if (tid < 7) bank_of(a, SEL_TMP).poses[(size_t) i * 7 + tid] = r[1 + tid];
 	}
-	if (tid == 0) a.bank[T].weights[i] = weight;
+	if (tid == 0) bank_of(a, SEL_TMP).weights[i] = weight;
 }

@@ -17,7 +17,8 @@
 //                 limits the candidates of a row to a ball; the rows are binned in a uniform grid (hashed
 //                 cells) and the <= 8 buckets the ball meets are walked as one list of float32 records, the
 //                 survivors of the float32 distance test take the exact FP64 test. Each row keeps its first 7
-//                 close rows.
+//                 close rows. The rows go to the lanes in the order of their candidate counts (a second counting
+//                 sort), so that a wave is not held up by the one row of a crowded cell in it.
 //   C. resolve  : one wave walks the rows in weight order, 64 row records at a time held in its lanes and
 //                 the "absorbed" bits spread over its lanes (integer work only); rows with more than 7
 //                 close rows are re-tested by the 64 lanes.
@@ -45,8 +46,8 @@ __host__ __device__ inline PruneLds prune_lds(int cutcap)
 	l.NS    = NS;
 	l.rad2  = 0;
 	l.x     = l.rad2 + cc;                   // sort words u64[NS]  |  the lists of the pair search (see `rest`)
-	// nbr u64[2*cc], cand float4[cc], owner int[cc], cstart u16[NB+2], absb int[64]
-	int rest  = 2 * cc + 2 * cc + cc / 2 + (PRUNE_NB + 2) / 4 + 1 + 32 + 4;
+	// nbr u64[2*cc], cand float4[cc], owner int[cc], cstart u16[NB+2], absb int[64], ord u16[cc]
+	int rest  = 2 * cc + 2 * cc + cc / 2 + (PRUNE_NB + 2) / 4 + 1 + 32 + cc / 4 + 1 + 4;
 	l.scan  = l.x + (NS > rest ? NS : rest);
 	l.bytes = (l.scan + 136) * 8;            // int[264] | double[28], + spare
 	return l;
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	unsigned int* cw = (unsigned int*) (owner + cc);       // [(NB + 2) / 2] two 16-bit bucket boundaries per word
 	const unsigned short* cstart = (const unsigned short*) cw;   // [NB + 2] bucket b is [cstart[b], cstart[b + 1])
 	int*    absb  = (int*) (cw + (PRUNE_NB + 2) / 2 + 1);  // [64] absorbed bits as left by the resolving wave
+	unsigned short* ord = (unsigned short*) (absb + 64);   // [cut] rows in the order the pair search takes them
 	int*    scan  = (int*) (smem + lay.scan);              // [264]
 	double* bred  = smem + lay.scan;                       // [28] block reduction scratch (before `scan` is used)
 
@@ -188,6 +190,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	const MixView vout = bank_view(a, SEL_OUT);
 	const int ne = a.emit_count[p];
 	const size_t eb = (size_t) p * a.ecap;
+	const double merge_thr2 = prm.merge_thr2;   // a local copy: a lambda that captured `prm` by reference would pin the argument block to memory
 	const int cut = min(min(prm.maxq, ne), cutcap);   // weightcut: every emitted weight is already >= MinWeight
 	double* srec = a.srec + (size_t) p * 10 * cutcap;  // [10][cutcap] the kept records in sorted order: mean, covariance, weight
 
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 		const double P0 = v[3], P1 = v[4], P2 = v[5], P3 = v[6], P4 = v[7], P5 = v[8];
 		double det = P0 * (P3 * P5 - P4 * P4) - P1 * (P1 * P5 - P4 * P2) + P2 * (P1 * P4 - P3 * P2);
 		bool pd = P0 > 0 && (P0 * P3 - P1 * P1) > 0 && det > 0;   // Sylvester
-		double rad = pd ? sqrt(prm.merge_thr2 * (P0 + P3 + P5)) : INFINITY;
+		double rad = pd ? sqrt(merge_thr2 * (P0 + P3 + P5)) : INFINITY;
 		rad2[r] = rad * rad * (1.0 + 1e-6);
 		if (pd) rmx = fmax(rmx, rad);
 		lo0 = fmin(lo0, v[0]); lo1 = fmin(lo1, v[1]); lo2 = fmin(lo2, v[2]);
@@ -344,23 +347,76 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 		__syncthreads();
 		PHD_STAMP(7);
 
+		// The rows are handed to the lanes in the order of their candidate counts (the rows of the 8 buckets their ball
+		// meets; cells near the sensor hold an order of magnitude more rows than the rest): a wave then walks as long as
+		// its rows need on average, not as long as the one unlucky row in it. Counting sort by min(count, 63); 63 also
+		// stands for the rows that must test every later row.
+		auto ranges = [&](int i, unsigned int* qb) {   // the 8 bucket ranges of row i as start | length << 16; returns the total
+			const double m0 = srec[i], m1 = srec[(size_t) cutcap + i], m2 = srec[(size_t) 2 * cutcap + i];
+			const int bx = (int) floor((m0 - mn0) * icell - 0.5), by = (int) floor((m1 - mn1) * icell - 0.5),
+			          bz = (int) floor((m2 - mn2) * icell - 0.5);
+			const unsigned int xa0 = (unsigned int) (bx >> 1) * HA, xa1 = (unsigned int) ((bx + 1) >> 1) * HA;
+			const unsigned int yb0 = (unsigned int) (by >> 1) * HB, yb1 = (unsigned int) ((by + 1) >> 1) * HB;
+			const unsigned int zc0 = (unsigned int) (bz >> 1) * HC, zc1 = (unsigned int) ((bz + 1) >> 1) * HC;
+			const int par0 = (bx & 1) | ((by & 1) << 1) | ((bz & 1) << 2);
+			int n = 0;
+#pragma unroll
+			for (int c = 0; c < 8; c++) {
+				const unsigned int h = ((c & 1) ? xa1 : xa0) ^ ((c & 2) ? yb1 : yb0) ^ ((c & 4) ? zc1 : zc0);
+				const int bk = (int) ((h & (PRUNE_NB / 8 - 1)) << 3) | (par0 ^ c);   // neighbours flip the parity bits
+				const int s0 = cstart[bk], n0 = cstart[bk + 1] - s0;
+				qb[c] = (unsigned int) s0 | ((unsigned int) n0 << 16);
+				n += n0;
+			}
+			return n;
+		};
+		int* hist = scan;   // [64]
+		if (tid < 64) hist[tid] = 0;
+		__syncthreads();
 		for (int i = tid; i < cut; i += 256) {
+			int key = 63;
+			if (rad2[i] <= rcap * rcap) {
+				unsigned int qb[8];
+				key = min(ranges(i, qb), 62);
+			}
+			owner[i] = key;
+			atomicAdd(&hist[key], 1);
+		}
+		__syncthreads();
+		if (tid < 64) {   // hist[key] = first position of the rows with that key, lightest first: thread t takes the positions
+			// t, t + 256, ..., so the waves that get a last, partial round of the heaviest rows started with the lightest
+			const int h = hist[tid];
+			int incl = h;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				int y = __shfl_up(incl, o, 64);
+				if (lane >= o) incl += y;
+			}
+			hist[tid] = incl - h;
+		}
+		__syncthreads();
+		for (int i = tid; i < cut; i += 256) {
+			ord[atomicAdd(&hist[owner[i]], 1)] = (unsigned short) i;
+			owner[i] = -1;
+		}
+		__syncthreads();
+		PHD_STAMP(8);
+
+		for (int t = tid; t < cut; t += 256) {
+			const int i = ord[t];
 			double P[6], Pi[6], det;
 #pragma unroll
-			for (int t = 0; t < 6; t++) P[t] = srec[(size_t) (3 + t) * cutcap + i];
+			for (int u = 0; u < 6; u++) P[u] = srec[(size_t) (3 + u) * cutcap + i];
 			inv_sym3(P, Pi, det);
 			const double m0 = srec[i], m1 = srec[(size_t) cutcap + i], m2 = srec[(size_t) 2 * cutcap + i], bound = rad2[i];
 			int cnt = 0;
-#ifdef PHD_STAMP_COUNTERS
-			int dbg_walk = 0, dbg_test = 0;
-#endif
 			unsigned int e[PRUNE_NBR];   // close rows found (statically indexed only)
 #pragma unroll
 			for (int q = 0; q < PRUNE_NBR; q++) e[q] = 0xffffu;
 			auto test = [&](int k) {
 				double d0 = m0 - srec[k], d1 = m1 - srec[(size_t) cutcap + k], d2 = m2 - srec[(size_t) 2 * cutcap + k];
 				double sq = d0 * d0 + d1 * d1 + d2 * d2;
-				if (sq <= bound && quad_sym(Pi, d0, d1, d2) < prm.merge_thr2) {   // Gaussian.SquareMahalanobis(b.Mean) < threshold^2
+				if (sq <= bound && quad_sym(Pi, d0, d1, d2) < merge_thr2) {   // Gaussian.SquareMahalanobis(b.Mean) < threshold^2
 					// keep the 7 smallest row numbers, ascending (insertion through a fixed network)
 					unsigned int v = (unsigned int) k;
 #pragma unroll
@@ -372,8 +428,6 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 				}
 			};
 			if (bound <= rcap * rcap) {
-				const int bx = (int) floor((m0 - mn0) * icell - 0.5), by = (int) floor((m1 - mn1) * icell - 0.5),
-				          bz = (int) floor((m2 - mn2) * icell - 0.5);
 				const float fx = (float) (m0 - mn0), fy = (float) (m1 - mn1), fz = (float) (m2 - mn2);
 				const double rr = sqrt(bound) + ferr;
 				const float thr = (float) (rr * rr * (1.0 + 1e-5));
@@ -386,49 +440,30 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 					}
 					pend0 = 0; pend1 = 0;
 				};
-				// the exact test is rare per lane but not per wave: a candidate that passes the float32 distance test is
-				// queued and tested later, so that the waves do not run the FP64 path at every candidate
-				auto visit = [&](const float4& cd) {
+				unsigned int qb[8];
+				const int n = ranges(i, qb);
+				// one candidate per trip, the 8 ranges one after the other. The exact test is rare per lane but not per
+				// wave: a candidate that passes the float32 distance test is queued and tested later, so that the waves do
+				// not run the FP64 path at every candidate
+				unsigned int cur = 0, left = 0;
+				int c = 0;
+				for (int f = 0; f < n; f++) {
+					while (left == 0) {
+						unsigned int q = qb[0];
+#pragma unroll
+						for (int u = 1; u < 8; u++) q = (c == u) ? qb[u] : q;
+						c++;
+						cur = q & 0xffff; left = q >> 16;
+					}
+					const float4 cd = cand[cur];
+					cur++; left--;
 					const int k = __float_as_int(cd.w);
 					const float e0 = fx - cd.x, e1 = fy - cd.y, e2 = fz - cd.z;
-					const bool pass = k > i && e0 * e0 + e1 * e1 + e2 * e2 <= thr;
-#ifdef PHD_STAMP_COUNTERS
-					dbg_walk++;
-					if (pass) dbg_test++;
-#endif
-					if (pass) {
+					if (k > i && e0 * e0 + e1 * e1 + e2 * e2 <= thr) {
 						if (npend < 4) pend0 |= (unsigned long long) k << (16 * npend);
 						else           pend1 |= (unsigned long long) k << (16 * (npend - 4));
 						npend++;
-					}
-				};
-				// the 8 buckets of the cells the ball meets: with 4096 buckets most hold no row or one, so the first row of
-				// every bucket is handled in straight-line code and only longer buckets are looped over
-				const unsigned int xa0 = (unsigned int) (bx >> 1) * HA, xa1 = (unsigned int) ((bx + 1) >> 1) * HA;
-				const unsigned int yb0 = (unsigned int) (by >> 1) * HB, yb1 = (unsigned int) ((by + 1) >> 1) * HB;
-				const unsigned int zc0 = (unsigned int) (bz >> 1) * HC, zc1 = (unsigned int) ((bz + 1) >> 1) * HC;
-				const int par0 = (bx & 1) | ((by & 1) << 1) | ((bz & 1) << 2);
-				int qs[8], qe[8];
-#pragma unroll
-				for (int c = 0; c < 8; c++) {
-					const unsigned int h = ((c & 1) ? xa1 : xa0) ^ ((c & 2) ? yb1 : yb0) ^ ((c & 4) ? zc1 : zc0);
-					const int b = (int) ((h & (PRUNE_NB / 8 - 1)) << 3) | (par0 ^ c);   // neighbours flip the parity bits
-					qs[c] = cstart[b];
-					qe[c] = cstart[b + 1];
-				}
-				bool more = false;
-#pragma unroll
-				for (int c = 0; c < 8; c++) {
-					if (qs[c] < qe[c]) visit(cand[qs[c]]);
-					more = more || qe[c] - qs[c] > 1;
-				}
-				if (more) {
-#pragma unroll
-					for (int c = 0; c < 8; c++) {
-						for (int q = qs[c] + 1; q < qe[c]; q++) {
-							visit(cand[q]);
-							if (npend > 7) drain();
-						}
+						if (npend > 7) drain();
 					}
 				}
 				drain();
@@ -448,10 +483,10 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 			nbr[2 * i + 1] = hi;
 #ifdef PHD_STAMP_COUNTERS   // (slow: contended atomics; counts only, never together with timing)
 			if (a.stamps && a.stamp_kernel == 2) {
-				atomicAdd(&a.stamps[(size_t) p * 16 + 12], (double) dbg_walk);
-				atomicAdd(&a.stamps[(size_t) p * 16 + 13], (double) dbg_test);
-				atomicAdd(&a.stamps[(size_t) p * 16 + 14], (double) cnt);
-				if (!(bound <= rcap * rcap)) atomicAdd(&a.stamps[(size_t) p * 16 + 15], 1.0);
+				atomicAdd(&a.stamps[(size_t) p * 16 + 12], (double) ((bound <= rcap * rcap) ? 0 : 1));   // rows on the full scan
+				atomicAdd(&a.stamps[(size_t) p * 16 + 14], (double) cnt);                               // close pairs
+				unsigned int qd[8];
+				atomicAdd(&a.stamps[(size_t) p * 16 + 13], (double) ((bound <= rcap * rcap) ? ranges(i, qd) : 0));     // candidates
 			}
 #endif
 		}
@@ -503,7 +538,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 					for (int s = i >> 6; s < nslots; s++) {
 						int k = s * 64 + lane;
 						if (k > i && k < cut && !((absorbed >> s) & 1u)) {
-							if (quad_sym(Pi, m0 - srec[k], m1 - srec[(size_t) cutcap + k], m2 - srec[(size_t) 2 * cutcap + k]) < prm.merge_thr2) {
+							if (quad_sym(Pi, m0 - srec[k], m1 - srec[(size_t) cutcap + k], m2 - srec[(size_t) 2 * cutcap + k]) < merge_thr2) {
 								absorbed |= 1u << s;
 								owner[k] = i;
 							}
@@ -583,5 +618,5 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	}
 	PHD_STAMP(5);
 	if (tid == 0) vout.count[p] = nsurv_before;
-	PHD_STAMP_FLUSH(2, 8);
+	PHD_STAMP_FLUSH(2, 9);
 }

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 	__shared__ int    s_i16[16];
 	__shared__ int    s_res, s_ok, s_best;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	double* gwp = gw ? gw : a.bank[a.sel[SEL_OUT]].weights;
+	double* gwp = gw ? gw : bank_of(a, SEL_OUT).weights;
 	double* w = use_lds ? lw : gwp;
 	if (use_lds) {
 		for (int i = tid; i < P; i += 1024) lw[i] = gwp[i];

@@ -31,10 +31,10 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int M = a.M;
 	const MixView vin = bank_view(a, SEL_IN);
-	const Bank& bin = a.bank[a.sel[SEL_IN]];
+	const Bank bin = bank_of(a, SEL_IN);
 	const int n = vin.count[p];
 	const size_t sb = (size_t) p * a.cap;
-	const Bank& bout = a.bank[a.sel[SEL_OUT]];
+	const Bank bout = bank_of(a, SEL_OUT);
 	const PoseD pose = load_pose(bin.poses + (size_t) p * 7);
 	// the particle keeps its pose and (until the reweight kernel runs) its weight in the output bank
 	if (tid < 7) bout.poses[(size_t) p * 7 + tid] = bin.poses[(size_t) p * 7 + tid];
