@@ -1288,7 +1288,7 @@ __global__ __launch_bounds__(256) void k_alpha_density(const DevParams prm, cons
 	const Bank bout = bank_of(a, SEL_OUT);
 	const int n = vin.count[p], nb = a.born_count[p], no = vout.count[p];
 	const int np = n + nb;
-	const size_t sbi = (size_t) p * cap, sbo = (size_t) p * cap;
+	const size_t sbi = in_base(a, p), sbo = (size_t) p * cap;
 	const int J = a.aJ[p];
 	const int JS = a.Jcap;
 	const double* lm = a.alm + (size_t) p * 3 * JS;   // [3][Jcap]

@@ -20,7 +20,7 @@ __device__ __forceinline__ void load_predicted(const DevParams& prm, const StepB
                                                double& w, double m[3], double P[6])
 {
 	if (c < n) {
-		const size_t i = (size_t) p * a.cap + c;
+		const size_t i = in_base(a, p) + c;
 		w = vin.w[i];
 #pragma unroll
 		for (int t = 0; t < 3; t++) m[t] = vin.m[t][i];

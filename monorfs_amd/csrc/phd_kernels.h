@@ -33,9 +33,18 @@ struct Bank {
 	double* weights;  // [Pcap]
 };
 
-#define SEL_IN  0   // bank a step reads
-#define SEL_OUT 1   // bank a step writes
-#define SEL_TMP 2   // bank a resampling copy goes to
+// Roles of the three banks. A bank holds the mixture planes of all particles and their small arrays (count, pose,
+// weight). Resampling does not copy mixtures: after it the small arrays of the new particles sit in one bank (SEL_IN)
+// while their mixtures are still the ones the step wrote into another (SEL_INMIX), particle p's at slot inslot[p]
+// (the deep copies of PHDNavigator.cs:740-741 are what an indirection makes of them). OUT differs from IN and INMIX;
+// TMP differs from IN and OUT (it may be INMIX: only its small arrays are written).
+#define SEL_IN     0   // bank whose small arrays a step reads
+#define SEL_OUT    1   // bank a step writes
+#define SEL_TMP    2   // bank the small arrays of a resampled state go to
+#define SEL_RES    3   // bank holding the small arrays of the last step's result
+#define SEL_INMIX  4   // bank whose mixtures a step reads, through inslot
+#define SEL_RESMIX 5   // bank holding the mixtures of the last step's result (slots: the resampling sources)
+#define SEL_STRIDE 8
 
 struct StepBufs {
 	int P;          // particles of this handle
@@ -47,7 +56,8 @@ struct StepBufs {
 	int Jcap;       // landmark scratch per particle
 	size_t plane;   // doubles per plane = Pcap * cap
 	Bank bank[3];
-	const int* sel; // [3] device-resident roles of the banks for this step (no host round trip to rotate them)
+	const int* sel; // [SEL_STRIDE] device-resident roles of the banks for this step (no host round trip to rotate them)
+	const int* inslot;   // [P] slot of particle p's mixture in the INMIX bank
 	const double* z;         // [M][3]
 	// corrected-but-unpruned components (weight >= MinWeight), unsorted
 	double* emit_w;      // [P][ecap]
@@ -98,18 +108,23 @@ __device__ __forceinline__ Bank bank_of(const StepBufs& a, int role)
 	return b;
 }
 
+// The mixtures of the bank playing `role` and the counts that go with them. For SEL_IN the planes are those of the
+// INMIX bank: particle p's components start at in_base(a, p), its count is count[p].
 __device__ __forceinline__ MixView bank_view(const StepBufs& a, int role)
 {
 	const Bank b = bank_of(a, role);
+	const double* mix = (role == SEL_IN) ? bank_of(a, SEL_INMIX).mix : b.mix;
 	MixView v;
-	v.w = b.mix;
+	v.w = const_cast<double*>(mix);
 #pragma unroll
-	for (int t = 0; t < 3; t++) v.m[t] = b.mix + (size_t) (1 + t) * a.plane;
+	for (int t = 0; t < 3; t++) v.m[t] = const_cast<double*>(mix) + (size_t) (1 + t) * a.plane;
 #pragma unroll
-	for (int t = 0; t < 6; t++) v.P[t] = b.mix + (size_t) (4 + t) * a.plane;
+	for (int t = 0; t < 6; t++) v.P[t] = const_cast<double*>(mix) + (size_t) (4 + t) * a.plane;
 	v.count = b.count;
 	return v;
 }
+
+__device__ __forceinline__ size_t in_base(const StepBufs& a, int p) { return (size_t) a.inslot[p] * a.cap; }
 
 #define TILE 256   // components staged per LDS tile
 
@@ -123,40 +138,53 @@ __device__ __forceinline__ MixView bank_view(const StepBufs& a, int role)
 
 #include "phd_resample.h"
 
-// Deep copy of the resampled particles (PHDNavigator.cs:740-741) and rotation of the bank roles for the
-// next step, decided on the device from the resampling flag so the host never waits inside a step.
-//   not resampled: the new state is the OUT bank      -> next roles (IN, OUT, TMP) = (OUT, TMP, IN)
-//   resampled    : particle i <- OUT[src[first + i] - first] written to TMP -> next roles = (TMP, IN, OUT)
-//   frozen       : roles stay (benchmark steady state)
+// The sharded step's rotation when no rank resampled (the single-handle step does this inside k_normalise_resample,
+// rotate_roles in phd_resample.h, where the rules are written down): roles (IN, OUT, TMP, INMIX) = (O, I, T, O), slots
+// identity; frozen: nothing moves. One thread per particle.
 __global__ __launch_bounds__(256) void k_gather_rotate(const StepBufs a, const int* src, const int* info, int first,
-                                                       int* sel_next, int frozen)
+                                                       int* sel_next, int frozen, int* inslot)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	const int resampled = info[1];
+	const int I = a.sel[SEL_IN], O = a.sel[SEL_OUT], T = a.sel[SEL_TMP], X = a.sel[SEL_INMIX];
+	if (i == 0) {
+		if (frozen)         { sel_next[SEL_IN] = I; sel_next[SEL_OUT] = O; sel_next[SEL_TMP] = T; sel_next[SEL_INMIX] = X; }
+		else if (resampled) { sel_next[SEL_IN] = T; sel_next[SEL_OUT] = I; sel_next[SEL_TMP] = O; sel_next[SEL_INMIX] = O; }
+		else                { sel_next[SEL_IN] = O; sel_next[SEL_OUT] = I; sel_next[SEL_TMP] = T; sel_next[SEL_INMIX] = O; }
+		sel_next[SEL_RES]    = resampled ? T : O;
+		sel_next[SEL_RESMIX] = O;
+	}
+	if (i >= a.P) return;
+	const int s = resampled ? src[first + i] - first : i;
+	if (resampled) {
+		const Bank bo = bank_of(a, SEL_OUT), bt = bank_of(a, SEL_TMP);
+		bt.count[i]   = bo.count[s];
+		bt.weights[i] = bo.weights[i];
+#pragma unroll
+		for (int t = 0; t < 7; t++) bt.poses[(size_t) i * 7 + t] = bo.poses[(size_t) s * 7 + t];
+	}
+	if (!frozen) inslot[i] = s;
+}
+
+// The mixtures of the current state gathered into its own bank: particle i <- (INMIX, inslot[i]) written to (IN, i),
+// after which INMIX = IN and the slots are the identity. Run before anything that addresses mixtures by particle
+// number in bulk (uploads and downloads of whole states, single-map writes, the sharded step's migration).
+__global__ __launch_bounds__(256) void k_materialise(const StepBufs a, int* sel, int* inslot)
 {
 	const int i = blockIdx.x, tid = threadIdx.x;
-	const int resampled = info[1];
-	const int I = a.sel[SEL_IN], O = a.sel[SEL_OUT], T = a.sel[SEL_TMP];
-	if (i == 0 && tid == 0) {
-		if (frozen)         { sel_next[0] = I; sel_next[1] = O; sel_next[2] = T; }
-		else if (resampled) { sel_next[0] = T; sel_next[1] = I; sel_next[2] = O; }
-		else                { sel_next[0] = O; sel_next[1] = T; sel_next[2] = I; }
-		sel_next[3] = resampled ? T : O;   // where the result of this step lives
-	}
-	if (!resampled) return;
-	const MixView from = bank_view(a, SEL_OUT), dst = bank_view(a, SEL_TMP);
-	const int s = src[first + i] - first;
-	const int n = from.count[s];
-	const size_t db = (size_t) i * a.cap, fb = (size_t) s * a.cap;
+	const MixView from = bank_view(a, SEL_IN);
+	const Bank bi = bank_of(a, SEL_IN);
+	const int n = bi.count[i];
+	const size_t db = (size_t) i * a.cap, fb = in_base(a, i);
+	double* w = bi.mix;
 	for (int c = tid; c < n; c += 256) {
-		dst.w[db + c] = from.w[fb + c];
+		w[db + c] = from.w[fb + c];
 #pragma unroll
-		for (int t = 0; t < 3; t++) dst.m[t][db + c] = from.m[t][fb + c];
-#pragma unroll
-		for (int t = 0; t < 6; t++) dst.P[t][db + c] = from.P[t][fb + c];
+		for (int t = 0; t < 9; t++) w[(size_t) (1 + t) * a.plane + db + c] = from.w[(size_t) (1 + t) * a.plane + fb + c];
 	}
-	if (tid == 0) {
-		dst.count[i] = n;
-		bank_of(a, SEL_TMP).weights[i] = bank_of(a, SEL_OUT).weights[i];
-	}
-	if (tid < 7) bank_of(a, SEL_TMP).poses[(size_t) i * 7 + tid] = bank_of(a, SEL_OUT).poses[(size_t) s * 7 + tid];
+	__syncthreads();
+	if (tid == 0) inslot[i] = i;   // only this workgroup reads inslot[i]
+	if (i == 0 && tid == 0) sel[SEL_INMIX] = a.sel[SEL_IN];
 }
 
 // Particle motion: TrackVehicle.UpdateNoisy (TrackVehicle.cs:89-102) = Pose3D.AddOdometry
@@ -219,13 +247,13 @@ __global__ __launch_bounds__(256) void k_replicate(const StepBufs a, double weig
 	const int i = blockIdx.x, tid = threadIdx.x;
 	const MixView from = bank_view(a, SEL_IN), dst = bank_view(a, SEL_OUT);
 	const int n = from.count[0];
-	const size_t db = (size_t) i * a.cap;
+	const size_t db = (size_t) i * a.cap, fb = in_base(a, 0);
 	for (int c = tid; c < n; c += 256) {
-		dst.w[db + c] = from.w[c];
+		dst.w[db + c] = from.w[fb + c];
 #pragma unroll
-		for (int t = 0; t < 3; t++) dst.m[t][db + c] = from.m[t][c];
+		for (int t = 0; t < 3; t++) dst.m[t][db + c] = from.m[t][fb + c];
 #pragma unroll
-		for (int t = 0; t < 6; t++) dst.P[t][db + c] = from.P[t][c];
+		for (int t = 0; t < 6; t++) dst.P[t][db + c] = from.P[t][fb + c];
 	}
 	const Bank bi = bank_of(a, SEL_IN);
 	const Bank bo = bank_of(a, SEL_OUT);
@@ -292,16 +320,20 @@ __global__ __launch_bounds__(256) void k_gather_local(const StepBufs a, const in
 
 // dstsrc[i] >= 0: local source slot in the OUT bank (skipped when k_gather_local already copied those);
 // < 0: record -(dstsrc[i] + 1) of the receive buffer
+// The sharded step copies mixtures for real (they cross ranks): it starts from a materialised state (INMIX = IN) and
+// leaves one (the new particles, mixtures included, in TMP; slots identity).
 __global__ __launch_bounds__(256) void k_unpack_gather(const StepBufs a, const int* dstsrc, const double* recvbuf,
-                                                       double weight, int* sel_next, int frozen, int local_done)
+                                                       double weight, int* sel_next, int frozen, int local_done, int* inslot)
 {
 	const int i = blockIdx.x, tid = threadIdx.x;
 	const int I = a.sel[SEL_IN], O = a.sel[SEL_OUT], T = a.sel[SEL_TMP];
 	if (i == 0 && tid == 0) {
-		if (frozen) { sel_next[0] = I; sel_next[1] = O; sel_next[2] = T; }
-		else        { sel_next[0] = T; sel_next[1] = I; sel_next[2] = O; }
-		sel_next[3] = T;
+		if (frozen) { sel_next[SEL_IN] = I; sel_next[SEL_OUT] = O; sel_next[SEL_TMP] = T; sel_next[SEL_INMIX] = a.sel[SEL_INMIX]; }
+		else        { sel_next[SEL_IN] = T; sel_next[SEL_OUT] = I; sel_next[SEL_TMP] = O; sel_next[SEL_INMIX] = T; }
+		sel_next[SEL_RES] = T;
+		sel_next[SEL_RESMIX] = T;
 	}
+	if (tid == 0 && !frozen) inslot[i] = i;
 	const MixView from = bank_view(a, SEL_OUT), dst = bank_view(a, SEL_TMP);
 	const size_t db = (size_t) i * a.cap;
 	const int code = dstsrc[i];

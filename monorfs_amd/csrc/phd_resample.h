@@ -86,9 +86,40 @@ __device__ __forceinline__ double block_sum_1024(double v, double* scratch16, in
 	return t;
 }
 
+// End of a single-handle step (sel_next != NULL), folded into the same launch: the resampled particles
+// (PHDNavigator.cs:740-741) and the bank roles of the next step, decided here from the resampling flag so the host never
+// waits inside a step. No mixture is copied:
+//   not resampled: the new state is the OUT bank                      -> (IN, OUT, TMP, INMIX) = (O, I, T, O), slots identity
+//   resampled    : small arrays of particle i <- OUT[src[i]] into TMP -> (IN, OUT, TMP, INMIX) = (T, I, O, O), slots src
+//   frozen       : roles and slots stay (benchmark steady state); RES / RESMIX say where the result is (slots: src)
+// Called by all 1024 threads after the source vector and the final weights are in global memory.
+__device__ __forceinline__ void rotate_roles(const StepBufs& a, const int* src, int resampled, int* sel_next, int frozen,
+                                             int* inslot, int tid)
+{
+	const int I = a.sel[SEL_IN], O = a.sel[SEL_OUT], T = a.sel[SEL_TMP], X = a.sel[SEL_INMIX];
+	if (tid == 0) {
+		if (frozen)         { sel_next[SEL_IN] = I; sel_next[SEL_OUT] = O; sel_next[SEL_TMP] = T; sel_next[SEL_INMIX] = X; }
+		else if (resampled) { sel_next[SEL_IN] = T; sel_next[SEL_OUT] = I; sel_next[SEL_TMP] = O; sel_next[SEL_INMIX] = O; }
+		else                { sel_next[SEL_IN] = O; sel_next[SEL_OUT] = I; sel_next[SEL_TMP] = T; sel_next[SEL_INMIX] = O; }
+		sel_next[SEL_RES]    = resampled ? T : O;
+		sel_next[SEL_RESMIX] = O;
+	}
+	const Bank bo = bank_of(a, SEL_OUT), bt = bank_of(a, SEL_TMP);
+	for (int i = tid; i < a.P; i += 1024) {
+		const int s = resampled ? src[i] : i;
+		if (resampled) {
+			bt.count[i]   = bo.count[s];
+			bt.weights[i] = bo.weights[i];
+#pragma unroll
+			for (int t = 0; t < 7; t++) bt.poses[(size_t) i * 7 + t] = bo.poses[(size_t) s * 7 + t];
+		}
+		if (!frozen) inslot[i] = s;
+	}
+}
+
 __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, double* gw, int P, double min_eff, double u,
                                                              int force_resample, int skip_normalise, int use_lds,
-                                                             int* src, int* info)
+                                                             int* src, int* info, int* sel_next, int frozen, int* inslot)
 {
 #pragma clang fp contract(off)   // the error-free transformations below must not be fused
 	extern __shared__ __align__(16) double lw[];   // [P] when use_lds
@@ -157,6 +188,7 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 			src[k] = k;
 			if (use_lds && !skip_normalise) gwp[k] = lw[k];
 		}
+		if (sel_next) rotate_roles(a, src, 0, sel_next, frozen, inslot, tid);   // no thread reads another's writes here
 		return;
 	}
 
@@ -269,4 +301,9 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 	}
 	__syncthreads();
 	for (int k = c0; k < c1; k++) gwp[k] = 1.0 / P;   // :742
+	if (sel_next) {
+		__threadfence_block();
+		__syncthreads();   // src and the weights of every particle are written
+		rotate_roles(a, src, 1, sel_next, frozen, inslot, tid);
+	}
 }

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 	const MixView vin = bank_view(a, SEL_IN);
 	const Bank bin = bank_of(a, SEL_IN);
 	const int n = vin.count[p];
-	const size_t sb = (size_t) p * a.cap;
+	const size_t sb = in_base(a, p);   // the particle's prior mixture in the INMIX bank
 	const Bank bout = bank_of(a, SEL_OUT);
 	const PoseD pose = load_pose(bin.poses + (size_t) p * 7);
 	// the particle keeps its pose and (until the reweight kernel runs) its weight in the output bank

@@ -41,9 +41,10 @@ struct phd_navigator {
 	bool frozen = false;
 
 	Bank   bank[3];
-	int*   d_sel = nullptr;      // [2][4]: roles for the current / next step (+ result bank)
+	int*   d_sel = nullptr;      // [2][SEL_STRIDE]: roles for the current / next step (+ where the last result is)
+	int*   d_inslot = nullptr;   // [Pcap] slot of every particle's mixture in the INMIX bank (identity unless the last step resampled)
 	int    parity = 0;
-	int    h_sel[4] = {0, 1, 2, 0};
+	int    h_sel[SEL_STRIDE] = {0, 1, 2, 0, 0, 0, 0, 0};
 
 	double* d_z = nullptr;
 	double* d_emit_w = nullptr;  int* d_emit_idx = nullptr; double* d_emit_rec = nullptr; int* d_emit_count = nullptr;
@@ -172,7 +173,8 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.P = nav->P; b.p0 = 0; b.qposes = nullptr; b.qlm = nullptr; b.qJ = 0; b.cap = nav->cap; b.M = nav->M; b.Mcap = nav->Mcap; b.ecap = nav->ecap; b.Jcap = nav->Jcap;
 	b.plane = (size_t) nav->Pcap * nav->cap;
 	for (int i = 0; i < 3; i++) b.bank[i] = nav->bank[i];
-	b.sel = nav->d_sel + nav->parity * 4;
+	b.sel = nav->d_sel + nav->parity * SEL_STRIDE;
+	b.inslot = nav->d_inslot;
 	b.z = nav->d_z;
 	b.emit_w = nav->d_emit_w; b.emit_idx = nav->d_emit_idx; b.emit_rec = nav->d_emit_rec; b.emit_count = nav->d_emit_count;
 	b.born_count = nav->d_born_count; b.born_k = nav->d_born_k; b.born_mean = nav->d_born_mean;
@@ -299,14 +301,15 @@ int launch_map(phd_navigator* nav, const StepBufs& b, bool with_alpha)
 	}
 }
 
-int launch_normalise(phd_navigator* nav, const StepBufs& b, double* gw, int P, double u, int force, int skipnorm, int* src, int* info)
+int launch_normalise(phd_navigator* nav, const StepBufs& b, double* gw, int P, double u, int force, int skipnorm, int* src, int* info,
+                     int* sel_next = nullptr)
 {
 	size_t lds = (size_t) P * 8;
 	int use_lds = lds <= 144 * 1024;
 	if (!use_lds) lds = 0;
 	HC(hipFuncSetAttribute((const void*) k_normalise_resample, hipFuncAttributeMaxDynamicSharedMemorySize, (int) std::max<size_t>(lds, 16)));
 	hipLaunchKernelGGL(k_normalise_resample, dim3(1), dim3(1024), lds, nav->stream, b, gw, P, nav->dp.min_eff, u, force, skipnorm,
-	                   use_lds, src, info);
+	                   use_lds, src, info, sel_next, nav->frozen ? 1 : 0, nav->d_inslot);
 	HC(hipGetLastError());
 	return PHD_OK;
 }
@@ -326,17 +329,23 @@ int check_flags(phd_navigator* nav)
 	return PHD_OK;
 }
 
-// copy one particle's mixture out of a bank into h_mw / h_mm / h_mc (row-major mean[3n], cov[9n])
-int fetch_map(phd_navigator* nav, int bankidx, int particle, int* ncomp)
+// copy one particle's mixture into h_mw / h_mm / h_mc (row-major mean[3n], cov[9n]): its count from the bank of the small
+// arrays, its components from `mixbank` at the slot dslots[particle] (device array; NULL or the same bank: its own slot)
+int fetch_map(phd_navigator* nav, int bankidx, int particle, int* ncomp, int mixbank = -1, const int* dslots = nullptr)
 {
-	int n = 0;
+	int n = 0, slot = particle;
 	HC(hipMemcpyAsync(&n, nav->bank[bankidx].count + particle, sizeof(int), hipMemcpyDeviceToHost, nav->stream));
+	if (mixbank >= 0 && mixbank != bankidx && dslots) {
+		HC(hipMemcpyAsync(&slot, dslots + particle, sizeof(int), hipMemcpyDeviceToHost, nav->stream));
+	}
 	HC(hipStreamSynchronize(nav->stream));
+	if (slot < 0 || slot >= nav->Pcap) return nav->fail(PHD_ERR_GENERIC, "corrupt particle slot");
+	const int srcbank = (mixbank >= 0) ? mixbank : bankidx;
 	if (n < 0 || n > nav->cap) return nav->fail(PHD_ERR_GENERIC, "corrupt component count");
 	nav->h_tmp.resize((size_t) 10 * std::max(n, 1));
 	size_t plane = (size_t) nav->Pcap * nav->cap;
 	if (n > 0) {
-		HC(hipMemcpy2DAsync(nav->h_tmp.data(), (size_t) n * 8, nav->bank[bankidx].mix + (size_t) particle * nav->cap,
+		HC(hipMemcpy2DAsync(nav->h_tmp.data(), (size_t) n * 8, nav->bank[srcbank].mix + (size_t) slot * nav->cap,
 		                    plane * 8, (size_t) n * 8, 10, hipMemcpyDeviceToHost, nav->stream));
 		HC(hipStreamSynchronize(nav->stream));
 	}
@@ -385,7 +394,7 @@ int upload_particle(phd_navigator* nav, int bankidx, int particle, const double*
 int sync_state(phd_navigator* nav)
 {
 	HC(hipStreamSynchronize(nav->stream));
-	HC(hipMemcpy(nav->h_sel, nav->d_sel + nav->parity * 4, 4 * sizeof(int), hipMemcpyDeviceToHost));
+	HC(hipMemcpy(nav->h_sel, nav->d_sel + nav->parity * SEL_STRIDE, SEL_STRIDE * sizeof(int), hipMemcpyDeviceToHost));
 	HC(hipMemcpy(nav->h_info, nav->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost));
 	HC(hipMemcpy(&nav->h_flags, nav->d_flags, sizeof(int), hipMemcpyDeviceToHost));
 	nav->sel_host_valid = true;
@@ -393,6 +402,39 @@ int sync_state(phd_navigator* nav)
 }
 
 int cur_bank(const phd_navigator* nav) { return nav->h_sel[SEL_IN]; }
+
+// Where the state a getter reports lives: the small arrays' bank, the mixtures' bank and the slot array. In frozen mode
+// the roles do not advance and the result of the last step is described by RES / RESMIX and the resampling sources.
+int res_small(const phd_navigator* nav) { return nav->frozen ? nav->h_sel[SEL_RES] : nav->h_sel[SEL_IN]; }
+int res_mix(const phd_navigator* nav) { return nav->frozen ? nav->h_sel[SEL_RESMIX] : nav->h_sel[SEL_INMIX]; }
+const int* res_slots(const phd_navigator* nav) { return nav->frozen ? nav->d_src : nav->d_inslot; }
+
+// The current state is about to be replaced as a whole: its mixtures will be addressed by particle number again.
+int reset_indirection(phd_navigator* nav)
+{
+	std::vector<int> id(nav->Pcap);
+	for (int i = 0; i < nav->Pcap; i++) id[i] = i;
+	HC(hipMemcpy(nav->d_inslot, id.data(), (size_t) nav->Pcap * 4, hipMemcpyHostToDevice));
+	nav->h_sel[SEL_INMIX] = nav->h_sel[SEL_IN];
+	nav->h_sel[SEL_RES] = nav->h_sel[SEL_IN];
+	nav->h_sel[SEL_RESMIX] = nav->h_sel[SEL_IN];
+	HC(hipMemcpy(nav->d_sel + nav->parity * SEL_STRIDE, nav->h_sel, SEL_STRIDE * sizeof(int), hipMemcpyHostToDevice));
+	return PHD_OK;
+}
+
+// Gather the mixtures of the current state into its own bank (k_materialise) if the last step left them behind an
+// indirection. Needs the host mirror of the roles (sync_state).
+int materialise(phd_navigator* nav)
+{
+	if (nav->h_sel[SEL_INMIX] == nav->h_sel[SEL_IN] || nav->P < 1) return PHD_OK;
+	StepBufs b = make_bufs(nav);
+	hipLaunchKernelGGL(k_materialise, dim3(nav->P), dim3(256), 0, nav->stream, b, nav->d_sel + nav->parity * SEL_STRIDE, nav->d_inslot);
+	HC(hipGetLastError());
+	HC(hipStreamSynchronize(nav->stream));
+	nav->h_sel[SEL_INMIX] = nav->h_sel[SEL_IN];   // RES / RESMIX keep describing the last (frozen) step's result, which this did not touch
+	HC(hipMemcpy(nav->d_sel + nav->parity * SEL_STRIDE, nav->h_sel, SEL_STRIDE * sizeof(int), hipMemcpyHostToDevice));
+	return PHD_OK;
+}
 
 }  // namespace
 
@@ -489,7 +531,7 @@ phd_navigator* phd_create(const phd_params* params, int device)
 		}
 	}
 	size_t E = (size_t) nav->Pcap * nav->ecap;
-	ok = ok && dalloc((void**) &nav->d_sel, 8 * 4);
+	ok = ok && dalloc((void**) &nav->d_sel, 2 * SEL_STRIDE * 4) && dalloc((void**) &nav->d_inslot, (size_t) nav->Pcap * 4);
 	ok = ok && dalloc((void**) &nav->d_z, (size_t) nav->Mcap * 3 * 8);
 	ok = ok && dalloc((void**) &nav->d_emit_w, E * 8) && dalloc((void**) &nav->d_emit_idx, E * 4);
 	ok = ok && dalloc((void**) &nav->d_emit_rec, E * 9 * 8) && dalloc((void**) &nav->d_emit_count, (size_t) nav->Pcap * 4);
@@ -516,8 +558,13 @@ phd_navigator* phd_create(const phd_params* params, int device)
 		phd_destroy(nav);
 		return nullptr;
 	}
-	int sel[8] = {0, 1, 2, 0, 0, 1, 2, 0};
+	int sel[2 * SEL_STRIDE] = {0, 1, 2, 0, 0, 0, 0, 0, 0, 1, 2, 0, 0, 0, 0, 0};
 	hipMemcpy(nav->d_sel, sel, sizeof(sel), hipMemcpyHostToDevice);
+	{
+		std::vector<int> id(nav->Pcap);
+		for (int i = 0; i < nav->Pcap; i++) id[i] = i;
+		hipMemcpy(nav->d_inslot, id.data(), (size_t) nav->Pcap * 4, hipMemcpyHostToDevice);
+	}
 	hipMemset(nav->d_flags, 0, 4);
 	hipMemset(nav->d_info, 0, 8);
 	hipMemset(nav->d_emit_count, 0, (size_t) nav->Pcap * 4);
@@ -533,7 +580,7 @@ void phd_destroy(phd_navigator* nav)
 	for (int i = 0; i < 3; i++) {
 		hipFree(nav->bank[i].mix); hipFree(nav->bank[i].count); hipFree(nav->bank[i].poses); hipFree(nav->bank[i].weights);
 	}
-	hipFree(nav->d_sel); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
+	hipFree(nav->d_sel); hipFree(nav->d_inslot); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
 	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
@@ -560,6 +607,8 @@ int phd_reset(phd_navigator* nav, int nparticles, const double* pose7, const dou
 	hipSetDevice(nav->device);
 	int rc = sync_state(nav);
 	if (rc) return rc;
+	rc = reset_indirection(nav);   // the state is replaced as a whole
+	if (rc) return rc;
 	int I = nav->h_sel[SEL_IN];
 	rc = upload_particle(nav, I, 0, w, mean3, cov9, ncomp);
 	if (rc) return rc;
@@ -569,9 +618,10 @@ int phd_reset(phd_navigator* nav, int nparticles, const double* pose7, const dou
 	hipLaunchKernelGGL(k_replicate, dim3(nparticles), dim3(256), 0, nav->stream, b, 1.0 / nparticles);
 	HC(hipGetLastError());
 	// the replicated state is in the OUT bank: make it current
-	int sel[4] = {nav->h_sel[SEL_OUT], nav->h_sel[SEL_TMP], nav->h_sel[SEL_IN], nav->h_sel[SEL_OUT]};
+	const int O = nav->h_sel[SEL_OUT], T = nav->h_sel[SEL_TMP];
+	int sel[SEL_STRIDE] = {O, I, T, O, O, O, 0, 0};   // IN, OUT, TMP, RES, INMIX, RESMIX
 	HC(hipStreamSynchronize(nav->stream));
-	HC(hipMemcpy(nav->d_sel + nav->parity * 4, sel, sizeof(sel), hipMemcpyHostToDevice));
+	HC(hipMemcpy(nav->d_sel + nav->parity * SEL_STRIDE, sel, sizeof(sel), hipMemcpyHostToDevice));
 	std::memcpy(nav->h_sel, sel, sizeof(sel));
 	nav->h_info[0] = 0; nav->h_info[1] = 0;   // BestParticle = 0 (:265)
 	HC(hipMemcpy(nav->d_info, nav->h_info, 8, hipMemcpyHostToDevice));
@@ -681,7 +731,10 @@ int phd_set_map(phd_navigator* nav, int particle, const double* w, const double*
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	if (particle < 0 || particle >= nav->P) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_map: particle out of range");
 	hipSetDevice(nav->device);
-	HC(hipStreamSynchronize(nav->stream));
+	int rc = sync_state(nav);
+	if (rc) return rc;
+	rc = materialise(nav);   // a particle's slot may be shared with the other copies of its resampling source
+	if (rc) return rc;
 	return upload_particle(nav, cur_bank(nav), particle, w, mean3, cov9, ncomp);
 }
 
@@ -695,6 +748,8 @@ int phd_upload_state_soa(phd_navigator* nav, int nparticles, int stride, const d
 	if (nparticles < 1 || nparticles > nav->Pcap || stride < 0 || stride > nav->cap) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_upload_state_soa: sizes out of range");
 	hipSetDevice(nav->device);
 	int rc = sync_state(nav);
+	if (rc) return rc;
+	rc = reset_indirection(nav);
 	if (rc) return rc;
 	int I = cur_bank(nav);
 	size_t plane = (size_t) nav->Pcap * nav->cap;
@@ -718,6 +773,8 @@ int phd_download_state_soa(phd_navigator* nav, int stride, double* planes, int32
 	int rc = sync_state(nav);
 	if (rc) return rc;
 	if (stride < 0 || stride > nav->cap) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_download_state_soa: stride out of range");
+	rc = materialise(nav);
+	if (rc) return rc;
 	int I = cur_bank(nav);
 	size_t plane = (size_t) nav->Pcap * nav->cap;
 	for (int f = 0; f < 10 && stride > 0; f++) {
@@ -769,15 +826,11 @@ int phd_step_async(phd_navigator* nav, uint8_t onlymapping, double u_resample)
 	int rc = launch_map(nav, b, !onlymapping);
 	if (rc) return rc;
 	timer_begin(nav, T_NR);
-	rc = launch_normalise(nav, b, nullptr, nav->P, u_resample, onlymapping ? -1 : 0, onlymapping ? 1 : 0, nav->d_src, nav->d_info);
+	// the same launch hands the resampled particles their small arrays and rotates the bank roles (rotate_roles)
+	rc = launch_normalise(nav, b, nullptr, nav->P, u_resample, onlymapping ? -1 : 0, onlymapping ? 1 : 0, nav->d_src, nav->d_info,
+	                      nav->d_sel + (nav->parity ^ 1) * SEL_STRIDE);
 	timer_end(nav, T_NR);
 	if (rc) return rc;
-	int* sel_next = nav->d_sel + (nav->parity ^ 1) * 4;
-	timer_begin(nav, T_GR, nullptr, true);
-	hipLaunchKernelGGL(k_gather_rotate, dim3(nav->P), dim3(256), 0, nav->stream, b, nav->d_src, nav->d_info, 0, sel_next,
-	                   nav->frozen ? 1 : 0);
-	timer_end(nav, T_GR);
-	HC(hipGetLastError());
 	nav->parity ^= 1;
 	nav->stage_valid = false;
 	nav->sel_host_valid = false;   // the rotation depends on the resampling flag, known only on the device
@@ -811,8 +864,7 @@ const double* phd_weights(phd_navigator* nav, int* length)
 	if (!nav) return nullptr;
 	hipSetDevice(nav->device);
 	if (sync_state(nav)) return nullptr;
-	// in frozen mode the roles do not advance: the result of the last step is in h_sel[3]
-	int bidx = nav->frozen ? nav->h_sel[3] : cur_bank(nav);
+	int bidx = res_small(nav);
 	nav->h_weights.resize(std::max(nav->P, 1));
 	if (hipMemcpy(nav->h_weights.data(), nav->bank[bidx].weights, (size_t) nav->P * 8, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
 	if (length) *length = nav->P;
@@ -832,7 +884,7 @@ const double* phd_poses(phd_navigator* nav, int* length)
 	if (!nav) return nullptr;
 	hipSetDevice(nav->device);
 	if (sync_state(nav)) return nullptr;
-	int bidx = nav->frozen ? nav->h_sel[3] : cur_bank(nav);
+	int bidx = res_small(nav);
 	nav->h_poses.resize((size_t) std::max(nav->P, 1) * 7);
 	if (hipMemcpy(nav->h_poses.data(), nav->bank[bidx].poses, (size_t) nav->P * 7 * 8, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
 	if (length) *length = nav->P * 7;
@@ -846,8 +898,7 @@ int phd_map(phd_navigator* nav, int particle, int* ncomp, const double** w, cons
 	hipSetDevice(nav->device);
 	int rc = sync_state(nav);
 	if (rc) return rc;
-	int bidx = nav->frozen ? nav->h_sel[3] : cur_bank(nav);
-	rc = fetch_map(nav, bidx, particle, ncomp);
+	rc = fetch_map(nav, res_small(nav), particle, ncomp, res_mix(nav), res_slots(nav));
 	if (rc) return rc;
 	if (w) *w = nav->h_mw.data();
 	if (mean3) *mean3 = nav->h_mm.data();
@@ -899,7 +950,7 @@ int phd_stage_map(phd_navigator* nav, int stage, int particle, int* ncomp, const
 	}
 	else if (stage == PHD_STAGE_PREDICTED) {
 		int n = 0;
-		rc = fetch_map(nav, nav->h_sel[SEL_IN], particle, &n);
+		rc = fetch_map(nav, nav->h_sel[SEL_IN], particle, &n, nav->h_sel[SEL_INMIX], nav->d_inslot);
 		if (rc) return rc;
 		int nb = 0;
 		HC(hipMemcpy(&nb, nav->d_born_count + particle, 4, hipMemcpyDeviceToHost));
@@ -1089,6 +1140,11 @@ int phd_step_local_async(phd_navigator* nav, uint8_t onlymapping)
 	if (nav->P < 1) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step_local: no particles");
 	hipSetDevice(nav->device);
 	nav->timing_now = (nav->timing_step++ % nav->timing_period) == 0;
+	// the sharded step copies mixtures between ranks by particle number: it starts from a materialised state
+	int rc = PHD_OK;
+	if (!nav->sel_host_valid) rc = sync_state(nav);
+	if (!rc) rc = materialise(nav);
+	if (rc) return rc;
 	StepBufs b = make_bufs(nav);
 	return launch_map(nav, b, !onlymapping);
 }
@@ -1270,11 +1326,12 @@ int phd_migration_unpack_async(phd_navigator* nav)
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	hipSetDevice(nav->device);
 	StepBufs b = make_bufs(nav);
-	int* sel_next = nav->d_sel + (nav->parity ^ 1) * 4;
+	int* sel_next = nav->d_sel + (nav->parity ^ 1) * SEL_STRIDE;
 	if (!nav->h_info[1]) {
 		// no resampling: only rotate the bank roles
 		timer_begin(nav, T_GR);
-		hipLaunchKernelGGL(k_gather_rotate, dim3(1), dim3(256), 0, nav->stream, b, nav->d_src, nav->d_info, 0, sel_next, nav->frozen ? 1 : 0);
+		hipLaunchKernelGGL(k_gather_rotate, dim3((nav->P + 255) / 256), dim3(256), 0, nav->stream, b, nav->d_src, nav->d_info, 0, sel_next,
+		                   nav->frozen ? 1 : 0, nav->d_inslot);
 		timer_end(nav, T_GR);
 		HC(hipGetLastError());
 	}
@@ -1283,7 +1340,7 @@ int phd_migration_unpack_async(phd_navigator* nav)
 		HC(hipMemcpyAsync(nav->d_code, nav->h_plan_recv.data(), (size_t) nav->P * 4, hipMemcpyHostToDevice, nav->stream));
 		timer_begin(nav, T_GR);
 		hipLaunchKernelGGL(k_unpack_gather, dim3(nav->P), dim3(256), 0, nav->stream, b, nav->d_code, nav->d_recv,
-		                   1.0 / (double) nav->last_world_particles, sel_next, nav->frozen ? 1 : 0, nav->local_gather_done ? 1 : 0);
+		                   1.0 / (double) nav->last_world_particles, sel_next, nav->frozen ? 1 : 0, nav->local_gather_done ? 1 : 0, nav->d_inslot);
 		timer_end(nav, T_GR);
 		HC(hipGetLastError());
 	}
@@ -1292,11 +1349,12 @@ int phd_migration_unpack_async(phd_navigator* nav)
 	nav->stage_valid = false;
 	if (nav->sel_host_valid && !nav->frozen) {   // same rotation as the kernels wrote to the device
 		int I = nav->h_sel[SEL_IN], O = nav->h_sel[SEL_OUT], T = nav->h_sel[SEL_TMP];
-		if (nav->h_info[1]) { nav->h_sel[0] = T; nav->h_sel[1] = I; nav->h_sel[2] = O; nav->h_sel[3] = T; }
-		else                { nav->h_sel[0] = O; nav->h_sel[1] = T; nav->h_sel[2] = I; nav->h_sel[3] = O; }
+		if (nav->h_info[1]) { nav->h_sel[SEL_IN] = T; nav->h_sel[SEL_OUT] = I; nav->h_sel[SEL_TMP] = O; nav->h_sel[SEL_RES] = T; nav->h_sel[SEL_INMIX] = T; nav->h_sel[SEL_RESMIX] = T; }
+		else                { nav->h_sel[SEL_IN] = O; nav->h_sel[SEL_OUT] = I; nav->h_sel[SEL_TMP] = T; nav->h_sel[SEL_RES] = O; nav->h_sel[SEL_INMIX] = O; nav->h_sel[SEL_RESMIX] = O; }
 	}
 	else if (nav->sel_host_valid) {
-		nav->h_sel[3] = nav->h_info[1] ? nav->h_sel[SEL_TMP] : nav->h_sel[SEL_OUT];
+		nav->h_sel[SEL_RES] = nav->h_info[1] ? nav->h_sel[SEL_TMP] : nav->h_sel[SEL_OUT];
+		nav->h_sel[SEL_RESMIX] = nav->h_sel[SEL_RES];
 	}
 	return PHD_OK;
 }

@@ -368,3 +368,65 @@ def test_loglike_gradient_through_the_batch(nav_mod):
         assert np.allclose(got[a], want, rtol=1e-4, atol=0.5), (got[a], want)
     assert np.max(np.abs(got)) > 10          # the gradients are far from zero: the comparison means something
     nav.close()
+
+
+def test_resampling_leaves_the_maps_in_place(nav_mod):
+    """A resampling step copies no mixture: the next step reads particle p's map at its source's slot in the bank the
+    step before wrote (k_gather_rotate / `inslot`). Steps that follow each other through that indirection must equal
+    steps from a state gathered into place after every step (download = k_materialise), bit for bit, and the oracle
+    within tolerance; single-map writes and the frozen mode's getters go through the same indirection."""
+    P, C, M = 48, 60, 16
+    f = Frame(P, C, M, 77, weight_profile="steady")
+    nav_a, p = make_nav(nav_mod, f)
+    nav_b, _ = make_nav(nav_mod, f)
+    st = orc.State(P, 700)
+    st.poses[:] = f.poses
+    st.w[:, :C], st.mean[:, :C], st.cov[:, :C], st.n[:] = f.w, f.mean, f.cov, C
+    rng = np.random.default_rng(78)
+    consecutive, last = 0, False
+    for step in range(5):
+        z = f.z + rng.normal(size=f.z.shape) * np.sqrt([2.0, 2.0, 1e-3]) * 0.3
+        u = float(rng.uniform(0.05, 0.95))
+        _, src, res, _ = orc.slam_update(p, st, z, u=u, threads=4)
+        nav_a.SlamUpdate(None, z, u_resample=u)            # only single-map getters in between: the indirection stays
+        nav_b.SlamUpdate(None, z, u_resample=u)
+        planes_b, counts_b, poses_b, weights_b = nav_b.download_state(600)   # gathers the maps into place
+        gsrc, gres = nav_a.resample_sources()
+        assert gres == res and np.array_equal(gsrc, src)
+        consecutive += int(last)                           # this step read its input through the previous resampling's slots
+        last = res
+        for i in range(P):
+            wa, ma, ca = nav_a.MapModel(i)
+            n = counts_b[i]
+            assert len(wa) == n and np.array_equal(wa, planes_b[0, i, :n]), "step %d particle %d" % (step, i)
+            assert np.array_equal(ma, np.stack([planes_b[1 + t, i, :n] for t in range(3)], axis=1))
+            if i % 7 == 0:
+                assert_mix_close((wa, ma, ca), st.map(i), 1e-7, "step %d map[%d]" % (step, i))
+        assert np.array_equal(nav_a.VehicleWeights, weights_b) and np.array_equal(nav_a.poses(), poses_b)
+    assert consecutive >= 1, "no step read its input through the slots of a resampling"
+    # a single-map write after a resampling: the particle's slot was shared with the other copies of its source
+    nav_a.set_map(3, f.map(0))
+    nav_b.set_map(3, f.map(0))
+    for i in range(P):
+        wa, ma, ca = nav_a.MapModel(i)
+        wb, mb, cb = nav_b.MapModel(i)
+        assert np.array_equal(wa, wb) and np.array_equal(ma, mb) and np.array_equal(ca, cb)
+    # frozen mode: the step's result is read through the resampling sources, the state itself does not move
+    before = nav_a.download_state(600)
+    nav_a.set_frozen(True)
+    nav_b.set_frozen(False)
+    z = f.z + rng.normal(size=f.z.shape) * np.sqrt([2.0, 2.0, 1e-3]) * 0.3
+    nav_a.SlamUpdate(None, z, u_resample=0.37)
+    nav_b.SlamUpdate(None, z, u_resample=0.37)
+    assert nav_a.resample_sources()[1] == nav_b.resample_sources()[1]
+    for i in range(0, P, 5):
+        wa, ma, ca = nav_a.MapModel(i)
+        wb, mb, cb = nav_b.MapModel(i)
+        assert np.array_equal(wa, wb) and np.array_equal(ma, mb) and np.array_equal(ca, cb)
+    assert np.array_equal(nav_a.VehicleWeights, nav_b.VehicleWeights)
+    nav_a.set_frozen(False)
+    after = nav_a.download_state(600)
+    for x, y in zip(before, after):
+        assert np.array_equal(x, y)
+    nav_a.close()
+    nav_b.close()
