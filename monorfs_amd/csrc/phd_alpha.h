@@ -1273,13 +1273,18 @@ __global__ __launch_bounds__(256, 4) void k_quasi_setll(const DevParams prm, con
 // with v(.) the full, ungated mixture density (Map.Evaluate(point), Map.cs:192-202) and m_j the landmarks of
 // the map estimate left in HBM by k_alpha_assoc. Landmark per lane, component tiles broadcast from LDS.
 // =================================================================================================
+#define DENS_JL 128   // landmarks whose partial sums stay in LDS
+#define DENS_REC 12   // gauss_record + the weight ratio of the component's surviving misdetection copy (+ 1: records stay 16-byte aligned)
+
 __global__ __launch_bounds__(256) void k_alpha_density(const DevParams prm, const StepBufs a)
 {
-	constexpr int JL = ALPHA_JL;
-	__shared__ double tile[TILE * 10];          // [TILE][10]: gauss_record
-	__shared__ double partl[(JL / 64) * 256];   // [JB][4][64] partial densities (HBM slab when J > JL)
-	__shared__ double red[256];
+	constexpr int JL = DENS_JL;
+	__shared__ double tile[TILE * DENS_REC];     // [TILE][12]
+	__shared__ double partpl[(JL / 64) * 256];   // [JB][4][64] partial densities of v_pred (HBM slab when J > JL)
+	__shared__ double partcl[(JL / 64) * 256];   // the same for v_corr
 	__shared__ double etab[EXPTAB_N];
+	__shared__ int s_wc[4];
+	double* red = tile;                          // reduction scratch once the sweeps are over
 
 	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int cap = a.cap;
@@ -1293,7 +1298,10 @@ __global__ __launch_bounds__(256) void k_alpha_density(const DevParams prm, cons
 	const int JS = a.Jcap;
 	const double* lm = a.alm + (size_t) p * 3 * JS;   // [3][Jcap]
 	double* gj = a.jscratch + (size_t) p * alpha_jscratch_doubles(a.Jcap);
-	double* part = (J <= JL) ? partl : gj + 13 * (size_t) JS;
+	double* partp = (J <= JL) ? partpl : gj + 13 * (size_t) JS;   // (the association kernel's arrays in the slab are dead by now)
+	double* partc = (J <= JL) ? partcl : gj;
+	const double* wcopy = a.wcopy + (size_t) p * (cap + a.Mcap);
+	const int* cover = a.cover + sbo;
 	exp_tab_init(etab, tid);
 	__syncthreads();
 
@@ -1301,44 +1309,67 @@ __global__ __launch_bounds__(256) void k_alpha_density(const DevParams prm, cons
 	// Component tiles are staged once and swept for every block of 64 landmarks (landmark per lane, the
 	// component broadcast from LDS). A last block with few landmarks is packed: LJ = 2^k lanes carry the
 	// landmarks and the 64 / LJ lane groups take different components, then the groups are summed.
+	//
+	// Most components of the corrected map are the misdetection copies of predicted components that came through
+	// PruneModel alone: the same Gaussian with the weight (1 - PD) w. Their densities are not evaluated again: the sweep
+	// over the predicted mixture adds ratio_c * (w_c N_c(m_j)) to the corrected sum as well, ratio_c = wcopy[c] / w_c
+	// (k_prune_merge, which also checks that the copy's moments are the component's up to Merge's rounding). The second
+	// sweep takes only the other corrected components (updated by a measurement, merged).
 	double plog_part = 0, clog_part = 0, pcount_part = 0;
 	{
 		const int JB = (J + 63) >> 6;
 		for (int c = tid; c < n; c += 256) pcount_part += vin.w[sbi + c];
+		for (int i = tid; i < JB * 256; i += 256) { partp[i] = 0; partc[i] = 0; }
 		for (int src = 0; src < 2; src++) {
 			const int total = (src == 0) ? np : no;
-			for (int i = tid; i < JB * 256; i += 256) part[i] = 0;
 			for (int c0 = 0; c0 < total; c0 += TILE) {
 				int c = c0 + tid;
-				if (c < total) {
-					double w, m[3], P[6], Pi[6], det;
-					if (src == 1) {
+				int cend;
+				if (src == 0) {
+					if (c < total) {
+						double w, m[3], P[6], Pi[6], det;
+						if (c < n) {
+							w = vin.w[sbi + c];
+#pragma unroll
+							for (int t = 0; t < 3; t++) m[t] = vin.m[t][sbi + c];
+#pragma unroll
+							for (int t = 0; t < 6; t++) P[t] = vin.P[t][sbi + c];
+						}
+						else {
+							const double* bm = a.born_mean + ((size_t) p * a.Mcap + (c - n)) * 3;
+							w = prm.birthw;
+							m[0] = bm[0]; m[1] = bm[1]; m[2] = bm[2];
+#pragma unroll
+							for (int t = 0; t < 6; t++) P[t] = prm.birthP[t];
+						}
+						inv_sym3(P, Pi, det);
+						gauss_record(w, m, Pi, PHD_INV_2PI / sqrt(fabs(det)), tile + tid * DENS_REC);
+						tile[tid * DENS_REC + 10] = (w > 0) ? wcopy[c] / w : 0.0;
+					}
+					cend = min(TILE, total - c0);
+				}
+				else {
+					// the corrected components not accounted for by the first sweep, compacted in map order
+					const bool other = c < total && !cover[c];
+					const unsigned long long bal = __ballot(other);
+					if (lane == 0) s_wc[wv] = __popcll(bal);
+					__syncthreads();
+					int slot = __popcll(bal & lanemask_lt());
+					for (int q = 0; q < wv; q++) slot += s_wc[q];
+					cend = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+					if (other) {
+						double w, m[3], P[6], Pi[6], det;
 						w = vout.w[sbo + c];
 #pragma unroll
 						for (int t = 0; t < 3; t++) m[t] = vout.m[t][sbo + c];
 #pragma unroll
 						for (int t = 0; t < 6; t++) P[t] = vout.P[t][sbo + c];
+						inv_sym3(P, Pi, det);
+						gauss_record(w, m, Pi, PHD_INV_2PI / sqrt(fabs(det)), tile + slot * DENS_REC);
 					}
-					else if (c < n) {
-						w = vin.w[sbi + c];
-#pragma unroll
-						for (int t = 0; t < 3; t++) m[t] = vin.m[t][sbi + c];
-#pragma unroll
-						for (int t = 0; t < 6; t++) P[t] = vin.P[t][sbi + c];
-					}
-					else {
-						const double* bm = a.born_mean + ((size_t) p * a.Mcap + (c - n)) * 3;
-						w = prm.birthw;
-						m[0] = bm[0]; m[1] = bm[1]; m[2] = bm[2];
-#pragma unroll
-						for (int t = 0; t < 6; t++) P[t] = prm.birthP[t];
-					}
-					inv_sym3(P, Pi, det);
-					gauss_record(w, m, Pi, PHD_INV_2PI / sqrt(fabs(det)), tile + tid * 10);
 				}
 				__syncthreads();
-				const int cend = min(TILE, total - c0);
-				for (int jb = 0; jb < JB; jb++) {
+				for (int jb = 0; jb < JB && cend > 0; jb++) {
 					const int rem = min(64, J - jb * 64);
 					const int LJ  = (rem > 32) ? 64 : ((rem <= 1) ? 1 : (1 << (32 - __clz(rem - 1))));
 					const int G   = 64 / LJ, g = lane / LJ, jl = lane & (LJ - 1);
@@ -1347,24 +1378,42 @@ __global__ __launch_bounds__(256) void k_alpha_density(const DevParams prm, cons
 					const double x0 = jv ? lm[j] : 0, x1 = jv ? lm[JS + j] : 0, x2 = jv ? lm[2 * JS + j] : 0;
 					// w * (mult * exp(-d^T Pinv d / 2)) of component cc at this lane's landmark (Map.cs:198)
 					auto dens = [&](int cc) {
-						const double* tt = tile + cc * 10;
+						const double* tt = tile + cc * DENS_REC;
 						return exp_neg(gauss_logw(tt, x0 - tt[0], x1 - tt[1], x2 - tt[2]), etab);
 					};
-					double acc = 0, acc2 = 0;
+					double acc = 0, acc2 = 0, cacc = 0, cacc2 = 0;
 					int cc = wv * G + g;
 					const int step = 4 * G;
-					for (; cc + step < cend; cc += 2 * step) {   // two independent components per trip
-						acc  += dens(cc);
-						acc2 += dens(cc + step);
+					if (src == 0) {
+						for (; cc + step < cend; cc += 2 * step) {   // two independent components per trip
+							const double e1 = dens(cc), e2 = dens(cc + step);
+							acc  += e1;
+							acc2 += e2;
+							cacc  = fma(tile[cc * DENS_REC + 10], e1, cacc);
+							cacc2 = fma(tile[(cc + step) * DENS_REC + 10], e2, cacc2);
+						}
+						if (cc < cend) {
+							const double e1 = dens(cc);
+							acc += e1;
+							cacc = fma(tile[cc * DENS_REC + 10], e1, cacc);
+						}
+						partp[(jb * 4 + wv) * 64 + lane] += acc + acc2;   // own slot
+						partc[(jb * 4 + wv) * 64 + lane] += cacc + cacc2;
 					}
-					if (cc < cend) acc += dens(cc);
-					acc += acc2;
-					part[(jb * 4 + wv) * 64 + lane] += acc;   // own slot
+					else {
+						for (; cc + step < cend; cc += 2 * step) {
+							acc  += dens(cc);
+							acc2 += dens(cc + step);
+						}
+						if (cc < cend) acc += dens(cc);
+						partc[(jb * 4 + wv) * 64 + lane] += acc + acc2;
+					}
 				}
 				__syncthreads();
 			}
 			__threadfence_block();
 			__syncthreads();
+			const double* part = (src == 0) ? partp : partc;
 			for (int jb = wv; jb < JB; jb += 4) {
 				const int rem = min(64, J - jb * 64);
 				const int LJ  = (rem > 32) ? 64 : ((rem <= 1) ? 1 : (1 << (32 - __clz(rem - 1))));

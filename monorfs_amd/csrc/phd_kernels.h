@@ -90,6 +90,8 @@ struct StepBufs {
 	int     qJ;
 	double* qgrad;       // [P][6] pose gradients (k_quasi_setll_grad)
 	int     qavg;        // TemperedAverage normalisation: 0 as the source reads, 1 weights / their sum
+	double* wcopy;       // [P][cap + Mcap] weight of the surviving misdetection copy of predicted component c (0: none), k_prune_merge -> k_alpha_density
+	int*    cover;       // [P][cap] 1: this pruned component is such a copy
 	double* stamps;      // [P][16] phase stamps of the diagnostic build (NULL otherwise)
 	int     stamp_kernel; // which kernel writes them (env PHD_STAMP_KERNEL): 2 prune, 3 assoc, 4 density, 1 correct
 };

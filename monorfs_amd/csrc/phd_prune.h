@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	const size_t eb = (size_t) p * a.ecap;
 	const double merge_thr2 = prm.merge_thr2;   // a local copy: a lambda that captured `prm` by reference would pin the argument block to memory
 	const int cut = min(min(prm.maxq, ne), cutcap);   // weightcut: every emitted weight is already >= MinWeight
-	double* srec = a.srec + (size_t) p * 10 * cutcap;  // [10][cutcap] the kept records in sorted order: mean, covariance, weight
+	double* srec = a.srec + (size_t) p * 11 * cutcap;  // [11][cutcap] the kept records in sorted order: mean, covariance, weight, canonical index
 
 	PHD_STAMP(0);
 	// ---- A. order by (weight desc, canonical index asc)
@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 #pragma unroll
 		for (int t = 0; t < 9; t++) srec[(size_t) t * cutcap + r] = v[t];
 		srec[(size_t) 9 * cutcap + r] = w;
+		srec[(size_t) 10 * cutcap + r] = (double) a.emit_idx[eb + slt];   // position in the reference's `corrected` list
 		const double P0 = v[3], P1 = v[4], P2 = v[5], P3 = v[6], P4 = v[7], P5 = v[8];
 		double det = P0 * (P3 * P5 - P4 * P4) - P1 * (P1 * P5 - P4 * P2) + P2 * (P1 * P4 - P3 * P2);
 		bool pd = P0 > 0 && (P0 * P3 - P1 * P1) > 0 && det > 0;   // Sylvester
@@ -552,7 +553,16 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	__syncthreads();
 
 	PHD_STAMP(4);
-	// ---- D. output position of every survivor (exclusive scan of the survivor flags) and the merges
+	// ---- D. output position of every survivor (exclusive scan of the survivor flags) and the merges.
+	// For the reweight (k_alpha_density): a survivor that absorbed nothing and is the misdetection copy of predicted
+	// component c (canonical index c < np, PHDNavigator.cs:837-840) IS that component with another weight — Merge
+	// (Gaussian.cs:329-346) of a single Gaussian changes its moments only by rounding, which is checked here —, so its
+	// density at a landmark is the predicted component's times wcopy[c] / w_c. wcopy[c] = that weight (0: none such),
+	// cover[pos] = 1 for the survivors accounted for this way.
+	const int npred = bank_of(a, SEL_IN).count[p] + a.born_count[p];
+	double* wcopy = a.wcopy + (size_t) p * (a.cap + a.Mcap);
+	for (int c = tid; c < npred; c += 256) wcopy[c] = 0.0;
+	__syncthreads();
 	int nsurv_before = 0;
 	for (int r0 = 0; r0 < cut; r0 += 256) {
 		const int  i = r0 + tid;
@@ -575,7 +585,9 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 			double M0 = 0.0 + w * m0, M1 = 0.0 + w * m1, M2 = 0.0 + w * m2;
 			double C0 = 0.0 + w * (rec[3] + m0 * m0), C1 = 0.0 + w * (rec[4] + m0 * m1), C2 = 0.0 + w * (rec[5] + m0 * m2);
 			double C3 = 0.0 + w * (rec[6] + m1 * m1), C4 = 0.0 + w * (rec[7] + m1 * m2), C5 = 0.0 + w * (rec[8] + m2 * m2);
+			int nabs = 0;
 			auto absorb = [&](int k) {
+				nabs++;
 				double rk[10];
 #pragma unroll
 				for (int t = 0; t < 10; t++) rk[t] = srec[(size_t) t * cutcap + k];
@@ -613,6 +625,16 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 			vout.m[0][ob] = o0; vout.m[1][ob] = o1; vout.m[2][ob] = o2;
 #pragma unroll
 			for (int t = 0; t < 6; t++) vout.P[t][ob] = oP[t];
+			int covered = 0;
+			const int cidx = (int) srec[(size_t) 10 * cutcap + i];
+			if (nabs == 0 && cidx < npred && !(W < 1e-15)) {
+				const double pscale = 1e-9 * fmax(fabs(rec[3]), fmax(fabs(rec[6]), fabs(rec[8])));
+				bool same = fabs(o0 - m0) <= 1e-9 * fabs(m0) && fabs(o1 - m1) <= 1e-9 * fabs(m1) && fabs(o2 - m2) <= 1e-9 * fabs(m2);
+#pragma unroll
+				for (int t = 0; t < 6; t++) same = same && fabs(oP[t] - rec[3 + t]) <= pscale;
+				if (same) { wcopy[cidx] = ow; covered = 1; }
+			}
+			a.cover[ob] = covered;
 		}
 		nsurv_before += total;
 	}
