@@ -430,3 +430,31 @@ def test_resampling_leaves_the_maps_in_place(nav_mod):
         assert np.array_equal(x, y)
     nav_a.close()
     nav_b.close()
+
+
+def test_reweight_far_from_the_origin(nav_mod):
+    """A scene 2 km from the origin: Gaussian.Merge's raw second moments (Gaussian.cs:336-344) then cost a pruned
+    singleton about eps |m|^2 = 1e-9 of its covariance, so k_prune_merge must NOT declare the corrected map's misdetection
+    copies equal to their predicted components, and k_alpha_density evaluates them itself — against the oracle."""
+    P, C, M = 4, 50, 14
+    f = Frame(P, C, M, 91, weight_profile="steady")
+    shift = np.array([1500.0, -900.0, 1100.0])
+    f.poses = f.poses.copy()
+    f.poses[:, :3] += shift
+    f.mean = f.mean + shift
+    nav, p = make_nav(nav_mod, f)
+    nav.run_stages(f.z, with_alpha=True)
+    alpha = nav.WeightAlpha()
+    for i in range(P):
+        pred = orc.predict(p, f.poses[i], f.z, f.map(i))
+        cor = orc.correct(p, f.poses[i], f.z, pred)
+        pr = orc.prune(p, cor)
+        got = nav.PruneModel(i)
+        assert len(got[0]) == len(pr[0])
+        assert np.allclose(got[0], pr[0], rtol=1e-7) and np.allclose(got[1], pr[1], rtol=1e-12, atol=1e-9)
+        a, _ = orc.weight_alpha(p, f.poses[i], f.z, pred, pr)
+        # eps |m|^2 / P = 1e-6 of every pruned covariance is rounding noise of the reference's own formula here, and the
+        # device's fused multiply-adds round it differently from the oracle's plain ones: what is left to agree on is
+        # about three digits of alpha (the kernels before and after the change compute the same bits in this regime)
+        assert np.isclose(alpha[i], a, rtol=5e-3, atol=0), "alpha[%d]: %r vs %r" % (i, alpha[i], a)
+    nav.close()
