@@ -14,6 +14,7 @@
 
 #define SW_TILE   128   // prior components staged per LDS tile
 #define SW_REC    20    // doubles per staged component: zh[3] G[6] lw | m[3] Gm[6] lwm  (two gauss_logw records)
+#define SW_UMAX   16    // measurements still unexplored when the density part leaves the pair loop (see the sweep)
 
 // =================================================================================================
 template <int ZB>
@@ -26,7 +27,9 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 	__shared__ double tile[TD];                 // [SW_TILE][20] prior components | [births][13] in the tail
 	__shared__ double etab[EXPTAB_N];
 	__shared__ int    born[MP];
-	__shared__ int    s_ncand, s_nb, s_nmis;
+	__shared__ int    s_ncand, s_nb, s_nmis, s_nu;
+	__shared__ int    s_ulist[SW_UMAX];
+	__shared__ double s_du[SW_UMAX];
 
 	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int M = a.M;
@@ -42,7 +45,7 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 	double rq[9];
 	conj_matrix(pose, rq);
 	exp_tab_init(etab, tid);
-	if (tid == 0) { s_ncand = 0; s_nb = 0; s_nmis = 0; }
+	if (tid == 0) { s_ncand = 0; s_nb = 0; s_nmis = 0; s_nu = 0; }
 	for (int k = tid; k < MP; k += 256) {
 		double z[3] = {0, 0, 1}, x[3] = {0, 0, 0};
 		if (k < M) {
@@ -88,9 +91,13 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 		}
 	};
 
-	// ---- prior components: Explored density and weight sums together. Every term of the density is >= 0, so a wave
-	// whose partial sums already reach the threshold for all of its measurements drops the density part.
-	bool explored = false;
+	// ---- prior components: Explored density and weight sums together. Every term of the density is >= 0, so a measurement
+	// is explored as soon as the sum so far reaches the threshold — within a tile or two for all but the few that will
+	// be born: a component within five sigma does it. Once at most SW_UMAX measurements are still open the
+	// density part leaves the pair loop (where it would keep costing all 64 lanes an evaluation per component) and
+	// the open measurements are summed the other way round: component per lane, one open measurement at a time, a
+	// wave reduction per tile. The terms are the same; only their order of addition differs.
+	bool compact = false;   // block-uniform
 	for (int c0 = 0; c0 < n; c0 += SW_TILE) {
 		{   // two threads per component: waves 0-1 build its map-space record, waves 2-3 its measurement-space record
 			const int cl = tid & (SW_TILE - 1), c = c0 + cl;
@@ -146,13 +153,30 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 		}
 		__syncthreads();
 		const int cend = min(SW_TILE, n - c0);
+		if (compact) {
+			const int nu = s_nu;
+			for (int u = wv; u < nu; u += 4) {   // (wave-uniform) this wave alone adds to s_du[u]
+				const int k = s_ulist[u];
+				const double ux = zmap[k * 3], uy = zmap[k * 3 + 1], uz = zmap[k * 3 + 2];
+				double acc = 0;
+				for (int cc = lane; cc < cend; cc += 64) {
+					const double* tt = tile + cc * SW_REC;
+					const double e0 = ux - tt[10], e1 = uy - tt[11], e2 = uz - tt[12];
+					const double vm = exp_neg(gauss_logw(tt + 10, e0, e1, e2), etab);
+					if (e0 * e0 + e1 * e1 + e2 * e2 <= g2e) acc += vm;
+				}
+#pragma unroll
+				for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+				if (lane == 0) s_du[u] += acc;
+			}
+		}
 		auto visit = [&](int cc) {
 			const double* tt = tile + cc * SW_REC;
 #pragma unroll
 			for (int b = 0; b < ZB; b++) {
 				double e0 = wx[b] - tt[10], e1 = wy[b] - tt[11], e2 = wz[b] - tt[12];
 				double sq = e0 * e0 + e1 * e1 + e2 * e2;
-				if (!explored) {
+				if (!compact) {
 					// w * N(x; m, P) of the component at MeasureToMap(z), inside the radius gate (Map.cs:214-217)
 					double vm = exp_neg(gauss_logw(tt + 10, e0, e1, e2), etab);
 					if (zv[b] && sq <= g2e) dens[b] += vm;
@@ -163,13 +187,38 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 		int cc = wv;
 		for (; cc + 4 < cend; cc += 8) { visit(cc); visit(cc + 4); }
 		if (cc < cend) visit(cc);
-		if (!explored) {
-			bool open = false;
+		if (!compact) {
 #pragma unroll
-			for (int b = 0; b < ZB; b++) open |= zv[b] && !(dens[b] >= thr);
-			explored = __ballot(open) == 0;
+			for (int b = 0; b < ZB; b++) part2[wv * MP + b * 64 + lane] = dens[b];
 		}
 		__syncthreads();
+		if (!compact) {   // every wave adds up the same partial sums
+			int nopen = 0;
+			unsigned long long open[ZB];
+#pragma unroll
+			for (int b = 0; b < ZB; b++) {
+				const int k = b * 64 + lane;
+				const double d = part2[k] + part2[MP + k] + part2[2 * MP + k] + part2[3 * MP + k];
+				open[b] = __ballot(zv[b] && !(d >= thr));
+				nopen += __popcll(open[b]);
+			}
+			if (nopen <= SW_UMAX) {
+				compact = true;
+				if (wv == 0) {   // read after the next tile's staging barrier (or the one before the births)
+					int base = 0;
+#pragma unroll
+					for (int b = 0; b < ZB; b++) {
+						if ((open[b] >> lane) & 1ull) {
+							const int u = base + __popcll(open[b] & lanemask_lt());
+							s_ulist[u] = b * 64 + lane;
+							s_du[u] = 0.0;
+						}
+						base += __popcll(open[b]);
+					}
+					if (lane == 0) s_nu = nopen;
+				}
+			}
+		}
 	}
 
 	// ---- births (:806-818): measurements whose density stays below the threshold, in measurement order
@@ -179,6 +228,12 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 	for (int k = tid; k < MP; k += 256) {
 		double d = part2[k] + part2[MP + k] + part2[2 * MP + k] + part2[3 * MP + k];
 		born[k] = (k < M) && !(d >= thr);   // !Explored (:808, :958)
+	}
+	__syncthreads();
+	if (tid < s_nu) {   // the measurements finished component-per-lane: their remaining terms are in s_du
+		const int k = s_ulist[tid];
+		const double d = part2[k] + part2[MP + k] + part2[2 * MP + k] + part2[3 * MP + k] + s_du[tid];
+		born[k] = !(d >= thr);
 	}
 	__syncthreads();
 	if (tid == 0) {
