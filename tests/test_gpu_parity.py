@@ -458,3 +458,32 @@ def test_reweight_far_from_the_origin(nav_mod):
         # about three digits of alpha (the kernels before and after the change compute the same bits in this regime)
         assert np.isclose(alpha[i], a, rtol=5e-3, atol=0), "alpha[%d]: %r vs %r" % (i, alpha[i], a)
     nav.close()
+
+
+@pytest.mark.parametrize("nborn", [5, 30])
+def test_births_with_the_density_out_of_the_pair_loop(nav_mod, nborn):
+    """k_sweep takes the Explored density out of its pair loop once at most 16 measurements are unexplored and sums
+    those component-per-lane: a frame with a few births (the switch happens, the births are decided by the second
+    form) and one with more births than that (the switch never happens), 400 components = 4 tiles, against the oracle."""
+    P, C, M = 3, 400, 64
+    f = Frame(P, C, M, 95, weight_profile="steady")
+    p0 = prm3d_defaults(max_particles=P, max_components=600, max_measurements=M)
+    f.w = f.w.copy()
+    picked = np.arange(0, 2 * nborn, 2)[:nborn]                     # measurements that must find nothing around them
+    for i in range(P):
+        for k in picked:
+            x = orc.measure_to_map(p0, f.poses[i], f.z[k])
+            f.w[i, np.linalg.norm(f.mean[i] - x, axis=1) < 0.45] = 1e-40
+    nav, p = make_nav(nav_mod, f)
+    nav.run_stages(f.z, with_alpha=True)
+    alpha = nav.WeightAlpha()
+    for i in range(P):
+        pred = orc.predict(p, f.poses[i], f.z, f.map(i))
+        assert len(pred[0]) - C >= nborn
+        assert_mix_close(nav.PredictConditional(i), pred, 1e-9, "predict[%d]" % i)
+        cor = orc.correct(p, f.poses[i], f.z, pred)
+        pr = orc.prune(p, cor)
+        assert_mix_close(nav.PruneModel(i), pr, 1e-7, "prune[%d]" % i)
+        a, _ = orc.weight_alpha(p, f.poses[i], f.z, pred, pr)
+        assert np.isclose(alpha[i], a, rtol=1e-6, atol=0), "alpha[%d]: %r vs %r" % (i, alpha[i], a)
+    nav.close()
