@@ -30,6 +30,7 @@
 
 #define PRUNE_NBR 7
 #define PRUNE_NB 4096   // buckets of the spatial hash (16-bit counters, two per LDS word)
+#define PRUNE_HEAVY 32  // a row with more candidates than this is searched by a whole wave
 
 struct PruneLds {
 	int rad2, x, scan;       // offsets in doubles
@@ -46,8 +47,8 @@ __host__ __device__ inline PruneLds prune_lds(int cutcap)
 	l.NS    = NS;
 	l.rad2  = 0;
 	l.x     = l.rad2 + cc;                   // sort words u64[NS]  |  the lists of the pair search (see `rest`)
-	// nbr u64[2*cc], cand float4[cc], owner int[cc], cstart u16[NB+2], absb int[64], ord u16[cc]
-	int rest  = 2 * cc + 2 * cc + cc / 2 + (PRUNE_NB + 2) / 4 + 1 + 32 + cc / 4 + 1 + 4;
+	// nbr u64[2*cc], cand float4[cc], owner int[cc], cstart u16[NB+2], absb int[64], ord u16[cc], rowpos u16[cc]
+	int rest  = 2 * cc + 2 * cc + cc / 2 + (PRUNE_NB + 2) / 4 + 1 + 32 + 2 * (cc / 4 + 1) + 4;
 	l.scan  = l.x + (NS > rest ? NS : rest);
 	l.bytes = (l.scan + 136) * 8;            // int[264] | double[28], + spare
 	return l;
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	const unsigned short* cstart = (const unsigned short*) cw;   // [NB + 2] bucket b is [cstart[b], cstart[b + 1])
 	int*    absb  = (int*) (cw + (PRUNE_NB + 2) / 2 + 1);  // [64] absorbed bits as left by the resolving wave
 	unsigned short* ord = (unsigned short*) (absb + 64);   // [cut] rows in the order the pair search takes them
+	unsigned short* rowpos = ord + cc;                      // [cut] position of row r in `cand`
 	int*    scan  = (int*) (smem + lay.scan);              // [264]
 	double* bred  = smem + lay.scan;                       // [28] block reduction scratch (before `scan` is used)
 
@@ -343,6 +345,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 			const int b = owner[r], sh = 16 * (b & 1);
 			const int pos = (int) ((atomicSub(&cw[b >> 1], 1u << sh) >> sh) & 0xffff) - 1;
 			cand[pos] = make_float4((float) s0, (float) s1, (float) s2, __int_as_float(r));
+			rowpos[r] = (unsigned short) pos;
 			owner[r] = -1;
 		}
 		__syncthreads();
@@ -352,10 +355,11 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 		// meets; cells near the sensor hold an order of magnitude more rows than the rest): a wave then walks as long as
 		// its rows need on average, not as long as the one unlucky row in it. Counting sort by min(count, 63); 63 also
 		// stands for the rows that must test every later row.
-		auto ranges = [&](int i, unsigned int* qb) {   // the 8 bucket ranges of row i as start | length << 16; returns the total
-			const double m0 = srec[i], m1 = srec[(size_t) cutcap + i], m2 = srec[(size_t) 2 * cutcap + i];
-			const int bx = (int) floor((m0 - mn0) * icell - 0.5), by = (int) floor((m1 - mn1) * icell - 0.5),
-			          bz = (int) floor((m2 - mn2) * icell - 0.5);
+		// (the row's own float32 coordinates, from its record in `cand`: 2^-24 of the extent away from the true ones, far
+		// inside the margin rcap leaves between a ball and the 2 x 2 x 2 cells around it — no global load in this part)
+		auto ranges = [&](const float4& me, unsigned int* qb) {   // the 8 bucket ranges of a row as start | length << 16; returns the total
+			const int bx = (int) floor((double) me.x * icell - 0.5), by = (int) floor((double) me.y * icell - 0.5),
+			          bz = (int) floor((double) me.z * icell - 0.5);
 			const unsigned int xa0 = (unsigned int) (bx >> 1) * HA, xa1 = (unsigned int) ((bx + 1) >> 1) * HA;
 			const unsigned int yb0 = (unsigned int) (by >> 1) * HB, yb1 = (unsigned int) ((by + 1) >> 1) * HB;
 			const unsigned int zc0 = (unsigned int) (bz >> 1) * HC, zc1 = (unsigned int) ((bz + 1) >> 1) * HC;
@@ -378,7 +382,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 			int key = 63;
 			if (rad2[i] <= rcap * rcap) {
 				unsigned int qb[8];
-				key = min(ranges(i, qb), 62);
+				key = min(ranges(cand[rowpos[i]], qb), 62);
 			}
 			owner[i] = key;
 			atomicAdd(&hist[key], 1);
@@ -402,19 +406,34 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 		}
 		__syncthreads();
 		PHD_STAMP(8);
+		// hist[key] now ends key's rows: the rows with more than PRUNE_HEAVY candidates (and those on the full scan) sit
+		// at the positions from hstart on. One lane would walk such a row for a hundred trips while its wave waits, so
+		// they are left to the loop after this one, where a wave spreads one row's candidates over its lanes.
+		const int hstart = hist[PRUNE_HEAVY];
+#ifdef PHD_STAMPS
+		long long acc_setup = 0, acc_trips = 0, acc_drain = 0, tmark = clock64();
+#endif
 
-		for (int t = tid; t < cut; t += 256) {
+		for (int t = tid; t < hstart; t += 256) {
 			const int i = ord[t];
-			double P[6], Pi[6], det;
-#pragma unroll
-			for (int u = 0; u < 6; u++) P[u] = srec[(size_t) (3 + u) * cutcap + i];
-			inv_sym3(P, Pi, det);
-			const double m0 = srec[i], m1 = srec[(size_t) cutcap + i], m2 = srec[(size_t) 2 * cutcap + i], bound = rad2[i];
+			const float4 me = cand[rowpos[i]];
+			const double bound = rad2[i];
 			int cnt = 0;
 			unsigned int e[PRUNE_NBR];   // close rows found (statically indexed only)
 #pragma unroll
 			for (int q = 0; q < PRUNE_NBR; q++) e[q] = 0xffffu;
+			// the row's own record (mean, P^-1) is needed by the exact test only, which few rows ever reach: loaded then
+			bool have = false;
+			double m0 = 0, m1 = 0, m2 = 0, Pi[6] = {0, 0, 0, 0, 0, 0};
 			auto test = [&](int k) {
+				if (!have) {
+					double P[6], det;
+#pragma unroll
+					for (int u = 0; u < 6; u++) P[u] = srec[(size_t) (3 + u) * cutcap + i];
+					inv_sym3(P, Pi, det);
+					m0 = srec[i]; m1 = srec[(size_t) cutcap + i]; m2 = srec[(size_t) 2 * cutcap + i];
+					have = true;
+				}
 				double d0 = m0 - srec[k], d1 = m1 - srec[(size_t) cutcap + k], d2 = m2 - srec[(size_t) 2 * cutcap + k];
 				double sq = d0 * d0 + d1 * d1 + d2 * d2;
 				if (sq <= bound && quad_sym(Pi, d0, d1, d2) < merge_thr2) {   // Gaussian.SquareMahalanobis(b.Mean) < threshold^2
@@ -429,7 +448,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 				}
 			};
 			if (bound <= rcap * rcap) {
-				const float fx = (float) (m0 - mn0), fy = (float) (m1 - mn1), fz = (float) (m2 - mn2);
+				const float fx = me.x, fy = me.y, fz = me.z;
 				const double rr = sqrt(bound) + ferr;
 				const float thr = (float) (rr * rr * (1.0 + 1e-5));
 				unsigned long long pend0 = 0, pend1 = 0;   // up to 8 queued rows as 16-bit fields
@@ -442,17 +461,38 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 					pend0 = 0; pend1 = 0;
 				};
 				unsigned int qb[8];
-				const int n = ranges(i, qb);
+				const int n = ranges(me, qb);
 				// one candidate per trip, the 8 ranges one after the other. The exact test is rare per lane but not per
 				// wave: a candidate that passes the float32 distance test is queued and tested later, so that the waves do
 				// not run the FP64 path at every candidate
+				// the non-empty ranges first, in their order (a stable compaction through static indices): the walk below then
+				// moves to the next range with one predicated step instead of a loop over possibly empty ones
+				unsigned int nz[8];
+				{
+					int before[8], run = 0;
+#pragma unroll
+					for (int u = 0; u < 8; u++) { before[u] = run; run += (qb[u] >> 16) ? 1 : 0; }
+#pragma unroll
+					for (int j = 0; j < 8; j++) {
+						unsigned int v = 0;
+#pragma unroll
+						for (int u = j; u < 8; u++) v = ((qb[u] >> 16) && before[u] == j) ? qb[u] : v;
+						nz[j] = v;
+					}
+				}
+#ifdef PHD_STAMPS
+				{ long long now = clock64(); acc_setup += now - tmark; tmark = now; }
+#endif
 				unsigned int cur = 0, left = 0;
 				int c = 0;
 				for (int f = 0; f < n; f++) {
-					while (left == 0) {
-						unsigned int q = qb[0];
+#ifdef PHD_STAMP_COUNTERS
+					if (a.stamps && a.stamp_kernel == 2 && (int) (__ffsll((long long) __ballot(1)) - 1) == lane) atomicAdd(&a.stamps[(size_t) p * 16 + 15], 1.0);   // wave-level trips
+#endif
+					if (left == 0) {
+						unsigned int q = nz[0];
 #pragma unroll
-						for (int u = 1; u < 8; u++) q = (c == u) ? qb[u] : q;
+						for (int u = 1; u < 8; u++) q = (c == u) ? nz[u] : q;
 						c++;
 						cur = q & 0xffff; left = q >> 16;
 					}
@@ -467,7 +507,13 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 						if (npend > 7) drain();
 					}
 				}
+#ifdef PHD_STAMPS
+				{ long long now = clock64(); acc_trips += now - tmark; tmark = now; }
+#endif
 				drain();
+#ifdef PHD_STAMPS
+				{ long long now = clock64(); acc_drain += now - tmark; tmark = now; }
+#endif
 			}
 			else {
 				for (int k = i + 1; k < cut; k++) test(k);
@@ -484,14 +530,101 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 			nbr[2 * i + 1] = hi;
 #ifdef PHD_STAMP_COUNTERS   // (slow: contended atomics; counts only, never together with timing)
 			if (a.stamps && a.stamp_kernel == 2) {
-				atomicAdd(&a.stamps[(size_t) p * 16 + 12], (double) ((bound <= rcap * rcap) ? 0 : 1));   // rows on the full scan
 				atomicAdd(&a.stamps[(size_t) p * 16 + 14], (double) cnt);                               // close pairs
 				unsigned int qd[8];
-				atomicAdd(&a.stamps[(size_t) p * 16 + 13], (double) ((bound <= rcap * rcap) ? ranges(i, qd) : 0));     // candidates
+				atomicAdd(&a.stamps[(size_t) p * 16 + 13], (double) ((bound <= rcap * rcap) ? ranges(me, qd) : 0));     // candidates
 			}
 #endif
 		}
+
+#ifdef PHD_STAMPS
+		if (tid == 0 && a.stamps && a.stamp_kernel == 2) { a.stamps[(size_t) p * 16 + 12] = (double) acc_setup; a.stamps[(size_t) p * 16 + 13] = (double) acc_trips; a.stamps[(size_t) p * 16 + 14] = (double) acc_drain; }
+#endif
+		PHD_STAMP(9);
+		for (int h = hstart + wv; h < cut; h += 4) {   // (wave-uniform) one crowded row per wave at a time, candidate per lane
+			const int i = ord[h];
+			const float4 me = cand[rowpos[i]];
+			const double bound = rad2[i];
+			int cnt = 0;
+			unsigned int e[PRUNE_NBR];   // the same in every lane
+#pragma unroll
+			for (int q = 0; q < PRUNE_NBR; q++) e[q] = 0xffffu;
+			bool have = false;
+			double m0 = 0, m1 = 0, m2 = 0, Pi[6] = {0, 0, 0, 0, 0, 0};
+			auto exact = [&](int k) {
+				if (!have) {
+					double P[6], det;
+#pragma unroll
+					for (int u = 0; u < 6; u++) P[u] = srec[(size_t) (3 + u) * cutcap + i];
+					inv_sym3(P, Pi, det);
+					m0 = srec[i]; m1 = srec[(size_t) cutcap + i]; m2 = srec[(size_t) 2 * cutcap + i];
+					have = true;
+				}
+				const double d0 = m0 - srec[k], d1 = m1 - srec[(size_t) cutcap + k], d2 = m2 - srec[(size_t) 2 * cutcap + k];
+				return d0 * d0 + d1 * d1 + d2 * d2 <= bound && quad_sym(Pi, d0, d1, d2) < merge_thr2;
+			};
+			auto collect = [&](bool close, int k) {   // the close rows found by the lanes, into the sorted list all lanes keep
+				unsigned long long bal = __ballot(close);
+				while (bal) {
+					const int l = __ffsll((long long) bal) - 1;
+					bal &= bal - 1;
+					unsigned int v = (unsigned int) __shfl(k, l, 64);
+#pragma unroll
+					for (int q = 0; q < PRUNE_NBR; q++) {
+						unsigned int lo_ = min(e[q], v), hi_ = max(e[q], v);
+						e[q] = lo_; v = hi_;
+					}
+					cnt++;
+				}
+			};
+			if (bound <= rcap * rcap) {
+				const double rr = sqrt(bound) + ferr;
+				const float thr = (float) (rr * rr * (1.0 + 1e-5));
+				unsigned int qb[8];
+				const int n = ranges(me, qb);
+				for (int f0 = 0; f0 < n; f0 += 64) {
+					const int f = f0 + lane;
+					int rem = f;
+					unsigned int cur = 0;
+					bool found = false;
+#pragma unroll
+					for (int c = 0; c < 8; c++) {
+						const int len = (int) (qb[c] >> 16);
+						if (!found && rem < len) { cur = (qb[c] & 0xffff) + (unsigned int) rem; found = true; }
+						else if (!found) rem -= len;
+					}
+					bool close = false;
+					int k = 0;
+					if (found) {
+						const float4 cd = cand[cur];
+						k = __float_as_int(cd.w);
+						const float e0 = me.x - cd.x, e1 = me.y - cd.y, e2 = me.z - cd.z;
+						if (k > i && e0 * e0 + e1 * e1 + e2 * e2 <= thr) close = exact(k);
+					}
+					collect(close, k);
+				}
+			}
+			else {
+				for (int k0 = i + 1; k0 < cut; k0 += 64) {
+					const int k = k0 + lane;
+					collect(k < cut && exact(k), k);
+				}
+			}
+			if (lane == 0) {
+				unsigned long long lo = (unsigned long long) min(cnt, 0xffff), hi = 0;
+#pragma unroll
+				for (int q = 0; q < PRUNE_NBR; q++) {
+					if (q < cnt) {
+						if (q < 3) lo |= (unsigned long long) e[q] << (16 * (q + 1));
+						else hi |= (unsigned long long) e[q] << (16 * (q - 3));
+					}
+				}
+				nbr[2 * i]     = lo;
+				nbr[2 * i + 1] = hi;
+			}
+		}
 	}
+	PHD_STAMP(10);
 	__syncthreads();
 
 	PHD_STAMP(3);
@@ -640,5 +773,5 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	}
 	PHD_STAMP(5);
 	if (tid == 0) vout.count[p] = nsurv_before;
-	PHD_STAMP_FLUSH(2, 9);
+	PHD_STAMP_FLUSH(2, 11);
 }

@@ -487,3 +487,26 @@ def test_births_with_the_density_out_of_the_pair_loop(nav_mod, nborn):
         a, _ = orc.weight_alpha(p, f.poses[i], f.z, pred, pr)
         assert np.isclose(alpha[i], a, rtol=1e-6, atol=0), "alpha[%d]: %r vs %r" % (i, alpha[i], a)
     nav.close()
+
+
+@pytest.mark.parametrize("dups,indefinite", [(40, False), (10, True)])
+def test_prune_crowded_cells_and_rows_without_a_bound(nav_mod, dups, indefinite):
+    """k_prune_merge hands a row with more than 32 candidates, and any row whose covariance gives no Euclidean bound (not
+    positive definite: it must be tested against every later row), to a whole wave: 5 centres x 40 near-duplicates put
+    ~100 rows into one cell; an indefinite covariance takes the second road. Against the oracle."""
+    rng = np.random.default_rng(5)
+    f = Frame(3, 200, 16, 23, weight_profile="steady")
+    f.mean = np.array(f.mean)
+    f.cov = np.array(f.cov)
+    centres = f.mean[:, :200 // dups]
+    f.mean[:, :] = np.repeat(centres, dups, axis=1) + rng.normal(size=f.mean.shape) * 2e-3
+    if indefinite:
+        f.cov[:, 7] = np.diag([2e-3, -1e-3, 1.5e-3])
+        f.cov[:, 90] = np.array([[1e-3, 2e-3, 0], [2e-3, 1e-3, 0], [0, 0, 1e-3]])
+    nav, p = make_nav(nav_mod, f)
+    nav.run_stages(f.z, with_alpha=False)
+    for i in range(f.P):
+        pred = orc.predict(p, f.poses[i], f.z, f.map(i))
+        pr = orc.prune(p, orc.correct(p, f.poses[i], f.z, pred))
+        assert_mix_close(nav.PruneModel(i), pr, 1e-7, "prune[%d]" % i)
+    nav.close()
