@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="particles in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP events")
-    ap.add_argument("--events-every", type=int, default=4, help="time the launches of every n-th step of the timed region (each event costs the device a few microseconds)")
+    ap.add_argument("--events-every", type=int, default=8, help="time the launches of every n-th step of the timed region (each event costs the device a few microseconds)")
     ap.add_argument("--force-dist", action="store_true", help="take the sharded (RCCL) step path even with one rank (rehearsal)")
     return ap.parse_args()
 
