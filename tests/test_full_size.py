@@ -169,3 +169,57 @@ def test_sharded_step_equals_single_handle(world):
     one.close()
     for nv in navs:
         nv.close()
+
+
+def test_sharded_step_after_a_single_handle_resampling():
+    """A single-handle step that resampled leaves the maps behind the slot indirection; the sharded sequence addresses
+    maps by particle number (they cross ranks), so phd_step_local_async first gathers them into place (k_materialise).
+    One handle takes [step, step], the other [step, sharded step with one rank]: the same state, bit for bit."""
+    import ctypes as C
+    import torch
+    from monorfs_amd import navigator
+    P, Cc, M = 64, 60, 16
+    f = Frame(P, Cc, M, 88, weight_profile="steady")
+    navs = []
+    for _ in range(2):
+        pr = prm3d_defaults(max_particles=P, max_components=600, max_measurements=M)
+        nv = navigator.PHDNavigator(pr, particlecount=P)
+        nv.upload_state(f.planes(), f.counts, f.poses, f.weights)
+        navs.append(nv)
+    a, b = navs
+    lib = b._lib
+    ip = C.POINTER(C.c_int32)
+    rng = np.random.default_rng(89)
+    for _ in range(6):                                   # ordinary steps until one resamples
+        z1 = f.z + rng.normal(size=f.z.shape) * [0.5, 0.5, 0.01]
+        a.SlamUpdate(None, z1, u_resample=0.41)
+        b.SlamUpdate(None, z1, u_resample=0.41)
+        if a.resample_sources()[1]:
+            break
+    assert a.resample_sources()[1], "no step resampled: this test would mean nothing"
+    z2 = f.z + 0.2
+    a.SlamUpdate(None, z2, u_resample=0.27)
+    b.set_measurements(z2)
+    b._check(lib.phd_set_stream(b._h, C.c_void_p(torch.cuda.current_stream().cuda_stream), 1))
+    gw = torch.as_tensor(_Dev(lib.phd_device_global_weights(b._h, P), P), device="cuda")
+    b._check(lib.phd_step_local_async(b._h, 0))
+    gw.copy_(torch.as_tensor(_Dev(lib.phd_device_local_weights(b._h), P), device="cuda"))
+    b._check(lib.phd_step_global_async(b._h, 0, 1, C.c_double(0.27)))
+    s, q = np.zeros(1, np.int32), np.zeros(1, np.int32)
+    b._check(lib.phd_migration_plan(b._h, 0, 1, s.ctypes.data_as(ip), q.ctypes.data_as(ip)))
+    b._check(lib.phd_migration_pack_async(b._h))
+    b._check(lib.phd_migration_unpack_async(b._h))
+    b.sync()
+    assert np.array_equal(a.VehicleWeights, b.VehicleWeights) and np.array_equal(a.poses(), b.poses())
+    assert a.BestParticle == b.BestParticle
+    for g in range(0, P, 3):
+        assert all(np.array_equal(x, y) for x, y in zip(a.MapModel(g), b.MapModel(g))), "particle %d" % g
+    # and onwards from the sharded step's (materialised) state with an ordinary one
+    b._check(lib.phd_set_stream(b._h, None, 0))
+    a.SlamUpdate(None, f.z, u_resample=0.63)
+    b.SlamUpdate(None, f.z, u_resample=0.63)
+    assert np.array_equal(a.VehicleWeights, b.VehicleWeights)
+    for g in range(0, P, 5):
+        assert all(np.array_equal(x, y) for x, y in zip(a.MapModel(g), b.MapModel(g)))
+    a.close()
+    b.close()
