@@ -298,65 +298,30 @@ __global__ __launch_bounds__(256) void k_pack_particles(const StepBufs a, const 
 	}
 }
 
-// The slots of this rank whose resampling source is one of its own particles, copied OUT -> TMP straight from the
-// global source vector (no host plan needed): the bulk of a migration step, overlapped with the host's round trip.
-__global__ __launch_bounds__(256) void k_gather_local(const StepBufs a, const int* gsrc, const int* info, int first)
-{
-	if (!info[1]) return;   // no resampling this step
-	const int i = blockIdx.x, tid = threadIdx.x;
-	const int s = gsrc[first + i] - first;
-	if (s < 0 || s >= a.P) return;   // remote source: filled by k_unpack_gather from the receive buffer
-	const MixView from = bank_view(a, SEL_OUT), dst = bank_view(a, SEL_TMP);
-	const int n = from.count[s];
-	const size_t db = (size_t) i * a.cap, fb = (size_t) s * a.cap;
-	for (int c = tid; c < n; c += 256) {
-		dst.w[db + c] = from.w[fb + c];
-#pragma unroll
-		for (int t = 0; t < 3; t++) dst.m[t][db + c] = from.m[t][fb + c];
-#pragma unroll
-		for (int t = 0; t < 6; t++) dst.P[t][db + c] = from.P[t][fb + c];
-	}
-	if (tid == 0) dst.count[i] = n;
-	if (tid < 7) bank_of(a, SEL_TMP).poses[(size_t) i * 7 + tid] = bank_of(a, SEL_OUT).poses[(size_t) s * 7 + tid];
-}
-
-// dstsrc[i] >= 0: local source slot in the OUT bank (skipped when k_gather_local already copied those);
-// < 0: record -(dstsrc[i] + 1) of the receive buffer
-// The sharded step copies mixtures for real (they cross ranks): it starts from a materialised state (INMIX = IN) and
-// leaves one (the new particles, mixtures included, in TMP; slots identity).
-__global__ __launch_bounds__(256) void k_unpack_gather(const StepBufs a, const int* dstsrc, const double* recvbuf,
-                                                       double weight, int* sel_next, int frozen, int local_done, int* inslot)
+// End of a sharded step that resampled. As in the single-handle step no local mixture is copied: particle i whose
+// source is a local particle reads that particle's slot of the OUT bank from now on; a particle that arrives from
+// another rank (record j of the receive buffer) is unpacked into a slot of the OUT bank that no local particle uses
+// as a source (fslot[j], chosen by the host plan: there are always enough) and read from there. Block b unpacks record
+// b (if there is one) and sets up particle b: small arrays into TMP, slot into inslot / slots.
+//   dstsrc[i] >= 0: local source slot; < 0: record -(dstsrc[i] + 1)
+__global__ __launch_bounds__(256) void k_unpack_gather(const StepBufs a, const int* dstsrc, const double* recvbuf, int nrecv,
+                                                       const int* fslot, double weight, int* sel_next, int frozen, int* inslot,
+                                                       int* slots)
 {
 	const int i = blockIdx.x, tid = threadIdx.x;
 	const int I = a.sel[SEL_IN], O = a.sel[SEL_OUT], T = a.sel[SEL_TMP];
 	if (i == 0 && tid == 0) {
 		if (frozen) { sel_next[SEL_IN] = I; sel_next[SEL_OUT] = O; sel_next[SEL_TMP] = T; sel_next[SEL_INMIX] = a.sel[SEL_INMIX]; }
-		else        { sel_next[SEL_IN] = T; sel_next[SEL_OUT] = I; sel_next[SEL_TMP] = O; sel_next[SEL_INMIX] = T; }
+		else        { sel_next[SEL_IN] = T; sel_next[SEL_OUT] = I; sel_next[SEL_TMP] = O; sel_next[SEL_INMIX] = O; }
 		sel_next[SEL_RES] = T;
-		sel_next[SEL_RESMIX] = T;
+		sel_next[SEL_RESMIX] = O;
 	}
-	if (tid == 0 && !frozen) inslot[i] = i;
-	const MixView from = bank_view(a, SEL_OUT), dst = bank_view(a, SEL_TMP);
-	const size_t db = (size_t) i * a.cap;
-	const int code = dstsrc[i];
-	if (code >= 0 && local_done) {}
-	else if (code >= 0) {
-		const int n = from.count[code];
-		const size_t fb = (size_t) code * a.cap;
-		for (int c = tid; c < n; c += 256) {
-			dst.w[db + c] = from.w[fb + c];
-#pragma unroll
-			for (int t = 0; t < 3; t++) dst.m[t][db + c] = from.m[t][fb + c];
-#pragma unroll
-			for (int t = 0; t < 6; t++) dst.P[t][db + c] = from.P[t][fb + c];
-		}
-		if (tid == 0) dst.count[i] = n;
-		if (tid < 7) bank_of(a, SEL_TMP).poses[(size_t) i * 7 + tid] = bank_of(a, SEL_OUT).poses[(size_t) code * 7 + tid];
-	}
-	else {
-		const size_t rec = (size_t) 8 + (size_t) 10 * a.cap;
-		const double* r = recvbuf + (size_t) (-(code + 1)) * rec;
+	const size_t rec = (size_t) 8 + (size_t) 10 * a.cap;
+	if (i < nrecv) {
+		const MixView dst = bank_view(a, SEL_OUT);
+		const double* r = recvbuf + (size_t) i * rec;
 		const int n = (int) r[0];
+		const size_t db = (size_t) fslot[i] * a.cap;
 		for (int c = tid; c < n; c += 256) {
 			dst.w[db + c] = r[8 + c];
 #pragma unroll
@@ -364,8 +329,26 @@ __global__ __launch_bounds__(256) void k_unpack_gather(const StepBufs a, const i
 #pragma unroll
 			for (int t = 0; t < 6; t++) dst.P[t][db + c] = r[8 + (size_t) (4 + t) * a.cap + c];
 		}
-		if (tid == 0) dst.count[i] = n;
-		if (tid < 7) bank_of(a, SEL_TMP).poses[(size_t) i * 7 + tid] = r[1 + tid];
 	}
-	if (tid == 0) bank_of(a, SEL_TMP).weights[i] = weight;
+	if (i >= a.P) return;
+	const Bank bo = bank_of(a, SEL_OUT), bt = bank_of(a, SEL_TMP);
+	const int code = dstsrc[i];
+	int slot;
+	if (code >= 0) {
+		slot = code;
+		if (tid == 0) bt.count[i] = bo.count[code];
+		if (tid < 7) bt.poses[(size_t) i * 7 + tid] = bo.poses[(size_t) code * 7 + tid];
+	}
+	else {
+		const int j = -(code + 1);
+		const double* r = recvbuf + (size_t) j * rec;
+		slot = fslot[j];
+		if (tid == 0) bt.count[i] = (int) r[0];
+		if (tid < 7) bt.poses[(size_t) i * 7 + tid] = r[1 + tid];
+	}
+	if (tid == 0) {
+		bt.weights[i] = weight;
+		slots[i] = slot;
+		if (!frozen) inslot[i] = slot;
+	}
 }

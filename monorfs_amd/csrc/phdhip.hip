@@ -42,6 +42,10 @@ struct phd_navigator {
 
 	Bank   bank[3];
 	int*   d_sel = nullptr;      // [2][SEL_STRIDE]: roles for the current / next step (+ where the last result is)
+	int*   d_mslot = nullptr;    // [Pcap] sharded step: slot of every particle's mixture in the OUT bank; d_fslot [Pcap]: free slots for arrivals
+	int*   d_fslot = nullptr;
+	const int* d_res_slots = nullptr;   // slots of the last step's result in RESMIX (frozen mode getters)
+	std::vector<int> h_fslot;
 	int*   d_inslot = nullptr;   // [Pcap] slot of every particle's mixture in the INMIX bank (identity unless the last step resampled)
 	int    parity = 0;
 	int    h_sel[SEL_STRIDE] = {0, 1, 2, 0, 0, 0, 0, 0};
@@ -408,7 +412,7 @@ int cur_bank(const phd_navigator* nav) { return nav->h_sel[SEL_IN]; }
 // the roles do not advance and the result of the last step is described by RES / RESMIX and the resampling sources.
 int res_small(const phd_navigator* nav) { return nav->frozen ? nav->h_sel[SEL_RES] : nav->h_sel[SEL_IN]; }
 int res_mix(const phd_navigator* nav) { return nav->frozen ? nav->h_sel[SEL_RESMIX] : nav->h_sel[SEL_INMIX]; }
-const int* res_slots(const phd_navigator* nav) { return nav->frozen ? nav->d_src : nav->d_inslot; }
+const int* res_slots(const phd_navigator* nav) { return nav->frozen ? (nav->d_res_slots ? nav->d_res_slots : nav->d_src) : nav->d_inslot; }
 
 // The current state is about to be replaced as a whole: its mixtures will be addressed by particle number again.
 int reset_indirection(phd_navigator* nav)
@@ -582,7 +586,7 @@ void phd_destroy(phd_navigator* nav)
 	for (int i = 0; i < 3; i++) {
 		hipFree(nav->bank[i].mix); hipFree(nav->bank[i].count); hipFree(nav->bank[i].poses); hipFree(nav->bank[i].weights);
 	}
-	hipFree(nav->d_sel); hipFree(nav->d_inslot); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
+	hipFree(nav->d_sel); hipFree(nav->d_inslot); hipFree(nav->d_mslot); hipFree(nav->d_fslot); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
 	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_wcopy); hipFree(nav->d_cover); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
@@ -828,6 +832,7 @@ int phd_step_async(phd_navigator* nav, uint8_t onlymapping, double u_resample)
 	int rc = launch_map(nav, b, !onlymapping);
 	if (rc) return rc;
 	timer_begin(nav, T_NR);
+	nav->d_res_slots = nav->d_src;
 	// the same launch hands the resampled particles their small arrays and rotates the bank roles (rotate_roles)
 	rc = launch_normalise(nav, b, nullptr, nav->P, u_resample, onlymapping ? -1 : 0, onlymapping ? 1 : 0, nav->d_src, nav->d_info,
 	                      nav->d_sel + (nav->parity ^ 1) * SEL_STRIDE);
@@ -1142,11 +1147,6 @@ int phd_step_local_async(phd_navigator* nav, uint8_t onlymapping)
 	if (nav->P < 1) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step_local: no particles");
 	hipSetDevice(nav->device);
 	nav->timing_now = (nav->timing_step++ % nav->timing_period) == 0;
-	// the sharded step copies mixtures between ranks by particle number: it starts from a materialised state
-	int rc = PHD_OK;
-	if (!nav->sel_host_valid) rc = sync_state(nav);
-	if (!rc) rc = materialise(nav);
-	if (rc) return rc;
 	StepBufs b = make_bufs(nav);
 	return launch_map(nav, b, !onlymapping);
 }
@@ -1267,6 +1267,18 @@ int phd_migration_plan(phd_navigator* nav, int rank, int world_size, int32_t* se
 	nav->h_plan_recv = code;
 	nav->nsend = (int) nav->h_plan_send.size();
 	nav->nrecv = slot;
+	// an arriving particle is unpacked into a slot of the OUT bank that no local particle keeps as its source
+	{
+		std::vector<char> used(Pl, 0);
+		for (int i = 0; i < Pl; i++) if (code[i] >= 0) used[code[i]] = 1;
+		nav->h_fslot.assign(std::max(slot, 1), 0);
+		int f = 0;
+		for (int j = 0; j < slot; j++) {
+			while (f < Pl && used[f]) f++;
+			if (f >= Pl) return nav->fail(PHD_ERR_GENERIC, "phd_migration_plan: no free slot for an arriving particle");
+			nav->h_fslot[j] = f++;
+		}
+	}
 	size_t rec = (size_t) 8 + (size_t) 10 * nav->cap;
 	int need = std::max(nav->nsend, nav->nrecv);
 	if (need > nav->migcap) {
@@ -1294,14 +1306,7 @@ int phd_migration_local_async(phd_navigator* nav, int rank, int world_size)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	if (world_size < 1 || rank < 0 || rank >= world_size) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_local: bad rank/world");
-	hipSetDevice(nav->device);
-	StepBufs b = make_bufs(nav);
-	timer_begin(nav, T_GR);
-	hipLaunchKernelGGL(k_gather_local, dim3(nav->P), dim3(256), 0, nav->stream, b, nav->d_plan, nav->d_info, rank * nav->P);
-	timer_end(nav, T_GR);
-	HC(hipGetLastError());
-	nav->local_gather_done = true;
-	return PHD_OK;
+	return PHD_OK;   // particles whose source is local are no longer copied at all (see k_unpack_gather): nothing to start early
 }
 
 int phd_migration_pack_async(phd_navigator* nav)
@@ -1339,10 +1344,14 @@ int phd_migration_unpack_async(phd_navigator* nav)
 	}
 	else {
 		if (!nav->d_code) HC(hipMalloc((void**) &nav->d_code, (size_t) nav->Pcap * 4));
+		if (!nav->d_fslot) HC(hipMalloc((void**) &nav->d_fslot, (size_t) nav->Pcap * 4));
+		if (!nav->d_mslot) HC(hipMalloc((void**) &nav->d_mslot, (size_t) nav->Pcap * 4));
 		HC(hipMemcpyAsync(nav->d_code, nav->h_plan_recv.data(), (size_t) nav->P * 4, hipMemcpyHostToDevice, nav->stream));
+		if (nav->nrecv > 0) HC(hipMemcpyAsync(nav->d_fslot, nav->h_fslot.data(), (size_t) nav->nrecv * 4, hipMemcpyHostToDevice, nav->stream));
+		nav->d_res_slots = nav->d_mslot;
 		timer_begin(nav, T_GR);
-		hipLaunchKernelGGL(k_unpack_gather, dim3(nav->P), dim3(256), 0, nav->stream, b, nav->d_code, nav->d_recv,
-		                   1.0 / (double) nav->last_world_particles, sel_next, nav->frozen ? 1 : 0, nav->local_gather_done ? 1 : 0, nav->d_inslot);
+		hipLaunchKernelGGL(k_unpack_gather, dim3(std::max(nav->P, nav->nrecv)), dim3(256), 0, nav->stream, b, nav->d_code, nav->d_recv, nav->nrecv,
+		                   nav->d_fslot, 1.0 / (double) nav->last_world_particles, sel_next, nav->frozen ? 1 : 0, nav->d_inslot, nav->d_mslot);
 		timer_end(nav, T_GR);
 		HC(hipGetLastError());
 	}
@@ -1351,12 +1360,12 @@ int phd_migration_unpack_async(phd_navigator* nav)
 	nav->stage_valid = false;
 	if (nav->sel_host_valid && !nav->frozen) {   // same rotation as the kernels wrote to the device
 		int I = nav->h_sel[SEL_IN], O = nav->h_sel[SEL_OUT], T = nav->h_sel[SEL_TMP];
-		if (nav->h_info[1]) { nav->h_sel[SEL_IN] = T; nav->h_sel[SEL_OUT] = I; nav->h_sel[SEL_TMP] = O; nav->h_sel[SEL_RES] = T; nav->h_sel[SEL_INMIX] = T; nav->h_sel[SEL_RESMIX] = T; }
+		if (nav->h_info[1]) { nav->h_sel[SEL_IN] = T; nav->h_sel[SEL_OUT] = I; nav->h_sel[SEL_TMP] = O; nav->h_sel[SEL_RES] = T; nav->h_sel[SEL_INMIX] = O; nav->h_sel[SEL_RESMIX] = O; }
 		else                { nav->h_sel[SEL_IN] = O; nav->h_sel[SEL_OUT] = I; nav->h_sel[SEL_TMP] = T; nav->h_sel[SEL_RES] = O; nav->h_sel[SEL_INMIX] = O; nav->h_sel[SEL_RESMIX] = O; }
 	}
 	else if (nav->sel_host_valid) {
 		nav->h_sel[SEL_RES] = nav->h_info[1] ? nav->h_sel[SEL_TMP] : nav->h_sel[SEL_OUT];
-		nav->h_sel[SEL_RESMIX] = nav->h_sel[SEL_RES];
+		nav->h_sel[SEL_RESMIX] = nav->h_sel[SEL_OUT];
 	}
 	return PHD_OK;
 }

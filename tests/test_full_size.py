@@ -172,9 +172,10 @@ def test_sharded_step_equals_single_handle(world):
 
 
 def test_sharded_step_after_a_single_handle_resampling():
-    """A single-handle step that resampled leaves the maps behind the slot indirection; the sharded sequence addresses
-    maps by particle number (they cross ranks), so phd_step_local_async first gathers them into place (k_materialise).
-    One handle takes [step, step], the other [step, sharded step with one rank]: the same state, bit for bit."""
+    """A single-handle step that resampled leaves the maps behind the slot indirection, and so does the sharded sequence
+    (local sources are not copied, arrivals go to free slots of the bank the step wrote): the two kinds of step can
+    follow each other. One handle takes [steps, step, step], the other [steps, sharded step with one rank, step]: the
+    same state, bit for bit."""
     import ctypes as C
     import torch
     from monorfs_amd import navigator
