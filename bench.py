@@ -160,7 +160,6 @@ def main():
         nav._check(lib.phd_step_local_async(h, 0))
         dist.all_gather_into_tensor(gw, dev_tensor(lib.phd_device_local_weights(h), P))
         nav._check(lib.phd_step_global_async(h, rank, world, u))
-        nav._check(lib.phd_migration_local_async(h, rank, world))   # local sources are copied while the host plans
         nav._check(lib.phd_migration_plan(h, rank, world, scounts.ctypes.data_as(ip), rcounts.ctypes.data_as(ip)))
         nav._check(lib.phd_migration_pack_async(h))
         bpp = C.c_int64(0)
