@@ -9,7 +9,7 @@ from .abi import PhdParams
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO_PATH = os.path.join(CSRC, "libphdhip.so")
-SOURCES = ["phdhip.hip", "phd_kernels.h", "phd_correct.h", "phd_prune.h", "phd_alpha.h", "phd_resample.h", "phd_device.h"]
+SOURCES = ["phdhip.hip", "phd_kernels.h", "phd_correct.h", "phd_sweep.h", "phd_prune.h", "phd_alpha.h", "phd_resample.h", "phd_device.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 
 dp = C.POINTER(C.c_double)
@@ -27,7 +27,28 @@ def build(force=False):
     return SO_PATH
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm brings its own libamdhip64 (no SONAME, loaded with global scope); libphdhip.so asks for the system's
+    libamdhip64.so.7. If the system one initialises first, a later `import torch` finds no GPU ("No HIP GPUs are
+    available": two HIP runtimes in one process). Loading PyTorch's runtime first, with global scope, makes libphdhip's
+    HIP symbols resolve to it — the arrangement every run has when torch is imported first — whatever the import order.
+    Hosts without PyTorch (the C++ and C# ones) are not concerned."""
+    if os.environ.get("PHD_SYSTEM_HIP"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        rt = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(rt):
+            C.CDLL(rt, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass   # no PyTorch, or it cannot be located: the system runtime it is
+
+
 def load():
+    _share_torch_hip_runtime()
     if not os.path.exists(SO_PATH):
         raise ImportError("libphdhip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback for the PHD path)")

@@ -105,15 +105,28 @@ __device__ __forceinline__ void rotate_roles(const StepBufs& a, const int* src, 
 		sel_next[SEL_RESMIX] = O;
 	}
 	const Bank bo = bank_of(a, SEL_OUT), bt = bank_of(a, SEL_TMP);
-	for (int i = tid; i < a.P; i += 1024) {
-		const int s = resampled ? src[i] : i;
+	// two particles per thread and trip, their loads issued together: this tail is two dependent round trips to memory
+	// per trip in a single workgroup, nothing else
+	for (int i0 = tid; i0 < a.P; i0 += 2048) {
+		const int i1 = i0 + 1024;
+		const bool v1 = i1 < a.P;
+		const int s0 = resampled ? src[i0] : i0, s1 = (resampled && v1) ? src[i1] : i1;
 		if (resampled) {
-			bt.count[i]   = bo.count[s];
-			bt.weights[i] = bo.weights[i];
+			const int c0 = bo.count[s0], c1 = v1 ? bo.count[s1] : 0;
+			const double w0 = bo.weights[i0], w1 = v1 ? bo.weights[i1] : 0.0;
+			double q0[7], q1[7];
 #pragma unroll
-			for (int t = 0; t < 7; t++) bt.poses[(size_t) i * 7 + t] = bo.poses[(size_t) s * 7 + t];
+			for (int t = 0; t < 7; t++) { q0[t] = bo.poses[(size_t) s0 * 7 + t]; q1[t] = v1 ? bo.poses[(size_t) s1 * 7 + t] : 0.0; }
+			bt.count[i0] = c0; bt.weights[i0] = w0;
+#pragma unroll
+			for (int t = 0; t < 7; t++) bt.poses[(size_t) i0 * 7 + t] = q0[t];
+			if (v1) {
+				bt.count[i1] = c1; bt.weights[i1] = w1;
+#pragma unroll
+				for (int t = 0; t < 7; t++) bt.poses[(size_t) i1 * 7 + t] = q1[t];
+			}
 		}
-		if (!frozen) inslot[i] = s;
+		if (!frozen) { inslot[i0] = s0; if (v1) inslot[i1] = s1; }
 	}
 }
 
