@@ -120,7 +120,9 @@ int phd_set_poses(phd_navigator* nav, const double* poses7, int nparticles);
  * Replaces the per-frame phd_set_poses upload.                                                   */
 int phd_update_motion(phd_navigator* nav, const double* odometry6, const double* noise6, int nparticles,
                       uint8_t perfect_still);
-/* Test/bench access to the public arrays VehicleWeights / MapModels (PHDNavigator.cs:128,134).   */
+/* Test/bench access to the public arrays VehicleWeights / MapModels (PHDNavigator.cs:128,134). A resampling step
+ * leaves the copies of a particle sharing their source's map (the deep copies of :740-741 are an index on the device):
+ * phd_set_map therefore first gathers every map into its own place, one pass over the state (phd_map does not).   */
 int phd_set_weights(phd_navigator* nav, const double* weights, int nparticles);
 int phd_set_map(phd_navigator* nav, int particle, const double* w, const double* mean3,
                 const double* cov9, int ncomp);
@@ -247,7 +249,8 @@ int phd_last_timing_counts(phd_navigator* nav, const int** counts);
 
 /* Bulk upload / download of the whole particle set in the device layout (benchmark and tests):
  * planes[10][nparticles][stride] = w, mean x y z, covariance xx xy xz yy yz zz; counts[nparticles];
- * poses7[nparticles][7]; weights[nparticles]. The upload sets the particle count.               */
+ * poses7[nparticles][7]; weights[nparticles]. The upload sets the particle count; the download gathers the maps of a
+ * resampled state into place first (see phd_set_map).                                           */
 int phd_upload_state_soa(phd_navigator* nav, int nparticles, int stride, const double* planes,
                          const int32_t* counts, const double* poses7, const double* weights);
 int phd_download_state_soa(phd_navigator* nav, int stride, double* planes, int32_t* counts,
