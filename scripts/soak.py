@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak: long randomized SlamUpdate sequences, device against the oracle at every step (GPU box only).
-    python scripts/soak.py [sequences] [steps]
+    python scripts/soak.py [sequences] [steps] [first sequence number]
 Every sequence draws its own sizes, pose motion, measurement noise and resampling numbers; the maps evolve (births,
 merges, cuts), so the device meets states no fixed fixture has. Stops at the first disagreement."""
 import os
@@ -73,4 +73,5 @@ def one_sequence(seq, nsteps, log):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     k = int(sys.argv[2]) if len(sys.argv) > 2 else 15
-    print("soak ok, worst particle-weight deviation %.3g" % run(n, k))
+    first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    print("soak ok, worst particle-weight deviation %.3g" % run(n, k, first))
