@@ -58,6 +58,20 @@ int main(int argc, char** argv)
 		std::printf("roundtrip");
 		for (double x : d) std::printf(" %.17g", x);
 		std::printf("\n");
+		monorfs::Matrix6 cov = monorfs::LogLikeFitCovariance(nav, starts[0], z, lm, lin, 1);
+		std::printf("covariance");
+		for (double x : cov) std::printf(" %.17g", x);
+		std::printf("\n");
+		monorfs::Map model;
+		for (auto& l : lm) model.push_back(monorfs::Gaussian{1.0001, l, {1e-4, 0, 0, 0, 1e-4, 0, 0, 0, 1e-4}});
+		double emptyspace = 0;
+		std::vector<monorfs::PoseComponent> mix = monorfs::GuidedFitMixture(nav, prm.measurer[0], starts[0], z, model, lin, 256, &emptyspace, 1);
+		std::printf("emptyspace %.17g\n", emptyspace);
+		for (auto& c : mix) {
+			std::printf("mixture %.17g", c.weight);
+			for (double x : c.mean) std::printf(" %.17g", x);
+			std::printf("\n");
+		}
 		monorfs::Map map = monorfs::FilterMissing(nav, trajectory, factors, 1, T);
 		for (auto& c : map) {
 			std::printf("component %.17g", c.weight);

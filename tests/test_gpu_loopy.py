@@ -117,6 +117,18 @@ def test_cpp_mirror_matches_python(nav, tmp_path):
         assert np.allclose(grad, nav.LogLikeGradient(starts[0], z, lm, lin), rtol=1e-6, atol=1e-3)
         rt = np.array([float(v) for row in rows if row[0] == "roundtrip" for v in row[1:]])
         assert np.allclose(rt, starts[0], atol=1e-12)
+        if mode == 1:   # the covariance fit and the guided mixture (printed for average_mode 1)
+            cov = np.array([float(v) for row in rows if row[0] == "covariance" for v in row[1:]]).reshape(6, 6)
+            wcov = loopy.LogLikeFitCovariance(nav, starts[0], z, lm, lin, 1)
+            assert np.allclose(cov, wcov, rtol=1e-6, atol=1e-12 * np.abs(wcov).max()), np.max(np.abs(cov - wcov))
+            model = (np.full(len(lm), 1.0001), lm, np.broadcast_to(1e-4 * np.eye(3), (len(lm), 3, 3)))
+            wempty, wmix = loopy.GuidedFitMixture(nav, starts[0], z, model, lin, 1)
+            empty = [float(row[1]) for row in rows if row[0] == "emptyspace"][0]
+            mix = np.array([[float(v) for v in row[1:]] for row in rows if row[0] == "mixture"])
+            assert np.isclose(empty, wempty, rtol=1e-12)
+            assert len(mix) == len(wmix) >= 1
+            for got, (ww, wm, _) in zip(mix, wmix):
+                assert np.allclose(got[1:], wm, atol=1e-12) and np.isclose(got[0], ww, rtol=1e-5)
         comp = np.array([[float(v) for v in row[1:]] for row in rows if row[0] == "component"])
         w, m, c = loopy.FilterMissing(nav, trajectory, factors, 1, T)
         assert len(comp) == len(w) > 0
