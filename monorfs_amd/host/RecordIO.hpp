@@ -12,6 +12,9 @@
 #pragma once
 #include "PHDNavigator.hpp"
 
+#include <algorithm>
+#include <cctype>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -307,6 +310,179 @@ inline std::string SerializeTrajectories(const TimedTrajectory& t)
 		if (i) s += "\n|\n";
 		s += G6(t[i].first) + "\n" + SerializeTimedArray(t[i].second);
 	}
+	return s;
+}
+
+// ---- Config (mono-rfs-lib/Config.cs): `FieldName: value` lines, matrices in Octave syntax ---------------------------------
+// The fields the PHD path reads are typed; every other field of the reference's Config travels as text, so that a
+// configuration read from a record is written back whole.
+struct Config {
+	std::string Model = "PRM3D";
+	std::vector<std::vector<double>> MotionCovariance = {{5e-3, 0, 0, 0, 0, 0}, {0, 5e-3, 0, 0, 0, 0}, {0, 0, 5e-3, 0, 0, 0},
+	                                                     {0, 0, 0, 2e-4, 0, 0}, {0, 0, 0, 0, 2e-4, 0}, {0, 0, 0, 0, 0, 2e-4}};
+	std::vector<std::vector<double>> MeasurementCovariance = {{2.0, 0, 0}, {0, 2.0, 0}, {0, 0, 1e-3}};   // SetPRM3DDefaults, :238-263
+	std::vector<std::vector<double>> BirthCovariance = {{1e-2, 0, 0}, {0, 1e-2, 0}, {0, 0, 1e-2}};
+	std::vector<double> VisibilityRamp = {3 * std::sqrt(2.0), 3 * std::sqrt(2.0), 3 * std::sqrt(1e-3)};
+	double DetectionProbability = 0.9, ClutterDensity = 3e-7, DensityDistanceThreshold = 0.5;
+	double BirthWeight = 0.05, MinWeight = 1e-3, MinEffectiveParticle = 0.1, MergeThreshold = 0.3, ExplorationThreshold = 1e-5;
+	double MotionCovarianceMultiplier = 1.0, MeasurementCovarianceMultiplier = 1.0, NavigatorPD = 0.9, NavigatorClutterDensity = 3e-7;
+	double GradientAscentRate = 1e-2, GradientClip = 10;
+	int    MaxQuantity = 600;
+	bool   PerfectStill = false;
+	std::vector<std::pair<std::string, std::string>> Others;   // fields outside the path (NParallel, MapClip, ...), verbatim
+};
+
+inline std::string Trim(const std::string& s)
+{
+	size_t a = s.find_first_not_of(" \t\r"), b = s.find_last_not_of(" \t\r");
+	return a == std::string::npos ? "" : s.substr(a, b - a + 1);
+}
+
+// `[a b; c d]` (Accord's OctaveMatrixFormatProvider, the syntax Config.FromDescriptor hands to Matrix.ParseJagged)
+inline std::vector<std::vector<double>> ParseOctaveMatrix(const std::string& text)
+{
+	std::string t = Trim(text);
+	if (!t.empty() && t.front() == '[') t = t.substr(1);
+	if (!t.empty() && t.back() == ']') t.pop_back();
+	std::vector<std::vector<double>> rows;
+	for (const std::string& row : Split(t, ";", false)) {
+		if (Trim(row).empty()) continue;
+		std::vector<double> r;
+		std::string clean = row;
+		for (char& c : clean) if (c == ',') c = ' ';
+		for (const std::string& v : Split(clean, " ", true)) r.push_back(ParseDouble(Trim(v), "the matrix descriptor '" + text + "' is malformed"));
+		rows.push_back(r);
+	}
+	return rows;
+}
+
+// Config.FromDescriptor (Config.cs:155-209): unknown fields are ignored by the reference (kept in Others here), a missing
+// parameter is left as it is, a line without a colon is reported (skipped lines land in `skipped`) and skipped
+inline void ConfigFromDescriptor(const std::vector<std::string>& lines, Config& c, std::vector<std::string>* skipped = nullptr)
+{
+	for (const std::string& line : lines) {
+		size_t colon = line.find(':');
+		if (colon == std::string::npos) {
+			if (skipped) skipped->push_back(line);
+			continue;
+		}
+		const std::string name = Trim(line.substr(0, colon)), value = Trim(line.substr(colon + 1));
+		auto num = [&]() { return ParseDouble(value, "Input string was not in a correct format."); };
+		auto boolean = [&]() {
+			std::string v = value;
+			for (char& ch : v) ch = (char) std::tolower((unsigned char) ch);
+			if (v != "true" && v != "false") throw FormatError("String was not recognized as a valid Boolean.");
+			return v == "true";
+		};
+		if      (name == "Model") c.Model = value;
+		else if (name == "MotionCovariance") c.MotionCovariance = ParseOctaveMatrix(value);
+		else if (name == "MeasurementCovariance") c.MeasurementCovariance = ParseOctaveMatrix(value);
+		else if (name == "BirthCovariance") c.BirthCovariance = ParseOctaveMatrix(value);
+		else if (name == "VisibilityRamp") c.VisibilityRamp = ParseOctaveMatrix(value).at(0);
+		else if (name == "DetectionProbability") c.DetectionProbability = num();
+		else if (name == "ClutterDensity") c.ClutterDensity = num();
+		else if (name == "DensityDistanceThreshold") c.DensityDistanceThreshold = num();
+		else if (name == "BirthWeight") c.BirthWeight = num();
+		else if (name == "MinWeight") c.MinWeight = num();
+		else if (name == "MinEffectiveParticle") c.MinEffectiveParticle = num();
+		else if (name == "MergeThreshold") c.MergeThreshold = num();
+		else if (name == "ExplorationThreshold") c.ExplorationThreshold = num();
+		else if (name == "MotionCovarianceMultiplier") c.MotionCovarianceMultiplier = num();
+		else if (name == "MeasurementCovarianceMultiplier") c.MeasurementCovarianceMultiplier = num();
+		else if (name == "NavigatorPD") c.NavigatorPD = num();
+		else if (name == "NavigatorClutterDensity") c.NavigatorClutterDensity = num();
+		else if (name == "GradientAscentRate") c.GradientAscentRate = num();
+		else if (name == "GradientClip") c.GradientClip = num();
+		else if (name == "MaxQuantity") {
+			char* end = nullptr;
+			long v = std::strtol(value.c_str(), &end, 10);
+			if (value.empty() || *end) throw FormatError("Input string was not in a correct format.");
+			c.MaxQuantity = (int) v;
+		}
+		else if (name == "PerfectStill") c.PerfectStill = boolean();
+		else {
+			bool found = false;
+			for (auto& o : c.Others) if (o.first == name) { o.second = value; found = true; }
+			if (!found) c.Others.emplace_back(name, value);
+		}
+	}
+}
+
+// double.ToString(): "3E-07" where printf writes "3e-07"
+inline std::string NetDouble(double x)
+{
+	std::string s = G15(x);
+	for (char& ch : s) if (ch == 'e') ch = 'E';
+	return s;
+}
+
+inline std::string OctaveMatrix(const std::vector<std::vector<double>>& m)
+{
+	std::string s = "[";
+	for (size_t i = 0; i < m.size(); i++) {
+		if (i) s += "; ";
+		for (size_t k = 0; k < m[i].size(); k++) s += (k ? " " : "") + NetDouble(m[i][k]);
+	}
+	return s + "]";
+}
+
+// Config.ToString (Config.cs:268-309) for the typed fields, then the others as they came
+inline std::string SerializeConfig(const Config& c)
+{
+	std::string s;
+	auto line = [&](const std::string& name, const std::string& value) { s += (s.empty() ? "" : "\n") + name + ": " + value; };
+	line("Model", c.Model);
+	line("MotionCovariance", OctaveMatrix(c.MotionCovariance));
+	line("MeasurementCovariance", OctaveMatrix(c.MeasurementCovariance));
+	line("DetectionProbability", NetDouble(c.DetectionProbability));
+	line("ClutterDensity", NetDouble(c.ClutterDensity));
+	line("PerfectStill", c.PerfectStill ? "True" : "False");
+	line("VisibilityRamp", OctaveMatrix({c.VisibilityRamp}));
+	line("DensityDistanceThreshold", NetDouble(c.DensityDistanceThreshold));
+	line("BirthCovariance", OctaveMatrix(c.BirthCovariance));
+	line("BirthWeight", NetDouble(c.BirthWeight));
+	line("MinWeight", NetDouble(c.MinWeight));
+	line("MinEffectiveParticle", NetDouble(c.MinEffectiveParticle));
+	line("MaxQuantity", std::to_string(c.MaxQuantity));
+	line("MergeThreshold", NetDouble(c.MergeThreshold));
+	line("ExplorationThreshold", NetDouble(c.ExplorationThreshold));
+	line("MotionCovarianceMultiplier", NetDouble(c.MotionCovarianceMultiplier));
+	line("MeasurementCovarianceMultiplier", NetDouble(c.MeasurementCovarianceMultiplier));
+	line("NavigatorPD", NetDouble(c.NavigatorPD));
+	line("NavigatorClutterDensity", NetDouble(c.NavigatorClutterDensity));
+	line("GradientAscentRate", NetDouble(c.GradientAscentRate));
+	line("GradientClip", NetDouble(c.GradientClip));
+	for (const auto& o : c.Others) line(o.first, o.second);
+	return s;
+}
+
+// The values PHDNavigator reads from Config as the parameter block of libphdhip: its particles are clones of the
+// reference vehicle with MeasurementCovarianceMultiplier, NavigatorPD and NavigatorClutterDensity (PHDNavigator.cs:257-259)
+inline phd_params PhdParamsFromConfig(const Config& c, int maxparticles, int maxcomponents, int maxmeasurements)
+{
+	if (c.Model != "PRM3D") throw FormatError("libphdhip implements the PRM3D model");
+	if (c.MeasurementCovariance.size() != 3 || c.BirthCovariance.size() != 3 || c.VisibilityRamp.size() < 3) throw FormatError("the PRM3D model needs 3 x 3 covariances and a visibility ramp of 3");
+	phd_params p;
+	phd_default_params(&p, maxparticles, std::max(maxcomponents, c.MaxQuantity), maxmeasurements);
+	for (int i = 0; i < 3; i++) {
+		for (int k = 0; k < 3; k++) {
+			p.R[i * 3 + k] = c.MeasurementCovarianceMultiplier * c.MeasurementCovariance[i].at(k);
+			p.birth_covariance[i * 3 + k] = c.BirthCovariance[i].at(k);
+		}
+		p.visibility_ramp[i] = c.VisibilityRamp[i];
+	}
+	p.pd = c.NavigatorPD; p.clutter_density = c.NavigatorClutterDensity;
+	p.birth_weight = c.BirthWeight; p.min_weight = c.MinWeight; p.min_effective_particle = c.MinEffectiveParticle;
+	p.max_quantity = c.MaxQuantity; p.merge_threshold = c.MergeThreshold; p.exploration_threshold = c.ExplorationThreshold;
+	p.density_distance_threshold = c.DensityDistanceThreshold;
+	return p;
+}
+
+// Manipulator.SerializedTags (Manipulator.cs:294-304)
+inline std::string SerializeTags(const TimedMessage& tags)
+{
+	std::string s;
+	for (size_t i = 0; i < tags.size(); i++) s += (i ? "\n" : "") + G6(tags[i].first) + " " + tags[i].second;
 	return s;
 }
 

@@ -19,7 +19,6 @@ sys.path.insert(0, ROOT)
 from monorfs_amd import recordio as rio
 from monorfs_amd.abi import prm3d_defaults
 
-MOTION_COV = np.diag([5e-3, 5e-3, 5e-3, 2e-4, 2e-4, 2e-4])   # Config.SetPRM3DDefaults (Config.cs:244-249)
 
 
 def frames_of(rec):
@@ -29,9 +28,14 @@ def frames_of(rec):
     return [(t, reading, zt.get(round(t, 9), np.zeros((0, 3)))) for t, reading in odo]
 
 
+def config_of(rec):
+    """the record's config.cfg over the defaults (Config.FromRecordFile, Config.cs:127-148), or the defaults"""
+    return rio.config_from_descriptor(rec["config.cfg"].splitlines()) if "config.cfg" in rec else rio.default_config()
+
+
 def params_of(rec, particles, maxm):
     pose, measurer, _ = rio.scene_from_descriptor(rec["scene.world"])
-    p = prm3d_defaults(max_particles=particles, max_components=600, max_measurements=max(maxm, 1))
+    p = rio.phd_params_from_config(config_of(rec), max_particles=particles, max_components=600, max_measurements=max(maxm, 1))
     if measurer is not None:
         p.measurer[:] = [measurer[0], float(np.float32(measurer[1])), float(np.float32(measurer[2]))] + list(measurer[3:7])
     return p, pose
@@ -72,7 +76,8 @@ def replay(rec, particles, seed, solver_cls):
     p, pose = params_of(rec, particles, max(len(z) for _, _, z in frames))
     solver = solver_cls(p, pose, particles)
     rng = np.random.default_rng(seed)
-    chol = np.linalg.cholesky(MOTION_COV)
+    cfg = config_of(rec)
+    chol = np.linalg.cholesky(cfg["MotionCovarianceMultiplier"] * np.array(cfg["MotionCovariance"], float))   # PHDNavigator.cs:257-259
     trajectory, estimate, maps = [], [], []
     tprev = frames[0][0]
     for t, reading, z in frames:
@@ -118,7 +123,7 @@ def make_synthetic_record(path, frames=12, landmarks=14, seed=3):
         traj.append((t, pose))
     rio.write_record(path, {"scene.world": scene, "odometry.out": rio.serialize_timed_array(odo),
                             "measurements.out": rio.serialize_measurements(meas), "trajectory.out": rio.serialize_timed_array(traj),
-                            "tags.out": "0 SLAM mode on"})
+                            "tags.out": "0 SLAM mode on", "config.cfg": rio.serialize_config(rio.default_config())})
     return path
 
 

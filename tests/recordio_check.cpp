@@ -74,6 +74,30 @@ int main(int argc, char** argv)
 	CHECK(cmd[0].size() == 6 && cmd[1][6] == 1 && cmd[2].size() == 11);
 
 	CHECK(G6(1234567.0) == "1.23457e+06" && G6(0.000012345678) == "1.23457e-05" && G6(0.5) == "0.5" && G6(100000.0) == "100000");
+	// Config (Config.cs:155-209, 268-309) and the parameter block built from it
+	{
+		Config cfg;
+		std::vector<std::string> skipped;
+		ConfigFromDescriptor(Split(slurp(dir + "/config.cfg"), "\n", true), cfg, &skipped);
+		CHECK(skipped.size() == 1 && skipped[0] == "this line has no colon and is skipped");
+		CHECK(cfg.MaxQuantity == 250 && cfg.MinEffectiveParticle == 0.3 && cfg.ClutterDensity == 3e-7 && cfg.NavigatorPD == 0.85);
+		CHECK(cfg.MeasurementCovariance[2][2] == 0.002 && cfg.MotionCovariance[5][5] == 0.0002 && cfg.BirthCovariance[1][1] == 1e-2);
+		CHECK(cfg.GradientClip == 10 && !cfg.PerfectStill);
+		bool future = false;
+		for (auto& o : cfg.Others) future = future || (o.first == "SomeFutureField" && o.second == "17");
+		CHECK(future);
+		std::string text = SerializeConfig(cfg);
+		CHECK(text.find("MeasurementCovariance: [2.5 0 0; 0 2.5 0; 0 0 0.002]") != std::string::npos);
+		CHECK(text.find("ClutterDensity: 3E-07") != std::string::npos && text.find("PerfectStill: False") != std::string::npos);
+		Config again;
+		ConfigFromDescriptor(Split(text, "\n", true), again);
+		CHECK(SerializeConfig(again) == text);
+		phd_params p = PhdParamsFromConfig(cfg, 8, 600, 16);
+		CHECK(p.R[0] == 5.0 && p.R[8] == 0.004 && p.pd == 0.85 && p.clutter_density == 6e-7 && p.max_quantity == 250);
+		CHECK(p.merge_threshold == 0.5 && p.min_weight == 0.002 && p.birth_weight == 0.04 && p.max_components >= 600);
+		CHECK(error_of([&] { Config bad; ConfigFromDescriptor({"MaxQuantity: many"}, bad); }) == "Input string was not in a correct format.");
+		CHECK(SerializeTags(tags) == slurp(dir + "/tags.out"));
+	}
 	std::printf("recordio ok\n");
 	return 0;
 }

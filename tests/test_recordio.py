@@ -13,9 +13,12 @@ REC = os.path.join(ROOT, "tests", "golden", "record")
 
 
 def test_cpp_header_parses_and_rewrites_the_record(tmp_path):
+    from monorfs_amd import _lib
+    so = _lib.build()   # PhdParamsFromConfig starts from phd_default_params (host code of the library; no GPU needed)
     exe = str(tmp_path / "recordio_check")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), "-o", exe,
-                           os.path.join(ROOT, "tests", "recordio_check.cpp")])
+                           os.path.join(ROOT, "tests", "recordio_check.cpp"), so, "-Wl,-rpath," + os.path.dirname(so),
+                           "-Wl,-rpath,/opt/rocm/lib"])
     r = subprocess.run([exe, REC], capture_output=True, text=True)
     assert r.returncode == 0 and "recordio ok" in r.stdout, r.stdout + r.stderr
 
@@ -70,3 +73,37 @@ def test_replay_of_a_record_matches_the_oracle(tmp_path):
     assert len(dmaps[-1][1][0]) >= 5                                  # the landmarks in view ended up in the map
     lines = list(zip(dev["maps.out"].split("\n"), ref["maps.out"].split("\n")))
     assert sum(x == y for x, y in lines) >= 0.98 * len(lines)
+
+
+def test_config_commands_and_tags():
+    """Config.FromDescriptor / ToString (Config.cs:155-209, 268-309), FileParser.CommandsFromDescriptor (:263-274),
+    TimedMessageFromDescriptor (:237-256) / Manipulator.SerializedTags, and the parameter block a PHDNavigator built
+    from that configuration reads (PHDNavigator.cs:257-259)."""
+    rec = rio.read_record(REC)
+    skipped = []
+    cfg = rio.config_from_descriptor(rec["config.cfg"].splitlines(), log=skipped.append)   # File.ReadAllLines
+    assert len(skipped) == 1 and "no colon" in skipped[0]                     # reported, then ignored (:162-165)
+    assert "SomeFutureField" not in cfg                                       # no such field: ignored
+    assert cfg["NParallel"] == 4 and cfg["MaxQuantity"] == 250 and cfg["MinEffectiveParticle"] == 0.3
+    assert cfg["MeasurementCovariance"] == [[2.5, 0, 0], [0, 2.5, 0], [0, 0, 0.002]] and cfg["ClutterDensity"] == 3e-7
+    assert cfg["GradientClip"] == 10.0 and cfg["BirthCovariance"][1][1] == 1e-2   # missing parameters are left as they were
+    assert cfg["MeasureElapsed"] == 0.0333333                                 # whole ticks of 100 ns
+    text = rio.serialize_config(cfg)
+    assert rio.serialize_config(rio.config_from_descriptor(text.split("\n"))) == text
+    assert "MeasurementCovariance: [2.5 0 0; 0 2.5 0; 0 0 0.002]" in text and "ClutterDensity: 3E-07" in text and "PerfectStill: False" in text
+    p = rio.phd_params_from_config(cfg, max_particles=8)
+    assert list(p.R) == [5.0, 0, 0, 0, 5.0, 0, 0, 0, 0.004]                  # MeasurementCovarianceMultiplier (PHDNavigator.cs:257-259)
+    assert p.pd == 0.85 and p.clutter_density == 6e-7 and p.max_quantity == 250 and p.merge_threshold == 0.5
+    assert p.min_weight == 0.002 and p.birth_weight == 0.04 and abs(p.visibility_ramp[2] - 0.134164078649987) < 1e-15
+    with pytest.raises(rio.FormatError):
+        rio.config_from_descriptor(["MaxQuantity: many"])
+    with pytest.raises(rio.FormatError):
+        rio.phd_params_from_config(dict(cfg, Model="Linear2D"))
+    cmds = rio.commands_from_descriptor(["0.01 0 0 0 0 0.002", "0 0 0 0 0 0 1", "0.02 0 0 0 0 0 -1 1 0.5 0.25 2"])
+    assert [len(c) for c in cmds] == [6, 7, 11] and cmds[2][6] == -1
+    with pytest.raises(rio.FormatError, match="the double descriptor '0.1 x' is malformed"):
+        rio.commands_from_descriptor(["0.1 x"])
+    tags = rio.timed_message_from_descriptor(rec["tags.out"].split("\n"))
+    assert rio.serialize_tags(tags) == rec["tags.out"] and all(isinstance(t, float) for t, _ in tags)
+    with pytest.raises(rio.FormatError, match="the TimedMessage descriptor 'soon SLAM mode on' is malformed"):
+        rio.timed_message_from_descriptor(["soon SLAM mode on"])
