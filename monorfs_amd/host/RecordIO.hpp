@@ -290,6 +290,21 @@ inline std::string SerializeMeasurements(const TimedMeasurements& m)
 	return s;
 }
 
+// Vehicle.ToString("g6") (Vehicle.cs:513-524): the scene file (scene.world of a record, `-f=` of the command line)
+inline std::string SerializeScene(const Scene& scene)
+{
+	std::string s = "pose\n\t";
+	for (size_t i = 0; i < scene.pose.size(); i++) s += (i ? " " : "") + G6(scene.pose[i]);
+	s += "\nparams\n\t";
+	for (size_t i = 0; i < scene.params.size(); i++) s += (i ? " " : "") + G6(scene.params[i]);
+	s += "\nlandmarks\n\t";
+	for (size_t l = 0; l < scene.landmarks.size(); l++) {
+		if (l) s += "\n\t";
+		for (size_t i = 0; i < scene.landmarks[l].size(); i++) s += (i ? " " : "") + G6(scene.landmarks[l][i]);
+	}
+	return s + "\n";
+}
+
 // Simulation.SerializedMaps (:199-206)
 inline std::string SerializeMaps(const TimedMapModel& maps)
 {

@@ -141,6 +141,11 @@ def gaussian_to_string(w, mean, cov):                    # Gaussian.cs:391-431
     return g6(w) + ";" + " ".join(g6(v) for v in mean) + ";" + " ".join(g6(v) for v in np.asarray(cov).reshape(-1))
 
 
+def serialize_scene(pose, params, landmarks):            # Vehicle.ToString("g6"), Vehicle.cs:513-524 (scene.world, -f=)
+    return ("pose\n\t" + " ".join(g6(v) for v in pose) + "\nparams\n\t" + " ".join(g6(v) for v in params) +
+            "\nlandmarks\n\t" + "\n\t".join(" ".join(g6(v) for v in l) for l in landmarks) + "\n")
+
+
 def serialize_timed_array(a):                            # Simulation.cs:155-166, 225-231
     return "\n".join(g6(t) + "".join(" " + g6(v) for v in vec) for t, vec in a)
 

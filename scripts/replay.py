@@ -102,8 +102,7 @@ def make_synthetic_record(path, frames=12, landmarks=14, seed=3):
     pose = np.array([0, 0, 0, 1.0, 0, 0, 0])
     zs = np.column_stack([rng.uniform(-260, 260, landmarks), rng.uniform(-190, 190, landmarks), rng.uniform(0.5, 1.6, landmarks)])
     lm = np.array([orc.measure_to_map(p, pose, z) for z in zs])
-    scene = "pose\n\t" + " ".join(rio.g6(v) for v in pose) + "\nparams\n\t" + " ".join(rio.g6(v) for v in p.measurer) + \
-            "\nlandmarks\n" + "".join("\t" + " ".join(rio.g6(v) for v in x) + "\n" for x in lm)
+    scene = rio.serialize_scene(pose, p.measurer, lm)
     _, _, lm = rio.scene_from_descriptor(scene)                     # what a reader of the file sees
     odo, meas, traj = [], [], []
     R = np.array(p.R).reshape(3, 3)

@@ -33,6 +33,7 @@ int main(int argc, char** argv)
 	Scene scene = SceneFromDescriptor(slurp(dir + "/scene.world"));
 	CHECK(scene.pose[0] == 0.1 && scene.pose[3] == 1 && scene.hasparams && scene.params[0] == 575.816 && scene.params[6] == 480);
 	CHECK(scene.landmarks.size() == 3 && scene.landmarks[2][1] == -0.4);
+	CHECK(SerializeScene(scene) == slurp(dir + "/scene.world"));
 	CHECK(SceneFromDescriptor("pose\n\t0 0 0 1 0 0 0\nfocal\n\t500 0.1 2 -320 -240 640 480\nlandmarks\n").params[0] == 500);   // deprecated alias
 	CHECK(error_of([] { SceneFromDescriptor("pose\n\t0 0 0 1 0 0 0\nlandmarks\n\t1 2\n"); }) == "Map landmarks must be 3D");
 	CHECK(ParseDictionary("\tchild first\nkey\n").empty());   // can't start with a child node (Util.cs:243-246)

@@ -27,6 +27,7 @@ def test_python_mirror_round_trips_every_member(tmp_path):
     rec = rio.read_record(REC)
     pose, params, lm = rio.scene_from_descriptor(rec["scene.world"])
     assert pose[0] == 0.1 and params[0] == 575.816 and lm.shape == (3, 3) and lm[2, 1] == -0.4
+    assert rio.serialize_scene(pose, params, lm) == rec["scene.world"]                    # Vehicle.ToString("g6")
     odo = rio.timed_array_from_descriptor(rec["odometry.out"].split("\n"), 6)
     assert odo[2][1][5] == -1.25e-05 and rio.serialize_timed_array(odo) == rec["odometry.out"]
     z = rio.measurements_from_descriptor(rec["measurements.out"], 3)
