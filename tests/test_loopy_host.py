@@ -122,3 +122,18 @@ def test_fit_covariance_and_guided_mixture():
         for k in range(i):
             d = comps[k][1] - comps[i][1]
             assert np.sqrt(d @ np.linalg.pinv(comps[k][2]) @ d) >= 0.1
+
+
+def test_pose3d_odometry_against_the_oracle():
+    """monorfs_amd/pose3d.py (used by scripts/simulate.py): Pose3D.AddOdometry / DiffOdometry (Pose3D.cs:314-356) against
+    the oracle's restatement and Pose3DTest's round trip"""
+    from monorfs_amd.pose3d import add_odometry, diff_odometry
+    rng = np.random.default_rng(12)
+    for _ in range(20):
+        a = np.concatenate([rng.normal(0, 1, 3), rng.normal(0, 1, 4)])
+        a[3:] /= np.linalg.norm(a[3:])
+        d = rng.normal(0, 0.3, 6)
+        b = add_odometry(a, d)
+        assert np.allclose(b, orc.add_odometry(a, d), atol=1e-14)
+        assert np.allclose(diff_odometry(b, a), orc.diff_odometry(b, a), atol=1e-13)
+        assert np.allclose(diff_odometry(b, a), d, atol=1e-12)

@@ -2,11 +2,13 @@
 (tests/recordio_check.cpp), the Python mirror against the same hand-written members of tests/golden/record/."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
 
 from monorfs_amd import recordio as rio
+from monorfs_amd.abi import prm3d_defaults
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REC = os.path.join(ROOT, "tests", "golden", "record")
@@ -108,3 +110,43 @@ def test_config_commands_and_tags():
     assert rio.serialize_tags(tags) == rec["tags.out"] and all(isinstance(t, float) for t, _ in tags)
     with pytest.raises(rio.FormatError, match="the TimedMessage descriptor 'soon SLAM mode on' is malformed"):
         rio.timed_message_from_descriptor(["soon SLAM mode on"])
+
+
+@pytest.mark.gpu
+def test_simulation_loop_writes_a_replayable_record(tmp_path):
+    """scripts/simulate.py: the reference's headless simulation loop (Simulation.Update) around the HIP solver. A vehicle
+    drifts past 12 landmarks for 40 frames; the record it writes parses member by member, the map it ends with holds the
+    landmarks it saw, each once (OSPA against them: no cardinality error, 15 cm), and the record replays through scripts/replay.py."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import orc
+    import replay
+    import simulate
+    rng = np.random.default_rng(8)
+    p = prm3d_defaults()
+    pose = np.array([0, 0, 0, 1.0, 0, 0, 0])
+    zs = np.column_stack([rng.uniform(-200, 200, 12), rng.uniform(-150, 150, 12), rng.uniform(0.6, 1.5, 12)])
+    lm = np.array([orc.measure_to_map(p, pose, z) for z in zs])
+    scene = rio.serialize_scene(pose, p.measurer, lm)
+    commands = ["0.002 0 0.003 0 0.001 0" + (" 1" if k == 0 else "") for k in range(40)]
+    cfg = rio.config_from_descriptor(["MinEffectiveParticle: 0.3", "ClutterDensity: 3E-07"])
+    rec = simulate.simulate(scene, commands, cfg, particles=16, seed=4)
+    assert set(rec) == set(rio.MEMBERS)
+    traj = rio.timed_array_from_descriptor(rec["trajectory.out"].split("\n"), 7)
+    odo = rio.timed_array_from_descriptor(rec["odometry.out"].split("\n"), 6)
+    z = rio.measurements_from_descriptor(rec["measurements.out"], 3)
+    maps = rio.map_history_from_descriptor(rec["maps.out"])
+    assert len(traj) == 41 and len(odo) == 40 and len(z) == 40 and len(maps) == 40
+    assert rio.timed_message_from_descriptor(rec["tags.out"].split("\n")) == [(0.0, "SLAM mode on")]
+    assert rio.config_from_descriptor(rec["config.cfg"].splitlines())["MinEffectiveParticle"] == 0.3
+    assert np.allclose(odo[5][1], [0.002, 0, 0.003, 0, 0.001, 0], atol=5e-3)        # the command plus odometry noise
+    w, m, c = maps[-1][1]
+    est, _ = orc.best_map_estimate((w, m, c))
+    def near(pts, zh):   # some measurement within a few sigma of where the landmark should appear
+        return len(pts) > 0 and np.min(np.linalg.norm((pts - zh) / [6.0, 6.0, 0.15], axis=1)) < 1
+    seen = [x for x in lm if any(near(pts, orc.measure_perfect(p, traj[k + 1][1], x)) for k, (_, pts) in enumerate(z))]
+    d, card = orc.ospa(est, np.array(seen))
+    assert len(seen) >= 8 and card == 0 and d < 0.15, (d, card, len(est), len(seen))   # every landmark once; the rest is the drift of a 16-particle SLAM run
+    path = str(tmp_path / "run.zip")
+    rio.write_record(path, rec)
+    out = replay.replay(rio.read_record(path), 16, 5, replay.DeviceSolver)
+    assert len(rio.map_history_from_descriptor(out["maps.out"])) == 40
