@@ -45,8 +45,10 @@ extern "C" {
 #define PHD_ERR_DEVICE            4   /* HIP runtime error, see phd_last_error                       */
 #define PHD_ERR_NO_DEVICE         5   /* no gfx950 device / HIP runtime unavailable                  */
 
-/* dynamics model; only PRM3D runs on the device. LINEAR2D exists so that the unit KATs of
- * PHDNavigatorTest.cs (Linear2D model) can be expressed with the same parameter block.     */
+/* dynamics model. PRM3D is the product. LINEAR2D is the toy model of the reference's unit tests (PHDNavigatorTest.cs):
+ * it runs through the same kernels — a pose is (x, y, 0, 1, 0, 0, 0), a measurement (x, y, 0), still three doubles, R is
+ * 2 x 2 row-major in the first four entries of `R` — so that those tests' vectors can be put to the device itself.
+ * phd_update_motion and phd_quasi_set_loglik* are PRM3D only.                                 */
 #define PHD_MODEL_LINEAR2D 0
 #define PHD_MODEL_PRM3D    1
 

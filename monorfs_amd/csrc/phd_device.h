@@ -44,6 +44,11 @@ struct DevParams {
 	double emit_log_floor;  // log(minw * kappa): no emitted weight can come from below it
 	int    gate_metric;
 	int    maxq;
+	int    linear2d;        // 1: the Linear2D toy model of the reference's unit tests (LinearPose2D, LinearMeasurement2D,
+	                        // Linear2DMeasurer.cs) carried in the three-dimensional machinery: the third measurement
+	                        // coordinate is always 0, its row of H is 0 and R gets a 1 there, so S, its determinant, K and
+	                        // every quadratic form are those of the 2-D model (the multiplier exponent is -1 in both, Gaussian.cs:155)
+	double lin_range;       // Linear2DMeasurer.Range: the visible square [-range, range]^2
 };
 
 #define PHD_INV_2PI 0.15915494309189535   // Math.Pow(2 * Math.PI, -3 / 2) with C# integer division (Gaussian.cs:155)
@@ -97,6 +102,10 @@ __device__ __forceinline__ void conj_matrix(const PoseD& p, double r[9])
 // MeasureToMap (PRM3DMeasurer.cs:299-312)
 __device__ __forceinline__ void measure_to_map(const DevParams& prm, const PoseD& p, const double z[3], double x[3])
 {
+	if (prm.linear2d) {   // Linear2DMeasurer.MeasureToMap (Linear2DMeasurer.cs:181-184)
+		x[0] = p.t[0] + z[0]; x[1] = p.t[1] + z[1]; x[2] = 0.0;
+		return;
+	}
 	double f = prm.focal;
 	double alpha = z[2] / sqrt(f * f + z[0] * z[0] + z[1] * z[1]);
 	double dx = alpha * z[0], dy = alpha * z[1], dz = alpha * f;
@@ -110,6 +119,11 @@ __device__ __forceinline__ void measure_to_map(const DevParams& prm, const PoseD
 __device__ __forceinline__ void measure_perfect(const DevParams& prm, const PoseD& p, const double m[3],
                                                 double zh[3], double l[3])
 {
+	if (prm.linear2d) {   // Linear2DMeasurer.MeasurePerfect (Linear2DMeasurer.cs:110-113)
+		zh[0] = m[0] - p.t[0]; zh[1] = m[1] - p.t[1]; zh[2] = 0.0;
+		l[0] = 0.0; l[1] = 0.0; l[2] = 1.0;
+		return;
+	}
 	double d[3] = {m[0] - p.t[0], m[1] - p.t[1], m[2] - p.t[2]};
 	to_local(p, d, l);
 	double euclid = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
@@ -122,6 +136,13 @@ __device__ __forceinline__ void measure_perfect(const DevParams& prm, const Pose
 // FuzzyVisibleM (PRM3DMeasurer.cs:277-291) * detectionProbability (SimulatedVehicle.cs:335-338)
 __device__ __forceinline__ double detection_probability_m(const DevParams& prm, const double z[3])
 {
+	if (prm.linear2d) {   // Linear2DMeasurer.FuzzyVisibleM (Linear2DMeasurer.cs:151-162)
+		double mind = (z[0] + prm.lin_range) / prm.ramp[0];
+		mind = fmin(mind, (prm.lin_range - z[0]) / prm.ramp[0]);
+		mind = fmin(mind, (z[1] + prm.lin_range) / prm.ramp[1]);
+		mind = fmin(mind, (prm.lin_range - z[1]) / prm.ramp[1]);
+		return fmax(0.0, fmin(1.0, mind)) * prm.pd;
+	}
 	double mind = (z[0] - prm.left) / prm.ramp[0];
 	mind = fmin(mind, (prm.right - z[0]) / prm.ramp[0]);
 	mind = fmin(mind, (z[1] - prm.top) / prm.ramp[1]);
@@ -134,6 +155,10 @@ __device__ __forceinline__ double detection_probability_m(const DevParams& prm, 
 // MeasurementJacobianL (PRM3DMeasurer.cs:157-177): H = Jproj(local) * R(q*)
 __device__ __forceinline__ void jacobian_l(const DevParams& prm, const double l[3], const double rq[9], double H[9])
 {
+	if (prm.linear2d) {   // Linear2DMeasurer.MeasurementJacobianL (Linear2DMeasurer.cs:115-119), a zero third row
+		H[0] = 1; H[1] = 0; H[2] = 0;  H[3] = 0; H[4] = 1; H[5] = 0;  H[6] = 0; H[7] = 0; H[8] = 0;
+		return;
+	}
 	double f = prm.focal;
 	double mag = ((l[2] > 0) ? 1.0 : -1.0) * sqrt(l[0] * l[0] + l[1] * l[1] + l[2] * l[2]);
 	double jp[9] = {f / l[2], 0.0, -f * l[0] / (l[2] * l[2]),

@@ -143,8 +143,16 @@ DevParams make_dev_params(const phd_params& p)
 	d.bottom = (double) ((int) p.measurer[4] + (int) p.measurer[6]);
 	for (int i = 0; i < 3; i++) d.ramp[i] = p.visibility_ramp[i];
 	for (int i = 0; i < 9; i++) d.R[i] = p.R[i];
+	d.linear2d  = p.model == PHD_MODEL_LINEAR2D ? 1 : 0;
+	d.lin_range = p.measurer[0];
+	if (d.linear2d) {   // R is 2 x 2 row-major in the first four entries: pad it with a unit third coordinate (DevParams)
+		const double r2[4] = {p.R[0], p.R[1], p.R[2], p.R[3]};
+		const double r3[9] = {r2[0], r2[1], 0, r2[2], r2[3], 0, 0, 0, 1};
+		for (int i = 0; i < 9; i++) d.R[i] = r3[i];
+		d.ramp[2] = 1.0;
+	}
 	double det;
-	inv3_host(p.R, d.Rinv, &det);
+	inv3_host(d.R, d.Rinv, &det);
 	d.logRmult = std::log(std::pow(2 * 3.14159265358979323846, -1.0) / std::sqrt(std::fabs(det)));
 	d.pd       = p.pd;
 	d.kappa    = p.clutter_density;
@@ -474,8 +482,8 @@ phd_navigator* phd_create(const phd_params* params, int device)
 {
 	g_create_error.clear();
 	if (!params) { g_create_error = "params is NULL"; return nullptr; }
-	if (params->model != PHD_MODEL_PRM3D || params->zdim != 3) {
-		g_create_error = "only the PRM3D model (Pose3D + PixelRangeMeasurement) runs on the device";
+	if (!((params->model == PHD_MODEL_PRM3D && params->zdim == 3) || (params->model == PHD_MODEL_LINEAR2D && params->zdim == 2))) {
+		g_create_error = "model / zdim must be PRM3D / 3 or LINEAR2D / 2";
 		return nullptr;
 	}
 	if (params->max_particles < 1 || params->max_components < 1 || params->max_measurements < 0 ||
@@ -650,6 +658,7 @@ int phd_set_poses(phd_navigator* nav, const double* poses7, int nparticles)
 int phd_update_motion(phd_navigator* nav, const double* odometry6, const double* noise6, int nparticles, uint8_t perfect_still)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->prm.model != PHD_MODEL_PRM3D) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_update_motion: Pose3D odometry, the PRM3D model only");
 	if (!odometry6 || nparticles != nav->P) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_update_motion: particle count mismatch");
 	hipSetDevice(nav->device);
 	bool zero = true;
@@ -670,6 +679,7 @@ static int quasi_batch(phd_navigator* nav, const double* poses7, int nposes, con
                        const double* z3, int nmeasurements, double* out, double* gradients6, int average_mode)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->prm.model != PHD_MODEL_PRM3D) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_quasi_set_loglik: the PRM3D model only");
 	if (nposes < 1 || nposes > nav->Pcap || nlandmarks < 0 || nlandmarks > nav->Jcap || nmeasurements < 0 ||
 	    nmeasurements > nav->prm.max_measurements || !poses7 || !out || (nlandmarks && !landmarks3) || (nmeasurements && !z3)) {
 		return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_quasi_set_loglik: sizes out of range (poses <= max_particles, landmarks <= min(1024, max_quantity), measurements <= max_measurements)");

@@ -1,0 +1,105 @@
+"""The reference's own unit-test vectors (PHDNavigatorTest.cs:85-265, transcribed into tests/golden/phdnavigator_kat.json)
+put to the DEVICE through the C-ABI: the Linear2D toy model of those tests runs through the same kernels as PRM3D
+(include/phdhip.h, PHD_MODEL_LINEAR2D). Matching as in the reference (every expected component found once, 1e-5), plus
+the oracle at the parity tolerances."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import orc
+from monorfs_amd.abi import PHD_GATE_DISABLED, params_from_dict
+from test_oracle_kat import assert_same_set, mix_of
+
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "phdnavigator_kat.json")))
+
+
+def device(params, pose2, model):
+    from monorfs_amd import navigator
+    p = params_from_dict(params, max_particles=1, max_components=600, max_measurements=8)
+    nav = navigator.PHDNavigator(p, particlecount=1, pose=[pose2[0], pose2[1], 0, 1, 0, 0, 0])
+    nav.reset(np.array([pose2[0], pose2[1], 0, 1.0, 0, 0, 0]), model, 1)
+    return nav, p
+
+
+def z3(measurements):
+    z = np.asarray(measurements, float).reshape(-1, 2)
+    return np.column_stack([z, np.zeros(len(z))])
+
+
+@pytest.mark.parametrize("case", ["predict_initial", "predict_known"])
+def test_predict_kats_on_the_device(case):
+    """PHDNavigatorTest.PredictInitial / PredictKnown (:85-126)"""
+    k = KAT[case]
+    nav, p = device(KAT["params"], KAT["pose"], mix_of(k["model"]))
+    nav.run_stages(z3(k["measurements"]), with_alpha=False)
+    got = nav.PredictConditional(0)
+    assert_same_set(got, k["expected"], KAT["tolerance"])
+    want = orc.predict(p, KAT["pose"] + [0.0], k["measurements"], mix_of(k["model"]))
+    assert len(got[0]) == len(want[0]) and np.allclose(got[0], want[0], rtol=1e-12) and np.allclose(got[1], want[1], rtol=1e-12, atol=1e-15)
+    nav.close()
+
+
+def test_correct_kat_on_the_device():
+    """PHDNavigatorTest.Correct (:128-193): all four (measurement, component) pairs, i.e. no radius gate"""
+    k = KAT["correct"]
+    nav, p = device(dict(KAT["params"], gate_metric=PHD_GATE_DISABLED), KAT["pose"], mix_of(k["model"]))
+    nav.run_stages(z3(k["measurements"]), with_alpha=False)
+    got = nav.CorrectConditional(0)
+    assert_same_set(got, k["expected"], KAT["tolerance"])
+    want = orc.correct(p, KAT["pose"] + [0.0], k["measurements"], mix_of(k["model"]))
+    keep = want[0] >= p.min_weight
+    ow, gw = np.sort(want[0][keep]), np.sort(got[0])
+    assert len(gw) == len(ow) and np.allclose(gw, ow, rtol=1e-9)
+    nav.close()
+
+
+def test_prune_kat_on_the_device():
+    """PHDNavigatorTest.Prune (:195-265): 13 components -> 5. The device prunes what its correction step emits, so the 13
+    are given as a prior seen from a pose far outside the visible square: every detection probability is 0, the
+    correction passes them on unchanged (weight (1 - 0) w) and PruneModel gets exactly the test's input."""
+    k = KAT["prune"]
+    nav, p = device(KAT["params"], [1000.0, -1000.0], mix_of(k["model"]))
+    nav.run_stages(np.zeros((0, 3)), with_alpha=False)
+    got = nav.PruneModel(0)
+    assert_same_set(got, k["expected"], KAT["tolerance"])
+    want = orc.prune(p, mix_of(k["model"]))
+    assert len(got[0]) == len(want[0]) and np.allclose(got[0], want[0], rtol=1e-9) and np.allclose(got[1], want[1], rtol=1e-9, atol=1e-12)
+    assert np.allclose(got[2], want[2], rtol=1e-7, atol=1e-12)
+    nav.close()
+
+
+def test_linear2d_step_against_the_oracle():
+    """a whole SlamUpdate of the toy model (reweight and resampling included) on the device against the oracle"""
+    rng = np.random.default_rng(61)
+    P, C, M = 12, 10, 5
+    params = dict(KAT["params"], min_effective_particle=0.5)
+    from monorfs_amd import navigator
+    p = params_from_dict(params, max_particles=P, max_components=600, max_measurements=8)
+    lm = rng.uniform(-4, 4, (C, 2))
+    nav = navigator.PHDNavigator(p, particlecount=P, pose=[0, 0, 0, 1, 0, 0, 0])
+    st = orc.State(P, 700)
+    poses = np.zeros((P, 7))
+    poses[:, 3] = 1
+    poses[:, :2] = rng.normal(0, 0.02, (P, 2))
+    model = (rng.uniform(0.5, 1.1, C), np.column_stack([lm, np.zeros(C)]), np.broadcast_to(np.diag([2e-3, 2e-3, 1e-2]), (C, 3, 3)).copy())
+    nav.reset(poses[0], model, P)
+    nav.set_poses(poses)
+    st.poses[:] = poses
+    for i in range(P):
+        st.w[i, :C], st.mean[i, :C], st.cov[i, :C], st.n[i] = model[0], model[1], model[2], C
+    for step in range(3):
+        z = lm[rng.permutation(C)[:M]] + rng.normal(0, 0.02, (M, 2))
+        best, src, res, _ = orc.slam_update(p, st, z, u=0.37 + 0.1 * step, threads=2)
+        nav.SlamUpdate(None, z3(z), u_resample=0.37 + 0.1 * step)
+        gsrc, gres = nav.resample_sources()
+        assert gres == res and np.array_equal(gsrc, src) and nav.BestParticle == best
+        assert np.allclose(nav.VehicleWeights, st.weights, rtol=1e-6, atol=1e-300)
+        for i in (0, P - 1):
+            gw, gm, gc = nav.MapModel(i)
+            ow, om, oc = st.map(i)
+            assert len(gw) == len(ow) and np.allclose(gw, ow, rtol=1e-7) and np.allclose(gm, om, rtol=1e-7, atol=1e-10)
+    nav.close()
