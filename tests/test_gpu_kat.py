@@ -103,3 +103,27 @@ def test_linear2d_step_against_the_oracle():
             ow, om, oc = st.map(i)
             assert len(gw) == len(ow) and np.allclose(gw, ow, rtol=1e-7) and np.allclose(gm, om, rtol=1e-7, atol=1e-10)
     nav.close()
+
+
+def test_resample_kat_on_the_device():
+    """SimulationTest.resample (SimulationTest.cs:225-270): weights {.11, .28, .31, .01, .29}: for every random number the
+    best particle's source is 2, particles 1, 2, 4 always survive, 0 and 3 each die for some — put to phd_resample, and
+    every index vector against the oracle's sequential recurrence."""
+    from monorfs_amd import navigator
+    k = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "resample_kat.json")))
+    w = np.array(k["weights"])
+    p = params_from_dict(KAT["params"], max_particles=5, max_components=600, max_measurements=8)
+    nav = navigator.PHDNavigator(p, particlecount=5)
+    missing = {s: 0 for s in k["sometimes_absent"]}
+    us = np.concatenate([np.linspace(1e-9, 1 - 1e-9, 1500), np.random.default_rng(7).random(500)])
+    for u in us:
+        src, best = nav.ResampleParticles(w, float(u))
+        osrc, obest = orc.resample(w, float(u))
+        assert np.array_equal(src, osrc) and best == obest
+        assert src[best] == k["best_source"] and np.all(np.diff(src) >= 0)
+        for s in k["always_present"]:
+            assert s in src
+        for s in missing:
+            missing[s] += s not in src
+    assert all(cnt > 0 for cnt in missing.values())
+    nav.close()
