@@ -239,6 +239,14 @@ int phd_quasi_set_loglik(phd_navigator* nav, const double* poses7, int nposes, c
 int phd_quasi_set_loglik_grad(phd_navigator* nav, const double* poses7, int nposes, const double* landmarks3, int nlandmarks,
                               const double* z3, int nmeasurements, int average_mode, double* out, double* gradients6);
 
+/* Test surface for the assignment enumerators the set log-likelihood runs on the device: MurtyPairing (mode 0,
+ * GraphCombinatorics.cs:241-272; n <= 32) or LexicographicalPairing(matrix, modelsize) (mode 1, :280-334; n <= 5) on a
+ * dense n x n profit matrix (row-major, -inf = no entry). assignments[k][n] (row -> column; -1: an unsolved first node),
+ * values[k] for the first min(count, maxcount) pairings in the order they are produced; *count = how many there are
+ * (at most 200, the length of the reference's logcomp). The vectors of GraphCombinatoricsTest.cs go through this.  */
+int phd_test_pairing(phd_navigator* nav, const double* matrix, int n, int mode, int modelsize, int maxcount,
+                     int32_t* assignments, double* values, int* count);
+
 /* Per-kernel device time in milliseconds, from HIP events recorded around every launch on the
  * handle's stream: the mean over the launches since the last phd_timing_reset; names[i] -> ms[i];
  * returns the number of entries. phd_timing_reset(nav, 0) switches the events off; (nav, n) times every n-th

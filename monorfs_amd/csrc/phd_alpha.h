@@ -436,6 +436,43 @@ __device__ int cluster_enumerate_wave(const double* mat, int n, int modelsize, d
 	return m;
 }
 
+// Test surface (phd_test_pairing): the pairing enumerators on a matrix handed in by the host, so that the vectors of
+// GraphCombinatoricsTest.cs reach the device code itself. One wave. mode 0: MurtyPairing (best first; the cut of
+// SetLogLikelihood's loop is kept out by pre-filling logcomp), mode 1: LexicographicalPairing(matrix, modelsize), n <= 5.
+__global__ __launch_bounds__(64) void k_test_pairing(MurtyNodes* nodes, const double* matrix, int n, int mode, int modelsize,
+                                                     int maxcount, int* assignments, double* values, int* count)
+{
+	__shared__ double lds[MURTY_LDS_DOUBLES + 2];
+	const int lane = threadIdx.x;
+	MurtyLds ws;
+	ws.profit  = nodes->profit;
+	ws.reduced = nodes->reduced;
+	ws.logcomp = lds;
+	ws.fkey    = ws.logcomp + MURTY_OUT;
+	ws.fnode   = (int*) (ws.fkey + MURTY_POOL);
+	ws.freelist = ws.fnode + MURTY_POOL;
+	ws.L = ws.freelist + MURTY_POOL;
+	ws.Z = ws.L + MURTY_NMAX;
+	for (int i = lane; i < MURTY_OUT; i += 64) ws.logcomp[i] = 1e300;
+	const int stride = (mode == 1) ? 5 : n;
+	double* mat = (mode == 1) ? ws.reduced : ws.profit;
+	for (int e = lane; e < n * n; e += 64) mat[(e / n) * stride + (e % n)] = matrix[e];
+	lds_fence();
+	int m;
+	if (mode == 1) {
+		m = cluster_enumerate_wave(mat, n, modelsize, ws.logcomp, lane, [&](int k, unsigned int perm) {
+			if (k < maxcount && lane < n) assignments[k * n + lane] = pk_get(perm, lane);
+		});
+	}
+	else {
+		m = wave_murty(ws, nodes, n, lane, [&](int k, int code) {
+			if (k < maxcount && lane < n) assignments[k * n + lane] = (code & 0x10000) ? -1 : (int) nodes->asg[code][lane];
+		});
+	}
+	for (int k = lane; k < m && k < maxcount; k += 64) values[k] = ws.logcomp[k];
+	if (lane == 0) *count = m;
+}
+
 // LDS layout of k_weight_alpha, shared with the host so the launch sizes it identically.
 // Arrays indexed by landmark live in LDS while the map estimate has at most ALPHA_JL landmarks; a larger
 // estimate (up to Jcap) moves them to a per-particle slab in HBM, reached through the same (flat) pointers.

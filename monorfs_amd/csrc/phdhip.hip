@@ -732,6 +732,37 @@ int phd_quasi_set_loglik_grad(phd_navigator* nav, const double* poses7, int npos
 	return quasi_batch(nav, poses7, nposes, landmarks3, nlandmarks, z3, nmeasurements, out, gradients6, average_mode);
 }
 
+int phd_test_pairing(phd_navigator* nav, const double* matrix, int n, int mode, int modelsize, int maxcount,
+                     int32_t* assignments, double* values, int* count)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (!matrix || !assignments || !values || !count || n < 1 || n > MURTY_NMAX || maxcount < 1 || (mode == 1 && n > 5) || mode < 0 || mode > 1) {
+		return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_test_pairing: n in 1..32 (1..5 for the lexicographic order), mode 0 or 1, buffers for maxcount pairings");
+	}
+	hipSetDevice(nav->device);
+	HC(hipStreamSynchronize(nav->stream));
+	double* dm = nullptr; int* da = nullptr; double* dv = nullptr; int* dc = nullptr;
+	HC(hipMalloc((void**) &dm, (size_t) n * n * 8));
+	HC(hipMalloc((void**) &da, (size_t) maxcount * n * 4));
+	HC(hipMalloc((void**) &dv, (size_t) maxcount * 8));
+	HC(hipMalloc((void**) &dc, 4));
+	hipError_t e = hipMemcpy(dm, matrix, (size_t) n * n * 8, hipMemcpyHostToDevice);
+	if (e == hipSuccess) {
+		hipMemset(da, 0xff, (size_t) maxcount * n * 4);
+		hipLaunchKernelGGL(k_test_pairing, dim3(1), dim3(64), 0, nav->stream, nav->d_murty, (const double*) dm, n, mode, modelsize, maxcount, da, dv, dc);
+		e = hipStreamSynchronize(nav->stream);
+	}
+	int m = 0;
+	if (e == hipSuccess) e = hipMemcpy(&m, dc, 4, hipMemcpyDeviceToHost);
+	const int k = std::min(m, maxcount);
+	if (e == hipSuccess && k > 0) e = hipMemcpy(assignments, da, (size_t) k * n * 4, hipMemcpyDeviceToHost);
+	if (e == hipSuccess && k > 0) e = hipMemcpy(values, dv, (size_t) k * 8, hipMemcpyDeviceToHost);
+	hipFree(dm); hipFree(da); hipFree(dv); hipFree(dc);
+	if (e != hipSuccess) return nav->fail(PHD_ERR_DEVICE, std::string("phd_test_pairing: ") + hipGetErrorString(e));
+	*count = m;
+	return PHD_OK;
+}
+
 int phd_set_weights(phd_navigator* nav, const double* weights, int nparticles)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;

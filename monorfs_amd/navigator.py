@@ -294,6 +294,19 @@ class PHDNavigator:
         ptr = self._lib.phd_stage_setloglik(self._h, C.byref(n))
         return np.ctypeslib.as_array(ptr, shape=(n.value,)).copy()
 
+    def test_pairing(self, matrix, lexicographic=False, modelsize=0, maxcount=200):
+        """the device's MurtyPairing (best first) or LexicographicalPairing(matrix, modelsize) on a dense profit matrix:
+        (assignments [k][n], values [k]) — phd_test_pairing, the surface GraphCombinatoricsTest's vectors go through"""
+        m = np.ascontiguousarray(matrix, np.float64)
+        n = m.shape[0]
+        asg = np.zeros((maxcount, n), np.int32)
+        val = np.zeros(maxcount)
+        cnt = C.c_int(0)
+        self._check(self._lib.phd_test_pairing(self._h, _ptr(m), n, 1 if lexicographic else 0, int(modelsize), maxcount,
+                                               asg.ctypes.data_as(ip), _ptr(val), C.byref(cnt)))
+        k = min(cnt.value, maxcount)
+        return asg[:k].tolist(), val[:k].copy()
+
     # ------------------------------------------------------------------ benchmark surface
     def set_measurements(self, measurements):
         z = np.ascontiguousarray(measurements, np.float64).reshape(-1, 3)

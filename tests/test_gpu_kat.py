@@ -127,3 +127,57 @@ def test_resample_kat_on_the_device():
             missing[s] += s not in src
     assert all(cnt > 0 for cnt in missing.values())
     nav.close()
+
+
+# ---------------------------------------------------------------- GraphCombinatoricsTest.cs on the device
+GC = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "graphcombinatorics_kat.json")))
+
+
+@pytest.fixture(scope="module")
+def pairing_nav():
+    from monorfs_amd import navigator
+    p = params_from_dict(KAT["params"], max_particles=1, max_components=600, max_measurements=8)
+    nav = navigator.PHDNavigator(p, particlecount=1)
+    yield nav
+    nav.close()
+
+
+def _mat(m):
+    return np.array([[float(x) for x in row] for row in m], float)
+
+
+@pytest.mark.parametrize("case", GC["linear_assignment"], ids=lambda c: c["name"])
+def test_hungarian_kats_on_the_device(pairing_nav, case):
+    """GraphCombinatoricsTest.LinearAssignment* (:201-255): the optimal assignment = the first pairing of the device's Murty"""
+    asg, val = pairing_nav.test_pairing(_mat(case["matrix"]), maxcount=1)
+    assert asg[0] == case["expected"]
+    assert val[0] == orc.assignment_value(_mat(case["matrix"]), case["expected"])
+
+
+@pytest.mark.parametrize("case", GC["murty_pairing"], ids=["full_small", "unique"])
+def test_murty_order_kats_on_the_device(pairing_nav, case):
+    """GraphCombinatoricsTest.MurtyPairing / MurtyPairingUnique (:358-404)"""
+    asg, val = pairing_nav.test_pairing(_mat(case["matrix"]))
+    assert asg == case["expected"] and np.all(np.diff(val) <= 0)
+    oasg, oval = orc.murty(_mat(case["matrix"]))
+    assert asg == oasg and np.array_equal(val, oval)
+
+
+@pytest.mark.parametrize("case", GC["lexicographical"], ids=lambda c: "modelsize%d" % c["modelsize"])
+def test_lexicographic_kats_on_the_device(pairing_nav, case):
+    """GraphCombinatoricsTest.LexicographicalPairing* (:258-306)"""
+    asg, val = pairing_nav.test_pairing(_mat(case["matrix"]), lexicographic=True, modelsize=case["modelsize"])
+    assert asg == case["expected"]
+    _, oval = orc.lexicographic(_mat(case["matrix"]), case["modelsize"])
+    assert np.array_equal(val, oval)
+
+
+def test_murty_on_a_larger_random_matrix(pairing_nav):
+    """beyond the reference's vectors: 9 x 9 with missing entries, the first 200 pairings in order against the oracle"""
+    rng = np.random.default_rng(71)
+    m = rng.uniform(-20, 0, (9, 9))
+    m[rng.uniform(size=m.shape) < 0.3] = -np.inf
+    m[np.arange(9), np.arange(9)] = rng.uniform(-5, 0, 9)       # a finite diagonal: solvable
+    asg, val = pairing_nav.test_pairing(m)
+    oasg, oval = orc.murty(m, maxcount=200)
+    assert len(asg) == len(oasg) == 200 and asg == oasg and np.allclose(val, oval, rtol=0, atol=1e-12)
