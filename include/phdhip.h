@@ -48,7 +48,7 @@ extern "C" {
 /* dynamics model. PRM3D is the product. LINEAR2D is the toy model of the reference's unit tests (PHDNavigatorTest.cs):
  * it runs through the same kernels — a pose is (x, y, 0, 1, 0, 0, 0), a measurement (x, y, 0), still three doubles, R is
  * 2 x 2 row-major in the first four entries of `R` — so that those tests' vectors can be put to the device itself.
- * phd_update_motion and phd_quasi_set_loglik* are PRM3D only.                                 */
+ * phd_update_motion is PRM3D only; the gradient of phd_quasi_set_loglik_grad has its first two entries for (x, y).  */
 #define PHD_MODEL_LINEAR2D 0
 #define PHD_MODEL_PRM3D    1
 

@@ -370,6 +370,11 @@ __device__ __noinline__ int wave_murty(const MurtyLds& ws, MurtyNodes* nodes, in
 // MeasurementJacobianP (PRM3DMeasurer.cs:185-211): jprojection (3 x 3) times [-R(q*) | -R(q*) [m - t]x], row-major 3 x 6
 __device__ void jacobian_p(const DevParams& prm, const PoseD& pose, const double m[3], double* Jp)
 {
+	if (prm.linear2d) {   // Linear2DMeasurer.MeasurementJacobianP (Linear2DMeasurer.cs:133-137): -I on (x, y)
+		for (int i = 0; i < 18; i++) Jp[i] = 0.0;
+		Jp[0] = -1.0; Jp[7] = -1.0;
+		return;
+	}
 	const double diff[3] = {m[0] - pose.t[0], m[1] - pose.t[1], m[2] - pose.t[2]};
 	double l[3];
 	to_local(pose, diff, l);

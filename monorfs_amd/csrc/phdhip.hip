@@ -679,7 +679,6 @@ static int quasi_batch(phd_navigator* nav, const double* poses7, int nposes, con
                        const double* z3, int nmeasurements, double* out, double* gradients6, int average_mode)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
-	if (nav->prm.model != PHD_MODEL_PRM3D) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_quasi_set_loglik: the PRM3D model only");
 	if (nposes < 1 || nposes > nav->Pcap || nlandmarks < 0 || nlandmarks > nav->Jcap || nmeasurements < 0 ||
 	    nmeasurements > nav->prm.max_measurements || !poses7 || !out || (nlandmarks && !landmarks3) || (nmeasurements && !z3)) {
 		return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_quasi_set_loglik: sizes out of range (poses <= max_particles, landmarks <= min(1024, max_quantity), measurements <= max_measurements)");

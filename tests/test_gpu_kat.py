@@ -181,3 +181,41 @@ def test_murty_on_a_larger_random_matrix(pairing_nav):
     asg, val = pairing_nav.test_pairing(m)
     oasg, oval = orc.murty(m, maxcount=200)
     assert len(asg) == len(oasg) == 200 and asg == oasg and np.allclose(val, oval, rtol=0, atol=1e-12)
+
+
+# ---------------------------------------------------------------- LoopyPHDNavigatorTest.LogLike2D on the device
+def test_loglike2d_on_the_device():
+    """LoopyPHDNavigatorTest.LogLike2D (:351-419), the reference's test of QuasiSetLogLikelihood and its gradient: Linear2D,
+    R = 5e-2 I, two measurements, three landmarks, the pose on a 201 x 201 grid over [-1, 1]^2; at every inner grid point
+    central differences of the value must equal the analytic gradient within 0.5. The 40 401 poses go to the device in
+    batches. With TemperedAverage's weights divided by their sum (average_mode 1) the assertion holds everywhere; as the
+    source reads (mode 0) it does not — the same finding as on the oracle (tests/test_oracle_kat.py), to which the
+    device is compared point by point."""
+    from monorfs_amd import navigator
+    params = dict(KAT["params"], R=[[5e-2, 0], [0, 5e-2]])
+    p = params_from_dict(params, max_particles=2048, max_components=600, max_measurements=8)
+    nav = navigator.PHDNavigator(p, particlecount=1)
+    z = np.array([[0, 1, 0], [0.2, 0.6, 0]], float)
+    lm = np.array([[0, 1.45, 0], [0, 0.65, 0], [1.0, 0, 0]])
+    n = 201
+    x = np.array([((i / (n - 1)) - 0.5) / 0.5 for i in range(n)])
+    poses = np.zeros((n * n, 7))
+    poses[:, 0], poses[:, 1], poses[:, 3] = np.repeat(x, n), np.tile(x, n), 1
+    for mode in (1, 0):
+        L, G = np.zeros(n * n), np.zeros((n * n, 6))
+        for s in range(0, n * n, 2048):
+            L[s:s + 2048], G[s:s + 2048] = nav.QuasiSetLogLikelihoodGradient(z, lm, poses[s:s + 2048], average_mode=mode)
+        L, G = L.reshape(n, n), G.reshape(n, n, 6)
+        assert np.all(G[:, :, 2:] == 0)
+        xnum = (L[2:, 1:-1] - L[:-2, 1:-1]) / (x[2:] - x[:-2])[:, None]
+        ynum = (L[1:-1, 2:] - L[1:-1, :-2]) / (x[2:] - x[:-2])[None, :]
+        bad = (np.abs(xnum - G[1:-1, 1:-1, 0]) > 0.5) | (np.abs(ynum - G[1:-1, 1:-1, 1]) > 0.5)
+        if mode == 1:
+            assert bad.sum() == 0
+        else:
+            assert 0.15 * (n - 2) ** 2 < bad.sum() < 0.35 * (n - 2) ** 2
+        for i, k in ((0, 0), (100, 100), (37, 151), (200, 3), (120, 80)):   # and the oracle at some points
+            v, g = orc.quasi_set_log_likelihood_grad(p, [x[i], x[k], 0, 1, 0, 0, 0], lm[:, :3], z[:, :2], mode)
+            assert np.isclose(L[i, k], v, rtol=1e-11, atol=1e-11) and np.allclose(G[i, k, :2], g, rtol=1e-9, atol=1e-9)
+        assert np.array_equal(nav.QuasiSetLogLikelihood(z, lm, poses[:2048]), L.reshape(-1)[:2048])
+    nav.close()
