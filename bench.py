@@ -8,12 +8,15 @@ components x 64 measurements); N > 1 keeps 2048 particles per GPU (weak scaling,
 one process per GPU, RCCL all-gather of the particle weights, all-to-all of migrating particles.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus N ...                      starts its own N ranks (torch.distributed.run, one per GPU)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,7 +42,41 @@ def parse():
     ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP events")
     ap.add_argument("--events-every", type=int, default=8, help="time the launches of every n-th step of the timed region (each event costs the device a few microseconds)")
     ap.add_argument("--force-dist", action="store_true", help="take the sharded (RCCL) step path even with one rank (rehearsal)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra legs of the N = 1 run (isolated kernel times, other modes)")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`bench.py --gpus N` started as ONE process: start the N ranks as children (torch.distributed.run, one per GPU) and
+    pass rank 0's JSON line through. Nothing here touches a GPU (counting devices does not initialise HIP on this image);
+    the current process is never re-executed."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible to this process; refusing to report a %d-GPU number "
+                         "from fewer devices" % (args.gpus, have, args.gpus))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit("bench.py --gpus %d: the rank processes exited with status %d (no number reported)" % (args.gpus, rc))
+    return 0
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 class DevArray:
@@ -66,15 +103,18 @@ def cpu_baseline(frame, params, sample, threads):
 
     orc.slam_update(params, state(min(P, threads)), frame.z, u=0.5, threads=threads)   # warm-up
     stages = np.zeros(4)
-    steps, elapsed = 0, 0.0
-    while elapsed < 12.0 and steps < 200:   # about 10-30 s of CPU work, every step from the same input
+    times = []
+    elapsed = 0.0
+    while (len(times) < 100 or elapsed < 8.0) and elapsed < 25.0 and len(times) < 400:   # >= 100 steps, about 10-25 s of CPU work, every step from the same input
         st = state(P)
         stt = np.zeros(4)
         t0 = time.perf_counter()
         orc.slam_update(params, st, frame.z, u=0.5, threads=threads, stage_times=stt)
-        elapsed += time.perf_counter() - t0
+        times.append(time.perf_counter() - t0)
+        elapsed += times[-1]
         stages += stt
-        steps += 1
+    steps = len(times)
+    med = float(np.median(times))
     # the same step on 1 thread and on 8 (the reference's Parallel.For runs on NParallel = 8 threads, Config.cs:46), on
     # proportionally smaller particle samples (about a second each)
     by_threads = {}
@@ -86,26 +126,33 @@ def cpu_baseline(frame, params, sample, threads):
         t0 = time.perf_counter()
         orc.slam_update(params, st, frame.z, u=0.5, threads=t)
         by_threads[str(t)] = n * frame.C * frame.M / (time.perf_counter() - t0)
-    by_threads[str(threads)] = steps * P * frame.C * frame.M / elapsed
-    return {"value": steps * P * frame.C * frame.M / elapsed, "unit": "PHD updates/s", "cores": threads, "kind": "port",
-            "by_threads": by_threads,
-            "sample": "%d steps of %d of the %d particles (C=%d, M=%d), oracle/phd_oracle.cpp with OpenMP over particles, %.1f s"
-                      % (steps, P, frame.P, frame.C, frame.M, elapsed),
+    by_threads[str(threads)] = P * frame.C * frame.M / med
+    return {"value": P * frame.C * frame.M / med, "unit": "PHD updates/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port",
+            "by_threads": by_threads, "steps": steps, "statistic": "median step time", "mean_value": steps * P * frame.C * frame.M / elapsed,
+            "sample": "%d steps of %d of the %d particles (C=%d, M=%d), oracle/phd_oracle.cpp with OpenMP over particles on %d threads, %.1f s; "
+                      "a restatement of the C# algorithm in C++, not the C# runtime"
+                      % (steps, P, frame.P, frame.C, frame.M, threads, elapsed),
             "stage_share": {k: float(v / stages.sum()) for k, v in zip(("predict", "correct", "prune", "reweight"), stages)}}
 
 
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)   # plain `python bench.py --gpus N`: this process only starts the ranks
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus != world:
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch as many ranks as GPUs asked for" % (args.gpus, world))
 
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the PHD path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no GPU of its own (LOCAL_RANK %d, %d device(s) visible)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
     # Native libraries (RCCL prints a banner) write to file descriptor 1: keep it for the one JSON line and send
@@ -117,6 +164,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        joined = torch.ones(1, dtype=torch.int32, device="cuda")
+        dist.all_reduce(joined)    # every rank is there and RCCL works, or this raises / times out
+        if int(joined.item()) != args.gpus:
+            raise SystemExit("bench.py: %d ranks joined, --gpus %d" % (int(joined.item()), args.gpus))
 
     from monorfs_amd import navigator
     from monorfs_amd.abi import prm3d_defaults
@@ -195,6 +246,70 @@ def main():
     kernels = nav.last_timings()
     launches = nav.last_timing_counts() if kernels else {}
 
+    # ---- extra legs of the single-GPU run, all outside the timed region ------------------------------------------------
+    # (1) every kernel alone on the chip: the same step on ONE stream (phd_set_split(1)), HIP events around every launch.
+    #     In the timed region the two particle halves run on concurrent streams, so an event pair there also spans the
+    #     other half's kernels; the roofline figure is taken from these non-overlapped launches.
+    iso, iso_ms = {}, None
+    extra = world == 1 and not use_dist and not args.no_extra and not args.no_events
+    if extra:
+        nav.set_split(1)
+        for _ in range(2):
+            step()
+        barrier()
+        nav.timing_reset(1)
+        t1 = time.perf_counter()
+        for _ in range(8):
+            step()
+        barrier()
+        iso_ms = (time.perf_counter() - t1) / 8 * 1e3
+        iso = nav.last_timings()
+        nav.timing_reset(False)
+        nav.set_split(0)
+
+    def short_run(fr, steps=10):
+        """ms per step of a short frozen run on another frame of the same shape (an extra, recorded next to the headline)"""
+        nav.set_frozen(False)
+        nav.upload_state(fr.planes(), fr.counts, fr.poses, fr.weights)
+        nav.set_measurements(fr.z)
+        nav.set_frozen(True)
+        for _ in range(3):
+            step()
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        return (time.perf_counter() - t2) / steps * 1e3
+
+    modes = {}
+    if extra and args.config == "B":
+        other = "survey" if args.weights == "steady" else "steady"
+        fo = Frame(P, Cc, M, seed, weight_profile=other)
+        mo = short_run(fo)
+        modes["weights_" + other] = {"ms_per_step": mo, "value": P * Cc * M / (mo * 1e-3), "unit": "PHD updates/s", "steps": 10,
+                                     "note": "SURVEY 8d's literal prior weights U(0.05, 1.2): every WeightAlpha underflows, no resampling" if other == "survey"
+                                             else "detected components U(0.6, 1.2), the others U(0.002, 0.06)"}
+        # SURVEY 8d "realistic-gate": the kernels evaluate ALL C x M pairs (the gate only masks), which is what the metric
+        # counts; the reference evaluates only the pairs inside the radius gate of Map.Near (PHDNavigator.cs:882). Their
+        # share on this frame (squared-Euclidean gate, DensityDistanceThreshold), from the frame itself on the host:
+        from monorfs_amd.synth import measure_to_map_identity
+        samp = min(P, 64)
+        x = measure_to_map_identity(frame.z)                                    # base pose = identity up to 1e-3: an estimate
+        d2 = ((frame.mean[:samp, :, None, :] - x[None, None, :, :]) ** 2).sum(-1)
+        share = float((d2 <= params.density_distance_threshold).mean())
+        modes["realistic_gate"] = {"gated_pair_share": share, "gated_pair_updates_per_s": share * units_per_s(P, Cc, M, elapsed, args.steps, world),
+                                   "note": "share of the (component, measurement) pairs inside the correct-step gate (reference-faithful "
+                                           "sparsity), estimated on %d particles; the rate is the headline value times that share" % samp}
+    if extra:
+        Pa, Ca, Ma, seeda = CONFIGS["A"]
+        if P >= Pa and Cc >= Ca and M >= Ma:
+            # BASELINE config A (256 x 128 x 32), the latency-bound regime, on the same handle
+            fa = Frame(Pa, Ca, Ma, seeda, weight_profile=args.weights)
+            ma = short_run(fa, steps=50)
+            modes["config_A"] = {"ms_per_step": ma, "value": Pa * Ca * Ma / (ma * 1e-3), "unit": "PHD updates/s", "steps": 50,
+                                 "workload": "%d particles x %d components x %d measurements" % (Pa, Ca, Ma)}
+
     if rank == 0:
         units = P * world * Cc * M * args.steps
         ms = elapsed / args.steps * 1e3
@@ -207,34 +322,53 @@ def main():
                                       % (args.config, P, Cc, M, args.weights),
                           "particles_per_gpu": P, "components": Cc, "measurements": M, "max_quantity": maxq,
                           "parallelism": "particles sharded x%d" % world}}
+        if use_dist:
+            out["rccl_ranks"] = dist.get_world_size()
         if kernels:
             # the step's per-particle kernels run once per particle sub-range (phd_set_split): a kernel's cost per
             # step is its mean launch duration x launches per step, and the dominant kernel is the largest of those
             timed_steps = len(range(0, args.steps, max(1, min(args.events_every, 255))))
             per_step = {k: launches[k] / timed_steps for k in kernels}
-            dom = max(kernels, key=lambda k: kernels[k] * per_step[k])
-            particles_per_launch = P / per_step[dom]
+            src = iso if iso else kernels                  # non-overlapped launches when they were taken
+            per_launch_particles = {k: (P if iso else P / per_step[k]) for k in src}
+            dom = max(src, key=lambda k: src[k] * (1 if iso else per_step[k]))
+            particles_per_launch = per_launch_particles[dom]
             alg_bytes = 160.0 * particles_per_launch * Cc   # 80 B/component read + 80 B written, per particle
-            achieved = alg_bytes / (kernels[dom] * 1e-3) / 1e9
+            achieved = alg_bytes / (src[dom] * 1e-3) / 1e9
             traffic = None
-            tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-            if os.path.exists(tfile):
-                try:
-                    traffic = json.load(open(tfile)).get(args.config, {}).get(dom)
-                except Exception:
-                    traffic = None
+            for tname in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+                tfile = os.path.join(ROOT, "profiles", tname)
+                if os.path.exists(tfile):
+                    try:
+                        traffic = json.load(open(tfile)).get(args.config, {}).get(dom)
+                    except Exception:
+                        traffic = None
+                    if traffic is not None:
+                        if not iso and per_step[dom] > 1 and tname.startswith("r02"):
+                            traffic = traffic / per_step[dom]   # r02 figures are per whole-range launch
+                        break
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": kernels[dom],
-                               "particles_per_launch": particles_per_launch, "launches_per_step": per_step[dom]}
+                               "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": src[dom],
+                               "particles_per_launch": particles_per_launch,
+                               "launches_per_step": 1 if iso else per_step[dom],
+                               "kernel_ms_source": "HIP events around non-overlapped launches (one stream, 8 steps after the timed region)" if iso
+                                                   else "HIP events inside the timed region (particle halves on concurrent streams: launches overlap)"}
+            if iso:
+                out["kernel_ms_isolated"] = iso
+                out["ms_per_step_one_stream"] = iso_ms
+                out["step_bytes"] = {"algorithmic_bytes_per_step": 160.0 * P * Cc, "achieved_GBs_whole_step": 160.0 * P * Cc / (ms * 1e-3) / 1e9,
+                                     "frac_of_peak": 160.0 * P * Cc / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             out["kernel_ms"] = kernels
             out["kernel_launches_per_step"] = per_step
             out["kernel_ms_sampling"] = "HIP events on every %d-th step of the timed region (%d of %d steps)" % (max(1, min(args.events_every, 255)), timed_steps, args.steps)
             # The step is bound by vector-ALU issue, not by HBM: the wave-level VALU instructions of one
             # step (SQ_INSTS_VALU of the committed profile, per particle) against the rate at which the chip sustains
             # FP64 FMAs (scripts/probes/mfma_f64_rate.hip: 53 TFLOP/s = 4.14e11 wave instructions/s).
-            vfile = os.path.join(ROOT, "profiles", "r01_valu_insts.json")
-            if os.path.exists(vfile):
+            for vname in ("r02_valu_insts.json", "r01_valu_insts.json"):
+                vfile = os.path.join(ROOT, "profiles", vname)
+                if not os.path.exists(vfile):
+                    continue
                 try:
                     valu = json.load(open(vfile)).get(args.config, {})
                     insts = sum(v.get("per_particle", 0.0) * P + v.get("per_launch", 0.0) for v in valu.values())
@@ -242,19 +376,27 @@ def main():
                     if insts > 0:
                         out["valu_issue"] = {"wave_instructions_per_step": insts, "sustained_wave_instructions_per_s": rate,
                                              "bound_ms": insts / rate * 1e3, "frac": insts / rate * 1e3 / ms,
-                                             "source": "profiles/r01_valu_insts.json (rocprofv3 SQ_INSTS_VALU), profiles/r01_mfma_f64_probe.txt"}
+                                             "source": "profiles/%s (rocprofv3 SQ_INSTS_VALU), profiles/r01_mfma_f64_probe.txt" % vname}
+                        break
                 except Exception:
                     pass
+        if modes:
+            out["other_modes"] = modes
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 16)
-            sample = args.cpu_sample or P
+            sample = args.cpu_sample or min(P, 256)
             out["cpu_baseline"] = cpu_baseline(frame, params, sample, threads)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     nav.close()
     if use_dist:
         dist.destroy_process_group()
+    return 0
+
+
+def units_per_s(P, C, M, elapsed, steps, world):
+    return P * world * C * M * steps / elapsed
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

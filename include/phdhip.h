@@ -207,10 +207,6 @@ int   phd_plan_migration(const int32_t* gsrc, int particles_per_rank, int world_
                          int32_t* send_counts, int32_t* recv_counts, int32_t* send_list, int32_t* dst_code);
 void* phd_migration_send_buffer(phd_navigator* nav, int64_t* bytes_per_particle);
 void* phd_migration_recv_buffer(phd_navigator* nav);
-/* kept for hosts written against the first version, where it started the copies of the slots whose source is a
- * particle of this rank while the host planned the exchange; such particles are not copied at all any more (they
- * are read at their source's slot), so this does nothing                                          */
-int   phd_migration_local_async(phd_navigator* nav, int rank, int world_size);
 int   phd_migration_pack_async(phd_navigator* nav);
 int   phd_migration_unpack_async(phd_navigator* nav);
 void* phd_stream(phd_navigator* nav);                               /* hipStream_t of the handle   */

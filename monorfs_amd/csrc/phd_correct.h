@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void k_emit_finish(const DevParams prm, const 
 	// the pair (component c, measurement k), already inside the radius gate: weight in the reference's arithmetic,
 	// and the Kalman update when it reaches MinWeight
 	auto pair = [&](int c, int k) {
+		PHD_REF_ARITH
 		double w, m[3], P[6];
 		load_predicted(prm, a, vin, p, n, c, w, m, P);
 		CompMeas q;

@@ -6,6 +6,14 @@
 
 #define PHD_WAVE 64
 
+// The reference runs on the CLR: IEEE doubles, no fused multiply-add. Everything that restates its arithmetic — the
+// measurement model, S and its inverse, the Kalman update, Merge, the closeness test — is compiled without FP contraction so
+// that it rounds like the reference (and like the oracle, built with -ffp-contract=off): means and covariances then leave
+// CorrectConditional and PruneModel bit for bit as the oracle's, and discrete decisions (AreClose, the MinWeight cut) see
+// the same numbers. Only the dense pair loops (gauss_logw + exp_neg: sums of thousands of terms, compared with a
+// tolerance) keep their fused multiply-adds. First statement of a function body.
+#define PHD_REF_ARITH _Pragma("clang fp contract(off)")
+
 // In-kernel stamps for a separate DIAGNOSTIC build only (hipcc -DPHD_STAMPS -> libphdhip_stamps.so, see
 // scripts/stamps.py): thread 0 of every workgroup records the shader clock at phase boundaries and leaves the
 // differences in a debug slab that no kernel reads. The product build compiles them to nothing.
@@ -60,6 +68,7 @@ struct PoseD {
 
 __device__ __forceinline__ PoseD load_pose(const double* __restrict__ s)
 {
+	PHD_REF_ARITH
 	PoseD p;
 	p.t[0] = s[0]; p.t[1] = s[1]; p.t[2] = s[2];
 	double w = s[3], x = s[4], y = s[5], z = s[6];
@@ -73,6 +82,7 @@ __device__ __forceinline__ void qmul(double aw, double ax, double ay, double az,
                                      double bw, double bx, double by, double bz,
                                      double& w, double& x, double& y, double& z)
 {
+	PHD_REF_ARITH
 	w = aw * bw - (ax * bx + ay * by + az * bz);
 	x = aw * bx + ax * bw + ay * bz - az * by;
 	y = aw * by + ay * bw + az * bx - ax * bz;
@@ -82,6 +92,7 @@ __device__ __forceinline__ void qmul(double aw, double ax, double ay, double az,
 // local = q* (0, d) q : world -> sensor frame (PRM3DMeasurer.cs:141-142)
 __device__ __forceinline__ void to_local(const PoseD& p, const double d[3], double l[3])
 {
+	PHD_REF_ARITH
 	double w1, x1, y1, z1, w2;
 	qmul(p.qw, -p.qx, -p.qy, -p.qz, 0.0, d[0], d[1], d[2], w1, x1, y1, z1);
 	qmul(w1, x1, y1, z1, p.qw, p.qx, p.qy, p.qz, w2, l[0], l[1], l[2]);
@@ -90,6 +101,7 @@ __device__ __forceinline__ void to_local(const PoseD& p, const double d[3], doub
 // Quaternion.Conjugate().ToMatrix() (Quaternion.cs:327-342 on (w, -x, -y, -z))
 __device__ __forceinline__ void conj_matrix(const PoseD& p, double r[9])
 {
+	PHD_REF_ARITH
 	double X = -p.qx, Y = -p.qy, Z = -p.qz, W = p.qw;
 	double xx = X * X, yy = Y * Y, zz = Z * Z;
 	double xy = X * Y, xz = X * Z, xw = X * W;
@@ -102,6 +114,7 @@ __device__ __forceinline__ void conj_matrix(const PoseD& p, double r[9])
 // MeasureToMap (PRM3DMeasurer.cs:299-312)
 __device__ __forceinline__ void measure_to_map(const DevParams& prm, const PoseD& p, const double z[3], double x[3])
 {
+	PHD_REF_ARITH
 	if (prm.linear2d) {   // Linear2DMeasurer.MeasureToMap (Linear2DMeasurer.cs:181-184)
 		x[0] = p.t[0] + z[0]; x[1] = p.t[1] + z[1]; x[2] = 0.0;
 		return;
@@ -119,6 +132,7 @@ __device__ __forceinline__ void measure_to_map(const DevParams& prm, const PoseD
 __device__ __forceinline__ void measure_perfect(const DevParams& prm, const PoseD& p, const double m[3],
                                                 double zh[3], double l[3])
 {
+	PHD_REF_ARITH
 	if (prm.linear2d) {   // Linear2DMeasurer.MeasurePerfect (Linear2DMeasurer.cs:110-113)
 		zh[0] = m[0] - p.t[0]; zh[1] = m[1] - p.t[1]; zh[2] = 0.0;
 		l[0] = 0.0; l[1] = 0.0; l[2] = 1.0;
@@ -136,6 +150,7 @@ __device__ __forceinline__ void measure_perfect(const DevParams& prm, const Pose
 // FuzzyVisibleM (PRM3DMeasurer.cs:277-291) * detectionProbability (SimulatedVehicle.cs:335-338)
 __device__ __forceinline__ double detection_probability_m(const DevParams& prm, const double z[3])
 {
+	PHD_REF_ARITH
 	if (prm.linear2d) {   // Linear2DMeasurer.FuzzyVisibleM (Linear2DMeasurer.cs:151-162)
 		double mind = (z[0] + prm.lin_range) / prm.ramp[0];
 		mind = fmin(mind, (prm.lin_range - z[0]) / prm.ramp[0]);
@@ -155,6 +170,7 @@ __device__ __forceinline__ double detection_probability_m(const DevParams& prm, 
 // MeasurementJacobianL (PRM3DMeasurer.cs:157-177): H = Jproj(local) * R(q*)
 __device__ __forceinline__ void jacobian_l(const DevParams& prm, const double l[3], const double rq[9], double H[9])
 {
+	PHD_REF_ARITH
 	if (prm.linear2d) {   // Linear2DMeasurer.MeasurementJacobianL (Linear2DMeasurer.cs:115-119), a zero third row
 		H[0] = 1; H[1] = 0; H[2] = 0;  H[3] = 0; H[4] = 1; H[5] = 0;  H[6] = 0; H[7] = 0; H[8] = 0;
 		return;
@@ -182,6 +198,7 @@ __device__ __forceinline__ void jacobian_l(const DevParams& prm, const double l[
 // cofactor formulas of the general inverse with the symmetric entries substituted.
 __device__ __forceinline__ void inv_sym3(const double P[6], double inv[6], double& det)
 {
+	PHD_REF_ARITH
 	double xx = P[0], xy = P[1], xz = P[2], yy = P[3], yz = P[4], zz = P[5];
 	double c00 = yy * zz - yz * yz;
 	double c01 = xy * zz - yz * xz;
@@ -199,6 +216,7 @@ __device__ __forceinline__ void inv_sym3(const double P[6], double inv[6], doubl
 // inverse and determinant of a general 3x3, row-major
 __device__ __forceinline__ void inv_gen3(const double a[9], double inv[9], double& det)
 {
+	PHD_REF_ARITH
 	double c00 = a[4] * a[8] - a[5] * a[7];
 	double c01 = a[3] * a[8] - a[5] * a[6];
 	double c02 = a[3] * a[7] - a[4] * a[6];
@@ -218,6 +236,7 @@ __device__ __forceinline__ void inv_gen3(const double a[9], double inv[9], doubl
 // d^T A d for symmetric A (upper triangle), accumulated row by row like Gaussian.Evaluate
 __device__ __forceinline__ double quad_sym(const double A[6], double d0, double d1, double d2)
 {
+	PHD_REF_ARITH
 	double r0 = A[0] * d0 + A[1] * d1 + A[2] * d2;
 	double r1 = A[1] * d0 + A[3] * d1 + A[4] * d2;
 	double r2 = A[2] * d0 + A[4] * d1 + A[5] * d2;
@@ -226,6 +245,7 @@ __device__ __forceinline__ double quad_sym(const double A[6], double d0, double 
 
 __device__ __forceinline__ double quad_gen(const double A[9], double d0, double d1, double d2)
 {
+	PHD_REF_ARITH
 	double r0 = A[0] * d0 + A[1] * d1 + A[2] * d2;
 	double r1 = A[3] * d0 + A[4] * d1 + A[5] * d2;
 	double r2 = A[6] * d0 + A[7] * d1 + A[8] * d2;
@@ -292,6 +312,7 @@ struct CompMeas {
 __device__ __forceinline__ void comp_measure(const DevParams& prm, const PoseD& pose, const double rq[9],
                                              const double m[3], const double P[6], CompMeas& o)
 {
+	PHD_REF_ARITH
 	double l[3];
 	measure_perfect(prm, pose, m, o.zh, l);
 	jacobian_l(prm, l, rq, o.H);
@@ -331,6 +352,7 @@ __device__ __forceinline__ void comp_measure(const DevParams& prm, const PoseD& 
 // K = PH Sinv, m' = m + K nu, P' = (I - K H) P (upper triangle kept)
 __device__ __forceinline__ void kalman_gain(const CompMeas& cm, double K[9])
 {
+	PHD_REF_ARITH
 #pragma unroll
 	for (int a = 0; a < 3; a++) {
 #pragma unroll
@@ -347,6 +369,7 @@ __device__ __forceinline__ void kalman_gain(const CompMeas& cm, double K[9])
 
 __device__ __forceinline__ void kalman_cov(const CompMeas& cm, const double K[9], const double P[6], double Pn[6])
 {
+	PHD_REF_ARITH
 	const double Pf[9] = {P[0], P[1], P[2], P[1], P[3], P[4], P[2], P[4], P[5]};
 	double IKH[9];
 #pragma unroll

@@ -224,10 +224,12 @@ __device__ inline void add_odometry(double s[7], const double* d)
 	s[3] = alpha * nq.w; s[4] = alpha * nq.x; s[5] = alpha * nq.y; s[6] = alpha * nq.z;
 }
 
-__global__ __launch_bounds__(256) void k_motion(double* poses, int P, const double* odometry, const double* noise, int use_noise)
+// (the bank holding the current poses is resolved here, on the device: correct right behind an asynchronous step)
+__global__ __launch_bounds__(256) void k_motion(const StepBufs a, int P, const double* odometry, const double* noise, int use_noise)
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
 	if (i >= P) return;
+	double* poses = bank_of(a, SEL_IN).poses;
 	double s[7], d[6];
 #pragma unroll
 	for (int t = 0; t < 7; t++) s[t] = poses[(size_t) i * 7 + t];
@@ -241,6 +243,16 @@ __global__ __launch_bounds__(256) void k_motion(double* poses, int P, const doub
 	}
 #pragma unroll
 	for (int t = 0; t < 7; t++) poses[(size_t) i * 7 + t] = s[t];
+}
+
+// phd_set_poses / phd_set_weights: staged values into the small arrays of the current state (the IN bank, whichever
+// it is by now). One thread per double.
+__global__ __launch_bounds__(256) void k_store_small(const StepBufs a, const double* poses, const double* weights, int P)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	const Bank bi = bank_of(a, SEL_IN);
+	if (poses && i < P * 7) bi.poses[i] = poses[i];
+	if (weights && i < P) bi.weights[i] = weights[i];
 }
 
 // replicate particle 0 of the IN bank over `P` particles of the OUT bank (PHDNavigator.reset, :256-263)

@@ -708,6 +708,9 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 		const int total = scan[0] + scan[1] + scan[2] + scan[3];
 		__syncthreads();
 		if (surv) {
+			// the reference runs on the CLR (no fused multiply-add): Merge's raw moments must round as there, or a scene far
+			// from the origin loses digits of the covariance to the difference (tests: test_reweight_far_from_the_origin)
+PHD_REF_ARITH
 			const int pos = base + __popcll(bal & lanemask_lt());
 			double rec[10];
 #pragma unroll
@@ -720,6 +723,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 			double C3 = 0.0 + w * (rec[6] + m1 * m1), C4 = 0.0 + w * (rec[7] + m1 * m2), C5 = 0.0 + w * (rec[8] + m2 * m2);
 			int nabs = 0;
 			auto absorb = [&](int k) {
+PHD_REF_ARITH
 				nabs++;
 				double rk[10];
 #pragma unroll

@@ -141,6 +141,13 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 	__shared__ int    s_i16[16];
 	__shared__ int    s_res, s_ok, s_best;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	// A kernel of this step raised a flag (emit capacity, landmark scratch): what it wrote into the OUT bank is not a
+	// valid state. The step is dropped as a whole — the roles stay, nothing of the current state was touched — and the host
+	// finds the flag at its next phd_sync. (Every thread reads the same word, written by earlier launches.)
+	if (sel_next && *a.flags != 0) {
+		if (tid < SEL_STRIDE) sel_next[tid] = a.sel[tid];
+		return;
+	}
 	double* gwp = gw ? gw : bank_of(a, SEL_OUT).weights;
 	double* w = use_lds ? lw : gwp;
 	if (use_lds) {

@@ -68,7 +68,13 @@ struct phd_navigator {
 	double* d_quasi = nullptr;    // phd_quasi_set_loglik: poses[Pcap][7], landmarks[Jcap][3], z[256][3], out[Pcap]
 	std::vector<double> h_quasi;
 	double* d_gw = nullptr; int gwcap = 0;           // gathered weights of all ranks
-	double* d_stage = nullptr;                       // staging for uploads
+	double* d_stage = nullptr;                       // device staging of phd_set_poses / phd_set_weights (stored into the IN bank by k_store_small)
+	// pinned host staging of the per-frame inputs (poses, weights, odometry + noise, measurements): the caller's buffers are
+	// copied here and are free when the call returns; the copy to the device is asynchronous. Two buffers, each guarded by
+	// an event recorded behind the copy that reads it.
+	double* h_stage[2] = {nullptr, nullptr}; hipEvent_t ev_stage[2] = {nullptr, nullptr}; bool stage_used[2] = {false, false};
+	int stage_i = 0; size_t stagecap = 0;
+	int nr_static_lds = 0;                           // static LDS of k_normalise_resample
 	// migration (multi-GPU resampling)
 	double* d_send = nullptr; double* d_recv = nullptr; int* d_plan = nullptr; int migcap = 0;
 	std::vector<int> h_plan_send, h_plan_recv;       // particle lists
@@ -200,6 +206,22 @@ StepBufs make_bufs(phd_navigator* nav)
 
 int zb_of(int M) { return M <= 64 ? 1 : (M <= 128 ? 2 : 4); }
 
+// A pinned staging buffer nobody reads any more (waits for the copy that last read it: normally long done).
+double* stage_acquire(phd_navigator* nav)
+{
+	nav->stage_i ^= 1;
+	const int i = nav->stage_i;
+	if (nav->stage_used[i]) hipEventSynchronize(nav->ev_stage[i]);
+	return nav->h_stage[i];
+}
+
+// ... the asynchronous copy out of it has been enqueued on the handle's stream
+void stage_release(phd_navigator* nav)
+{
+	hipEventRecord(nav->ev_stage[nav->stage_i], nav->stream);
+	nav->stage_used[nav->stage_i] = true;
+}
+
 
 // HIP events around every kernel launch, on the stream the kernel is launched on. `chained`: the launch follows the
 // previous timed launch on the same stream with nothing in between, so that launch's end event is this one's start.
@@ -248,9 +270,7 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha)
 	const int want = nav->nsplit > 0 ? nav->nsplit : (P >= 1024 ? 2 : 1);
 	const int S = std::max(1, std::min(std::min(want, (int) phd_navigator::MAXSPLIT), P));
 	const size_t lp = (size_t) prune_lds(nav->cutcap).bytes;
-	const AlphaLds lay = alpha_lds(ZB * 64, nav->cutcap);
-	HC(hipFuncSetAttribute((const void*) k_prune_merge, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lp));
-	HC(hipFuncSetAttribute((const void*) k_alpha_assoc<ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
+	const AlphaLds lay = alpha_lds(ZB * 64, nav->cutcap);   // (the dynamic LDS limits of the kernels were raised once, in phd_create)
 	if (S > 1) {
 		HC(hipEventRecord(nav->ev_fork, nav->stream));
 		for (int s = 1; s < S; s++) HC(hipStreamWaitEvent(nav->aux[s - 1], nav->ev_fork, 0));
@@ -294,11 +314,9 @@ int launch_quasi(phd_navigator* nav, const StepBufs& b, int nposes, bool gradien
 {
 	const AlphaLds lay = alpha_lds(ZB * 64, nav->cutcap);
 	if (gradient) {
-		HC(hipFuncSetAttribute((const void*) k_quasi_setll_grad<ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
 		hipLaunchKernelGGL(k_quasi_setll_grad<ZB>, dim3(nposes), dim3(256), lay.bytes, nav->stream, nav->dp, b, nav->cutcap);
 	}
 	else {
-		HC(hipFuncSetAttribute((const void*) k_quasi_setll<ZB>, hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
 		hipLaunchKernelGGL(k_quasi_setll<ZB>, dim3(nposes), dim3(256), lay.bytes, nav->stream, nav->dp, b, nav->cutcap);
 	}
 	HC(hipGetLastError());
@@ -317,10 +335,11 @@ int launch_map(phd_navigator* nav, const StepBufs& b, bool with_alpha)
 int launch_normalise(phd_navigator* nav, const StepBufs& b, double* gw, int P, double u, int force, int skipnorm, int* src, int* info,
                      int* sel_next = nullptr)
 {
+	// the weight vector is staged in LDS when it fits beside the kernel's static arrays (160 KB per CU); above that the
+	// kernel works on the vector in global memory
 	size_t lds = (size_t) P * 8;
-	int use_lds = lds <= 144 * 1024;
+	int use_lds = lds + (size_t) nav->nr_static_lds + 256 <= 160 * 1024;
 	if (!use_lds) lds = 0;
-	HC(hipFuncSetAttribute((const void*) k_normalise_resample, hipFuncAttributeMaxDynamicSharedMemorySize, (int) std::max<size_t>(lds, 16)));
 	hipLaunchKernelGGL(k_normalise_resample, dim3(1), dim3(1024), lds, nav->stream, b, gw, P, nav->dp.min_eff, u, force, skipnorm,
 	                   use_lds, src, info, sel_next, nav->frozen ? 1 : 0, nav->d_inslot);
 	HC(hipGetLastError());
@@ -567,6 +586,45 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	ok = ok && dalloc((void**) &nav->d_alm, (size_t) nav->Pcap * 3 * nav->Jcap * 8);
 	ok = ok && dalloc((void**) &nav->d_aJ, (size_t) nav->Pcap * 4) && dalloc((void**) &nav->d_account, (size_t) nav->Pcap * 8);
 	ok = ok && dalloc((void**) &nav->d_jscratch, (size_t) nav->Pcap * alpha_jscratch_doubles(nav->Jcap) * 8);
+	nav->stagecap = std::max((size_t) nav->Pcap * 8 + 8, (size_t) 256 * 3);   // poses + weights | odometry + noise | measurements
+	ok = ok && dalloc((void**) &nav->d_stage, nav->stagecap * 8) && dalloc((void**) &nav->d_motion, ((size_t) nav->Pcap * 6 + 6) * 8);
+	for (int i = 0; i < 2; i++) {
+		ok = ok && hipHostMalloc((void**) &nav->h_stage[i], nav->stagecap * 8, hipHostMallocDefault) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&nav->ev_stage[i], hipEventDisableTiming) == hipSuccess;
+	}
+	{
+		// dynamic LDS limits, once: they depend on the handle's capacities only (the same kernels serve every handle of the
+		// process: the limit is only ever raised)
+		static int lim_prune = 0, lim_alpha[3] = {0, 0, 0};
+		const int lp = prune_lds(nav->cutcap).bytes;
+		if (lp > lim_prune) { ok = ok && hipFuncSetAttribute((const void*) k_prune_merge, hipFuncAttributeMaxDynamicSharedMemorySize, lp) == hipSuccess; lim_prune = lp; }
+		const int la[3] = {alpha_lds(64, nav->cutcap).bytes, alpha_lds(128, nav->cutcap).bytes, alpha_lds(256, nav->cutcap).bytes};
+		if (la[0] > lim_alpha[0]) {
+			ok = ok && hipFuncSetAttribute((const void*) k_alpha_assoc<1>, hipFuncAttributeMaxDynamicSharedMemorySize, la[0]) == hipSuccess;
+			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll<1>, hipFuncAttributeMaxDynamicSharedMemorySize, la[0]) == hipSuccess;
+			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll_grad<1>, hipFuncAttributeMaxDynamicSharedMemorySize, la[0]) == hipSuccess;
+			lim_alpha[0] = la[0];
+		}
+		if (la[1] > lim_alpha[1]) {
+			ok = ok && hipFuncSetAttribute((const void*) k_alpha_assoc<2>, hipFuncAttributeMaxDynamicSharedMemorySize, la[1]) == hipSuccess;
+			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll<2>, hipFuncAttributeMaxDynamicSharedMemorySize, la[1]) == hipSuccess;
+			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll_grad<2>, hipFuncAttributeMaxDynamicSharedMemorySize, la[1]) == hipSuccess;
+			lim_alpha[1] = la[1];
+		}
+		if (la[2] > lim_alpha[2]) {
+			ok = ok && hipFuncSetAttribute((const void*) k_alpha_assoc<4>, hipFuncAttributeMaxDynamicSharedMemorySize, la[2]) == hipSuccess;
+			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll<4>, hipFuncAttributeMaxDynamicSharedMemorySize, la[2]) == hipSuccess;
+			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll_grad<4>, hipFuncAttributeMaxDynamicSharedMemorySize, la[2]) == hipSuccess;
+			lim_alpha[2] = la[2];
+		}
+		hipFuncAttributes fa;
+		if (ok && hipFuncGetAttributes(&fa, (const void*) k_normalise_resample) == hipSuccess) {
+			nav->nr_static_lds = (int) fa.sharedSizeBytes;
+			ok = ok && hipFuncSetAttribute((const void*) k_normalise_resample, hipFuncAttributeMaxDynamicSharedMemorySize,
+			                               160 * 1024 - nav->nr_static_lds) == hipSuccess;
+		}
+		else ok = false;
+	}
 	if (!ok) {
 		g_create_error = std::string("device allocation failed: ") + hipGetErrorString(hipGetLastError());
 		phd_destroy(nav);
@@ -600,6 +658,11 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_wcopy); hipFree(nav->d_cover); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
 	if (nav->h_pin) hipHostFree(nav->h_pin);
+	for (int i = 0; i < 2; i++) {
+		if (nav->h_stage[i]) hipHostFree(nav->h_stage[i]);
+		if (nav->ev_stage[i]) hipEventDestroy(nav->ev_stage[i]);
+	}
+	hipFree(nav->d_stage);
 	if (nav->own_stream) hipStreamDestroy(nav->own_stream);
 	for (int i = 0; i < phd_navigator::MAXSPLIT - 1; i++) {
 		if (nav->aux[i]) hipStreamDestroy(nav->aux[i]);
@@ -648,8 +711,16 @@ int phd_set_poses(phd_navigator* nav, const double* poses7, int nparticles)
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	if (nparticles != nav->P || !poses7) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_poses: particle count mismatch");
 	hipSetDevice(nav->device);
-	HC(hipMemcpyAsync(nav->bank[cur_bank(nav)].poses, poses7, (size_t) nparticles * 7 * 8, hipMemcpyHostToDevice, nav->stream));
-	HC(hipStreamSynchronize(nav->stream));
+	// the bank that holds the current poses is known to the device (the roles rotate there, at the end of a step): the poses
+	// are staged and stored by a kernel that resolves it, so this is correct right behind phd_step_async and never waits
+	double* hs = stage_acquire(nav);
+	std::memcpy(hs, poses7, (size_t) nparticles * 7 * 8);
+	HC(hipMemcpyAsync(nav->d_stage, hs, (size_t) nparticles * 7 * 8, hipMemcpyHostToDevice, nav->stream));
+	stage_release(nav);
+	StepBufs b = make_bufs(nav);
+	hipLaunchKernelGGL(k_store_small, dim3((nparticles * 7 + 255) / 256), dim3(256), 0, nav->stream, b, (const double*) nav->d_stage, (const double*) nullptr, nparticles);
+	HC(hipGetLastError());
+	nav->stage_valid = false;
 	return PHD_OK;
 }
 
@@ -664,13 +735,15 @@ int phd_update_motion(phd_navigator* nav, const double* odometry6, const double*
 	bool zero = true;
 	for (int t = 0; t < 6; t++) zero = zero && odometry6[t] == 0;
 	const int use_noise = noise6 && !(perfect_still && zero);   // "static friction makes the robot stay put", TrackVehicle.cs:93-94
-	if (!nav->d_motion) HC(hipMalloc((void**) &nav->d_motion, ((size_t) nav->Pcap * 6 + 6) * 8));
-	HC(hipMemcpyAsync(nav->d_motion, odometry6, 6 * 8, hipMemcpyHostToDevice, nav->stream));
-	if (use_noise) HC(hipMemcpyAsync(nav->d_motion + 6, noise6, (size_t) nparticles * 6 * 8, hipMemcpyHostToDevice, nav->stream));
-	hipLaunchKernelGGL(k_motion, dim3((nparticles + 255) / 256), dim3(256), 0, nav->stream, nav->bank[cur_bank(nav)].poses, nparticles,
+	double* hs = stage_acquire(nav);
+	std::memcpy(hs, odometry6, 6 * 8);
+	if (use_noise) std::memcpy(hs + 6, noise6, (size_t) nparticles * 6 * 8);
+	HC(hipMemcpyAsync(nav->d_motion, hs, (6 + (use_noise ? (size_t) nparticles * 6 : 0)) * 8, hipMemcpyHostToDevice, nav->stream));
+	stage_release(nav);   // the caller's buffers are free again; nothing waits for the device
+	StepBufs b = make_bufs(nav);
+	hipLaunchKernelGGL(k_motion, dim3((nparticles + 255) / 256), dim3(256), 0, nav->stream, b, nparticles,
 	                   (const double*) nav->d_motion, (const double*) (nav->d_motion + 6), use_noise);
 	HC(hipGetLastError());
-	HC(hipStreamSynchronize(nav->stream));   // the caller's buffers are free again
 	nav->stage_valid = false;
 	return PHD_OK;
 }
@@ -767,8 +840,14 @@ int phd_set_weights(phd_navigator* nav, const double* weights, int nparticles)
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	if (nparticles != nav->P || !weights) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_weights: particle count mismatch");
 	hipSetDevice(nav->device);
-	HC(hipMemcpyAsync(nav->bank[cur_bank(nav)].weights, weights, (size_t) nparticles * 8, hipMemcpyHostToDevice, nav->stream));
-	HC(hipStreamSynchronize(nav->stream));
+	double* hs = stage_acquire(nav);
+	std::memcpy(hs, weights, (size_t) nparticles * 8);
+	HC(hipMemcpyAsync(nav->d_stage, hs, (size_t) nparticles * 8, hipMemcpyHostToDevice, nav->stream));
+	stage_release(nav);
+	StepBufs b = make_bufs(nav);
+	hipLaunchKernelGGL(k_store_small, dim3((nparticles + 255) / 256), dim3(256), 0, nav->stream, b, (const double*) nullptr, (const double*) nav->d_stage, nparticles);
+	HC(hipGetLastError());
+	nav->stage_valid = false;
 	return PHD_OK;
 }
 
@@ -841,8 +920,10 @@ int phd_set_measurements(phd_navigator* nav, const double* z3, int nmeasurements
 	}
 	hipSetDevice(nav->device);
 	if (nmeasurements > 0) {
-		HC(hipMemcpyAsync(nav->d_z, z3, (size_t) nmeasurements * 3 * 8, hipMemcpyHostToDevice, nav->stream));
-		HC(hipStreamSynchronize(nav->stream));
+		double* hs = stage_acquire(nav);
+		std::memcpy(hs, z3, (size_t) nmeasurements * 3 * 8);
+		HC(hipMemcpyAsync(nav->d_z, hs, (size_t) nmeasurements * 3 * 8, hipMemcpyHostToDevice, nav->stream));
+		stage_release(nav);
 	}
 	nav->M = nmeasurements;
 	return PHD_OK;
@@ -1278,16 +1359,24 @@ int phd_migration_plan(phd_navigator* nav, int rank, int world_size, int32_t* se
 	if (!nav->sel_host_valid) rc = sync_state(nav);
 	if (rc) return rc;
 	const int Pl = nav->P, Pg = Pl * world_size, first = rank * Pl;
-	if (nav->h_pin_cap < Pg + 2) {
+	if (nav->h_pin_cap < Pg + 3) {
 		if (nav->h_pin) hipHostFree(nav->h_pin);
 		nav->h_pin = nullptr;
-		HC(hipHostMalloc((void**) &nav->h_pin, (size_t) (Pg + 2) * 4, hipHostMallocDefault));
-		nav->h_pin_cap = Pg + 2;
+		HC(hipHostMalloc((void**) &nav->h_pin, (size_t) (Pg + 3) * 4, hipHostMallocDefault));
+		nav->h_pin_cap = Pg + 3;
 	}
-	// one round trip: the resampling flag and the global source vector land in pinned memory together
+	// one round trip: the resampling flag, the global source vector and the status flags land in pinned memory together
 	HC(hipMemcpyAsync(nav->h_pin, nav->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, nav->stream));
 	HC(hipMemcpyAsync(nav->h_pin + 2, nav->d_plan, (size_t) Pg * 4, hipMemcpyDeviceToHost, nav->stream));
+	HC(hipMemcpyAsync(nav->h_pin + 2 + Pg, nav->d_flags, sizeof(int), hipMemcpyDeviceToHost, nav->stream));
 	HC(hipStreamSynchronize(nav->stream));
+	if (nav->h_pin[2 + Pg]) {
+		// a kernel of the local step raised a flag: the step is dropped before anything rotates (the caller must not go on to
+		// pack / unpack; the state is the one before phd_step_local_async)
+		nav->h_flags = nav->h_pin[2 + Pg];
+		hipMemsetAsync(nav->d_flags, 0, 4, nav->stream);
+		return check_flags(nav);
+	}
 	nav->h_info[0] = nav->h_pin[0]; nav->h_info[1] = nav->h_pin[1];
 	for (int r = 0; r < world_size; r++) send_counts[r] = recv_counts[r] = 0;
 	nav->nsend = nav->nrecv = 0;
@@ -1339,15 +1428,6 @@ void* phd_migration_send_buffer(phd_navigator* nav, int64_t* bytes_per_particle)
 }
 
 void* phd_migration_recv_buffer(phd_navigator* nav) { return nav ? nav->d_recv : nullptr; }
-
-// Optional, right after phd_step_global_async: copy the slots whose source particle lives on this rank (decided on the
-// device from the global source vector) while the host is still on its way to phd_migration_plan.
-int phd_migration_local_async(phd_navigator* nav, int rank, int world_size)
-{
-	if (!nav) return PHD_ERR_BAD_ARGUMENT;
-	if (world_size < 1 || rank < 0 || rank >= world_size) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_local: bad rank/world");
-	return PHD_OK;   // particles whose source is local are no longer copied at all (see k_unpack_gather): nothing to start early
-}
 
 int phd_migration_pack_async(phd_navigator* nav)
 {

@@ -36,7 +36,7 @@ gw = torch.as_tensor(DevArray(lib.phd_device_global_weights(h, P), P), device="c
 ip = C.POINTER(C.c_int32)
 sc, rc = np.zeros(1, np.int32), np.zeros(1, np.int32)
 empty = torch.empty(0, dtype=torch.float64, device="cuda")
-names = ["local step", "all-gather", "global step", "local gather", "plan (host)", "pack", "all-to-all", "unpack"]
+names = ["local step", "all-gather", "global step", "plan (host)", "pack", "all-to-all", "unpack"]
 acc = np.zeros(len(names))
 
 
@@ -54,11 +54,10 @@ for it in range(N + 3):
     phase(0, lambda: nav._check(lib.phd_step_local_async(h, 0)))
     phase(1, lambda: dist.all_gather_into_tensor(gw, torch.as_tensor(DevArray(lib.phd_device_local_weights(h), P), device="cuda")))
     phase(2, lambda: nav._check(lib.phd_step_global_async(h, 0, 1, 0.5)))
-    phase(3, lambda: nav._check(lib.phd_migration_local_async(h, 0, 1)))
-    phase(4, lambda: nav._check(lib.phd_migration_plan(h, 0, 1, sc.ctypes.data_as(ip), rc.ctypes.data_as(ip))))
-    phase(5, lambda: nav._check(lib.phd_migration_pack_async(h)))
-    phase(6, lambda: dist.all_to_all_single(empty, empty, [0], [0]))
-    phase(7, lambda: nav._check(lib.phd_migration_unpack_async(h)))
+    phase(3, lambda: nav._check(lib.phd_migration_plan(h, 0, 1, sc.ctypes.data_as(ip), rc.ctypes.data_as(ip))))
+    phase(4, lambda: nav._check(lib.phd_migration_pack_async(h)))
+    phase(5, lambda: dist.all_to_all_single(empty, empty, [0], [0]))
+    phase(6, lambda: nav._check(lib.phd_migration_unpack_async(h)))
 for n, a in zip(names, acc):
     print("%-14s %.3f ms" % (n, a / N * 1e3))
 print("sum            %.3f ms" % (acc.sum() / N * 1e3))

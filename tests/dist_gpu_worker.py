@@ -58,8 +58,6 @@ def main():
         dist.all_gather_into_tensor(gw_host, lw)
         dev(lib.phd_device_global_weights(h, Pg), Pg).copy_(gw_host)
         nav._check(lib.phd_step_global_async(h, rank, world, C.c_double(u)))
-        if step % 2 == 0:
-            nav._check(lib.phd_migration_local_async(h, rank, world))
         nav._check(lib.phd_migration_plan(h, rank, world, scounts.ctypes.data_as(ip), rcounts.ctypes.data_as(ip)))
         nav._check(lib.phd_migration_pack_async(h))
         bpp = C.c_int64(0)

@@ -127,8 +127,6 @@ def test_sharded_step_equals_single_handle(world):
         sc, rc, sends, recvs, recs = [], [], [], [], []
         for r, nv in enumerate(navs):
             nv._check(lib.phd_step_global_async(nv._h, r, world, C.c_double(u)))
-            if r % 2 == 1:   # odd ranks take the early device-side copy of their local sources, even ranks the plain path
-                nv._check(lib.phd_migration_local_async(nv._h, r, world))
             s, q = np.zeros(world, np.int32), np.zeros(world, np.int32)
             nv._check(lib.phd_migration_plan(nv._h, r, world, s.ctypes.data_as(ip), q.ctypes.data_as(ip)))
             nv._check(lib.phd_migration_pack_async(nv._h))

@@ -1,0 +1,253 @@
+"""GPU parity cases added in round 2 (through the C-ABI, against the CPU oracle):
+  * BASELINE config A (256 x 128 x 32) at its stated size, the whole step for every particle;
+  * ResampleParticles on weight vectors of 16 384 - 32 768 entries (config C8's global vector; both the LDS-staged and
+    the global-memory branch of k_normalise_resample, and the sizes around the switch);
+  * the setters right behind an asynchronous step (the bank roles rotate on the device);
+  * a failed step (emit capacity) leaves the state as it was;
+  * means and covariances of CorrectConditional bit for bit as the oracle's (the reference's arithmetic is compiled
+    without FP contraction on the device, as the CLR runs it)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import orc
+from monorfs_amd.abi import prm3d_defaults
+from monorfs_amd.synth import CONFIGS, Frame
+
+
+@pytest.fixture(scope="module")
+def nav_mod():
+    from monorfs_amd import navigator
+    return navigator
+
+
+def make_nav(navigator, frame, maxq=600, **over):
+    p = prm3d_defaults(max_particles=frame.P, max_components=max(maxq, frame.C), max_measurements=max(frame.M, 1))
+    p.max_quantity = maxq
+    for k, v in over.items():
+        setattr(p, k, v)
+    nav = navigator.PHDNavigator(p, particlecount=frame.P)
+    nav.upload_state(frame.planes(), frame.counts, frame.poses, frame.weights)
+    return nav, p
+
+
+def oracle_state(f, cap=700):
+    st = orc.State(f.P, cap)
+    st.poses[:] = f.poses
+    st.w[:, :f.C], st.mean[:, :f.C], st.cov[:, :f.C], st.n[:] = f.w, f.mean, f.cov, f.C
+    return st
+
+
+IU = np.triu_indices(3)
+
+
+def assert_map_close(got, exp, rtol, what):
+    (gw, gm, gc), (ew, em, ec) = got, exp
+    assert len(gw) == len(ew), "%s: %d components, oracle has %d" % (what, len(gw), len(ew))
+    assert np.allclose(gw, ew, rtol=rtol, atol=1e-12), what
+    assert np.allclose(gm, em, rtol=rtol, atol=1e-11), what
+    assert np.allclose(gc[:, IU[0], IU[1]], ec[:, IU[0], IU[1]], rtol=rtol, atol=1e-13), what
+
+
+def test_config_A_full_size_step(nav_mod):
+    """BASELINE config A, 256 particles x 128 components x 32 measurements: two full steps, every particle against the
+    oracle (weights 1e-6, resampling sources and BestParticle exact, every map 1e-7, OSPA of the best map 1e-4)."""
+    P, C, M, seed = CONFIGS["A"]
+    f = Frame(P, C, M, seed, weight_profile="steady")
+    nav, p = make_nav(nav_mod, f)
+    st = oracle_state(f)
+    rng = np.random.default_rng(seed)
+    for step in range(2):
+        z = f.z + rng.normal(size=f.z.shape) * np.sqrt([2.0, 2.0, 1e-3]) * 0.2 * step
+        u = float(rng.uniform(0.05, 0.95))
+        best, src, res, _ = orc.slam_update(p, st, z, u=u, threads=8)
+        nav.SlamUpdate(None, z, u_resample=u)
+        gsrc, gres = nav.resample_sources()
+        assert gres == res and np.array_equal(gsrc, src), "step %d: resampling differs" % step
+        assert nav.BestParticle == best
+        assert np.allclose(nav.VehicleWeights, st.weights, rtol=1e-6, atol=1e-300)
+        for i in range(P):
+            assert_map_close(nav.MapModel(i), st.map(i), 1e-7, "step %d map[%d]" % (step, i))
+        glm, _ = orc.best_map_estimate(nav.MapModel(nav.BestParticle))
+        olm, _ = orc.best_map_estimate(st.map(best))
+        d, card = orc.ospa(glm, olm)
+        assert card == 0 and d < 1e-4
+    nav.close()
+
+
+@pytest.mark.parametrize("P", [16384, 18300, 18400, 18432, 20000, 32768])
+def test_resample_large_vectors(nav_mod, P):
+    """ResampleParticles / ParticleDepleted on the global weight vector of a sharded run (C8: 16 384) and beyond, bit-exact
+    against the sequential recurrence: the LDS-staged branch (up to ~18 350 weights beside the kernel's static arrays),
+    the sizes around the switch, and the global-memory branch."""
+    p = prm3d_defaults(max_particles=4, max_components=600, max_measurements=8)
+    nav = nav_mod.PHDNavigator(p, particlecount=4)
+    rng = np.random.default_rng(P)
+    for power, u in ((8, 0.5), (1, 0.25), (30, 0.999999), (2, 1e-12)):
+        w = rng.random(P) ** power
+        w /= w.sum()
+        src, best = nav.ResampleParticles(w, u)
+        osrc, obest = orc.resample(w, u)
+        assert np.array_equal(src, osrc), "P=%d power=%d u=%g: %d sources differ" % (P, power, u, np.count_nonzero(src != osrc))
+        assert best == obest
+        assert nav.ParticleDepleted(w) == orc.particle_depleted(p, w)
+    nav.close()
+
+
+def test_setters_right_behind_an_asynchronous_step(nav_mod):
+    """phd_step_async rotates the bank roles on the device; phd_update_motion / phd_set_poses / phd_set_weights called
+    right behind it (no phd_sync, no getter) must land in the NEW current state. Same sequence with a synchronisation
+    after every call, and the oracle, as the references."""
+    f = Frame(48, 60, 14, 207, weight_profile="steady")
+    rng = np.random.default_rng(3)
+    reading = np.array([0.02, -0.01, 0.03, 0.01, -0.02, 0.015])
+    noise = rng.normal(0, 1, (f.P, 6)) * [5e-3, 5e-3, 5e-3, 2e-4, 2e-4, 2e-4]
+    z2 = f.z + rng.normal(size=f.z.shape) * np.sqrt([2.0, 2.0, 1e-3]) * 0.3
+    neww = rng.uniform(0.5, 1.5, f.P)
+    neww /= neww.sum()
+
+    def run(sync):
+        nav, p = make_nav(nav_mod, f)
+        nav.set_measurements(f.z)
+        nav.step_async(0.37)
+        if sync:
+            nav.sync()
+        nav.UpdateOdometry(None, reading, noise)
+        if sync:
+            nav.sync()
+        nav.set_weights(neww)
+        if sync:
+            nav.sync()
+        nav.set_measurements(z2)
+        nav.step_async(0.61)
+        nav.sync()
+        out = (nav.VehicleWeights, nav.poses(), nav.resample_sources(), [nav.MapModel(i) for i in (0, 17, f.P - 1)], nav.BestParticle)
+        nav.close()
+        return out, p
+
+    (wa, pa, sa, ma, ba), p = run(False)
+    (wb, pb, sb, mb, bb), _ = run(True)
+    assert np.array_equal(wa, wb) and np.array_equal(pa, pb) and np.array_equal(sa[0], sb[0]) and sa[1] == sb[1] and ba == bb
+    for x, y in zip(ma, mb):
+        assert all(np.array_equal(a, b) for a, b in zip(x, y))
+    # and against the oracle
+    st = oracle_state(f)
+    orc.slam_update(p, st, f.z, u=0.37, threads=4)
+    st.poses[:] = orc.update_motion(st.poses, reading, noise, False)
+    st.weights[:] = neww
+    best, src, res, _ = orc.slam_update(p, st, z2, u=0.61, threads=4)
+    assert np.array_equal(sa[0], src) and sa[1] == res and ba == best
+    assert np.allclose(wa, st.weights, rtol=1e-6, atol=1e-300)
+    assert np.allclose(pa, st.poses, rtol=0, atol=1e-14)
+
+    # phd_set_poses the same way
+    nav, p = make_nav(nav_mod, f)
+    nav.set_measurements(f.z)
+    nav.step_async(0.37)
+    poses2 = f.poses.copy()
+    poses2[:, :3] += 0.01
+    nav.set_poses(poses2)           # no synchronisation in between
+    assert np.array_equal(nav.poses(), poses2)
+    nav.close()
+
+
+def test_a_failed_step_leaves_the_state_as_it_was(nav_mod):
+    """A step whose corrected mixture outgrows emit_capacity reports PHD_ERR_CAPACITY and is dropped as a whole: the
+    particle set (weights, poses, maps, BestParticle) is the one before the step — also for a second step queued behind
+    the failed one —, and a step that fits runs from it."""
+    small = Frame(6, 40, 6, 52, weight_profile="steady")
+    p = prm3d_defaults(max_particles=small.P, max_components=600, max_measurements=32)
+    p.emit_capacity = 64
+    p.max_quantity = 64
+    nav = nav_mod.PHDNavigator(p, particlecount=small.P)
+    nav.upload_state(small.planes(), small.counts, small.poses, small.weights)
+    nav.SlamUpdate(None, small.z, u_resample=0.3)           # a step that fits
+
+    def snapshot():
+        return (nav.VehicleWeights, nav.poses(), nav.BestParticle, [nav.MapModel(i) for i in range(small.P)])
+
+    before = snapshot()
+    rng = np.random.default_rng(1)
+    many = np.column_stack([rng.uniform(-300, 300, 32), rng.uniform(-220, 220, 32), rng.uniform(0.3, 1.8, 32)])   # 32 births
+    for attempt in range(2):                                 # twice: the failed phd_sync clears the flag
+        nav.set_measurements(many)
+        nav.step_async(0.5)
+        nav.step_async(0.5)                                  # queued behind the failed one: dropped too
+        with pytest.raises(nav_mod.PHDError) as e:
+            nav.sync()
+        assert e.value.status == 2
+        after = snapshot()
+        assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1]) and before[2] == after[2]
+        for x, y in zip(before[3], after[3]):
+            assert all(np.array_equal(a, b) for a, b in zip(x, y))
+    nav.SlamUpdate(None, small.z[:3], u_resample=0.4)       # the handle still works, from the kept state
+    assert np.isclose(nav.VehicleWeights.sum(), 1.0)
+    nav.close()
+
+
+def test_corrected_means_and_covariances_are_bit_exact(nav_mod):
+    """The measurement model, S^-1, the Kalman gain and update run without FP contraction on the device, in the
+    reference's order of operations: every corrected component's mean and covariance equal the oracle's bit for bit
+    (weights go through exp and the per-measurement sums: 1e-9)."""
+    f = Frame(4, 150, 40, 211, weight_profile="steady")
+    nav, p = make_nav(nav_mod, f)
+    nav.run_stages(f.z, with_alpha=False)
+    for i in range(f.P):
+        pred = orc.predict(p, f.poses[i], f.z, f.map(i))
+        ew, em, ec = orc.correct(p, f.poses[i], f.z, pred)
+        keep = ew >= p.min_weight
+        ew, em, ec = ew[keep], em[keep], ec[keep]
+        gw, gm, gc = nav.CorrectConditional(i)
+        assert len(gw) == len(ew)
+        # pair the two sets by mean (exact match expected), then compare everything
+        index = {m.tobytes(): j for j, m in enumerate(gm)}
+        nexact = 0
+        for k in range(len(ew)):
+            j = index.get(em[k].tobytes())
+            assert j is not None, "particle %d: oracle component %d (w=%g) has no device twin with the same mean bits" % (i, k, ew[k])
+            assert np.array_equal(gc[j][IU], ec[k][IU]), "particle %d component %d: covariance bits differ" % (i, k)
+            assert np.isclose(gw[j], ew[k], rtol=1e-9, atol=0)
+            nexact += gw[j] == ew[k]
+        assert nexact >= np.count_nonzero(ew < 0.2 * f.w[i].max()) // 4   # the misdetection copies inside the field of view: PD = 0.9 exactly
+    nav.close()
+
+
+def test_far_from_the_origin_stage_by_stage(nav_mod):
+    """A scene 2 km from the origin, where Gaussian.Merge's raw second moments (Gaussian.cs:336-344) cost a pruned
+    singleton eps |m|^2 ~ 5e-10 of its covariance entries whatever the machine: each stage is checked on the inputs the
+    device itself produced, so that no stage's tolerance hides behind the conditioning of another.
+      * CorrectConditional: means / covariances bit-exact, weights 1e-9 (as above);
+      * PruneModel + Merge: the oracle's prune of the DEVICE's corrected list equals the device's pruned map to 1e-12
+        (same arithmetic, no contraction: in practice bit for bit);
+      * WeightAlpha: the oracle's alpha for (oracle predicted, DEVICE pruned map) within 1e-6 of the device's."""
+    P, C, M = 4, 50, 14
+    f = Frame(P, C, M, 91, weight_profile="steady")
+    shift = np.array([1500.0, -900.0, 1100.0])
+    f.poses = f.poses.copy()
+    f.poses[:, :3] += shift
+    f.mean = f.mean + shift
+    nav, p = make_nav(nav_mod, f)
+    nav.run_stages(f.z, with_alpha=True)
+    alpha = nav.WeightAlpha()
+    for i in range(P):
+        pred = orc.predict(p, f.poses[i], f.z, f.map(i))
+        ew, em, ec = orc.correct(p, f.poses[i], f.z, pred)
+        keep = ew >= p.min_weight
+        gw, gm, gc = nav.CorrectConditional(i)
+        assert len(gw) == np.count_nonzero(keep)
+        index = {m.tobytes(): j for j, m in enumerate(gm)}
+        order = []
+        for k in np.flatnonzero(keep):                          # the device's list in the reference's (canonical) order
+            j = index.get(em[k].tobytes())
+            assert j is not None and np.array_equal(gc[j][IU], ec[k][IU]) and np.isclose(gw[j], ew[k], rtol=1e-9)
+            order.append(j)
+        dev_corrected = (gw[order], gm[order], ec[keep])        # full covariances from the oracle: equal bits in the upper triangle
+        opr = orc.prune(p, dev_corrected)
+        got = nav.PruneModel(i)
+        assert len(got[0]) == len(opr[0])
+        assert np.allclose(got[0], opr[0], rtol=1e-12) and np.allclose(got[1], opr[1], rtol=1e-13, atol=0)
+        assert np.allclose(got[2][:, IU[0], IU[1]], opr[2][:, IU[0], IU[1]], rtol=1e-9, atol=1e-16)
+        a, _ = orc.weight_alpha(p, f.poses[i], f.z, pred, opr)
+        assert np.isclose(alpha[i], a, rtol=1e-6, atol=0), "alpha[%d]: %r vs %r" % (i, alpha[i], a)
+    nav.close()

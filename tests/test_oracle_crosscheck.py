@@ -250,38 +250,76 @@ def test_weight_alpha_against_second_reading(seed):
     assert np.isclose(got, want, rtol=1e-9, atol=0), (got, want)
 
 
-@pytest.mark.parametrize("seed", range(4))
-def test_prm3d_correct_against_second_reading(seed):
-    """CorrectConditional (PHDNavigator.cs:829-906) for the pixel-range model, one formula at a time in numpy."""
-    rng = np.random.default_rng(400 + seed)
-    p = prm3d_defaults(4, 600, 8)
-    pose, lm, z = random_case(rng, p, 3, 3)
-    pred = random_mixture(rng, lm, 0.3, 1.1)
+def numpy_correct(p, pose, z, pred, by_value):
+    """CorrectConditional (PHDNavigator.cs:829-906) for the pixel-range model, one formula at a time in numpy.
+    by_value: look a near component's arrays up through a dictionary keyed by the component's VALUE, as the reference's
+    `qindex` (a Dictionary<Gaussian, int>, :854, :868, with Gaussian.Equals / GetHashCode comparing weight, mean and
+    covariance exactly, Gaussian.cs:436-489) does: bit-identical components then share the index of the last of them."""
     R = np.array(p.R).reshape(3, 3)
     gate = p.density_distance_threshold               # squared-Euclidean metric by default (Map.Near, :882)
     comps = []
     zh, H, S, PD = [], [], [], []
-    for w, m, P in zip(*pred):
+    qindex = {}
+    for n, (w, m, P) in enumerate(zip(*pred)):
         zh.append(measure_perfect(p, pose, m))
         H.append(jacobian_l(p, pose, m))
         S.append(H[-1] @ P @ H[-1].T + R)
         PD.append(detection_probability_m(p, zh[-1]))
         comps.append(((1 - PD[-1]) * w, m, P))                                        # :837-840
+        qindex[(float(w), m.tobytes(), P.tobytes())] = n                              # :868
     for zk in z:
         x = measure_to_map(p, pose, zk)
         near = [n for n in range(len(pred[0])) if np.sum((x - pred[1][n]) ** 2) <= gate]
-        q = {n: multiplier(S[n]) * np.exp(-0.5 * (zk - zh[n]) @ np.linalg.inv(S[n]) @ (zk - zh[n])) for n in near}
-        weightsum = sum(PD[n] * pred[0][n] * q[n] for n in near)                      # :886-890
-        for n in near:
+        if by_value:
+            near = [qindex[(float(pred[0][n]), pred[1][n].tobytes(), pred[2][n].tobytes())] for n in near]   # int i = qindex[landmark]
+        q = [multiplier(S[n]) * np.exp(-0.5 * (zk - zh[n]) @ np.linalg.inv(S[n]) @ (zk - zh[n])) for n in near]
+        weightsum = sum(PD[n] * pred[0][n] * qn for n, qn in zip(near, q))            # :886-890
+        for n, qn in zip(near, q):
             K = pred[2][n] @ H[n].T @ np.linalg.inv(S[n])
-            comps.append((PD[n] * pred[0][n] * q[n] / (p.clutter_density + weightsum),   # :899
+            comps.append((PD[n] * pred[0][n] * qn / (p.clutter_density + weightsum),  # :899
                           pred[1][n] + K @ (zk - zh[n]), (np.eye(3) - K @ H[n]) @ pred[2][n]))
+    return comps
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_prm3d_correct_against_second_reading(seed):
+    rng = np.random.default_rng(400 + seed)
+    p = prm3d_defaults(4, 600, 8)
+    pose, lm, z = random_case(rng, p, 3, 3)
+    pred = random_mixture(rng, lm, 0.3, 1.1)
+    comps = numpy_correct(p, pose, z, pred, by_value=False)
     ow, om, oc = orc.correct(p, pose, z, pred)
     assert len(ow) == len(comps)
     for i, (w, m, P) in enumerate(comps):
         assert np.isclose(ow[i], w, rtol=1e-9, atol=1e-300), (i, ow[i], w)
         assert np.allclose(om[i], m, rtol=1e-9, atol=1e-12)
         assert np.allclose(oc[i], P, rtol=1e-8, atol=1e-14)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_qindex_by_value_aliases_only_equal_numbers(seed):
+    """The reference finds a near component's cached arrays through `qindex`, a dictionary keyed by the Gaussian's VALUE
+    (PHDNavigator.cs:854, :868; Gaussian.cs:436-489): two bit-identical components (two births from a measurement reported
+    twice) both resolve to the LAST of them. Every cached array is a deterministic function of (weight, mean, covariance,
+    pose), so the aliased index holds the very numbers the own index would: the corrected map is the same, entry for
+    entry, as with the positional indices the oracle and the device use. Shown here on a mixture with a duplicated
+    component and a duplicated measurement: by-value and positional readings agree exactly, and with the oracle."""
+    rng = np.random.default_rng(450 + seed)
+    p = prm3d_defaults(4, 600, 8)
+    pose, lm, z = random_case(rng, p, 3, 3)
+    w, m, P = random_mixture(rng, lm, 0.3, 1.1)
+    pred = (np.concatenate([w, w[1:2]]), np.concatenate([m, m[1:2]]), np.concatenate([P, P[1:2]]))   # component 1 twice
+    z = np.concatenate([z, z[:1]])                                                                  # measurement 0 twice
+    a = numpy_correct(p, pose, z, pred, by_value=True)
+    b = numpy_correct(p, pose, z, pred, by_value=False)
+    assert len(a) == len(b)
+    for (wa, ma, Pa), (wb, mb, Pb) in zip(a, b):
+        assert wa == wb and np.array_equal(ma, mb) and np.array_equal(Pa, Pb)
+    ow, om, oc = orc.correct(p, pose, z, pred)
+    assert len(ow) == len(a)
+    for i, (wi, mi, Pi) in enumerate(a):
+        assert np.isclose(ow[i], wi, rtol=1e-9, atol=1e-300) and np.allclose(om[i], mi, rtol=1e-9, atol=1e-12)
+        assert np.allclose(oc[i], Pi, rtol=1e-8, atol=1e-14)
 
 
 def _qexp(w):
