@@ -39,9 +39,11 @@ extern "C" {
 #define PHD_OK                    0
 #define PHD_ERR_GENERIC          -1
 #define PHD_ERR_BAD_ARGUMENT      1   /* a size/pointer/flag is out of range                        */
-#define PHD_ERR_CAPACITY          2   /* a mixture outgrew its slab (raise max_components/emit_cap) */
-#define PHD_ERR_ASSOCIATION       3   /* data-association cluster beyond the on-device solver's cap;
-                                         surfaces as Data["module"]="association" (Simulation.cs:666) */
+#define PHD_ERR_CAPACITY          2   /* a mixture outgrew its slab (raise max_components/emit_cap); the step is dropped,
+                                         the state is the one before it                              */
+#define PHD_ERR_ASSOCIATION       3   /* a data-association cluster of more than 256 rows, or the clusters beyond 64 rows
+                                         used up the association workspace; surfaces as Data["module"]="association"
+                                         (Simulation.cs:666). The step is dropped, the state is the one before it.   */
 #define PHD_ERR_DEVICE            4   /* HIP runtime error, see phd_last_error                       */
 #define PHD_ERR_NO_DEVICE         5   /* no gfx950 device / HIP runtime unavailable                  */
 
@@ -141,6 +143,11 @@ int phd_slam_update(phd_navigator* nav, const double* z3, int nmeasurements,
 int phd_set_measurements(phd_navigator* nav, const double* z3, int nmeasurements);
 int phd_step_async(phd_navigator* nav, uint8_t onlymapping, double u_resample);
 int phd_sync(phd_navigator* nav);
+/* Workspace of the set log-likelihood for data-association clusters of 65 .. 256 rows (MurtyPairing, GraphCombinatorics.cs:
+ * 241-272, has no size limit; clusters of up to 64 rows work in a per-particle block and never fail): one slab per handle,
+ * 128 MiB by default, about 0.4 MB per cluster of 128 rows and 1.3 MB per cluster of 256 in one step. When a step runs out
+ * of it (PHD_ERR_ASSOCIATION) the state is kept: raise it here and run the step again.                                */
+int phd_set_association_workspace(phd_navigator* nav, int64_t bytes);
 /* Benchmark aid: when frozen, a step reads the current state but does not replace it, so every
  * step sees identical input sizes (SURVEY §8d "steady state").                                   */
 int phd_set_frozen(phd_navigator* nav, uint8_t frozen);
@@ -236,7 +243,7 @@ int phd_quasi_set_loglik_grad(phd_navigator* nav, const double* poses7, int npos
                               const double* z3, int nmeasurements, int average_mode, double* out, double* gradients6);
 
 /* Test surface for the assignment enumerators the set log-likelihood runs on the device: MurtyPairing (mode 0,
- * GraphCombinatorics.cs:241-272; n <= 32) or LexicographicalPairing(matrix, modelsize) (mode 1, :280-334; n <= 5) on a
+ * GraphCombinatorics.cs:241-272; n <= 256) or LexicographicalPairing(matrix, modelsize) (mode 1, :280-334; n <= 5) on a
  * dense n x n profit matrix (row-major, -inf = no entry). assignments[k][n] (row -> column; -1: an unsolved first node),
  * values[k] for the first min(count, maxcount) pairings in the order they are produced; *count = how many there are
  * (at most 200, the length of the reference's logcomp). The vectors of GraphCombinatoricsTest.cs go through this.  */

@@ -72,6 +72,7 @@ def load():
         "phd_step_async": (C.c_int, [P, C.c_uint8, C.c_double]),
         "phd_sync": (C.c_int, [P]),
         "phd_set_frozen": (C.c_int, [P, C.c_uint8]),
+        "phd_set_association_workspace": (C.c_int, [P, C.c_int64]),
         "phd_update_motion": (C.c_int, [P, dp, dp, C.c_int, C.c_uint8]),
         "phd_quasi_set_loglik": (C.c_int, [P, dp, C.c_int, dp, C.c_int, dp, C.c_int, dp]),
         "phd_quasi_set_loglik_grad": (C.c_int, [P, dp, C.c_int, dp, C.c_int, dp, C.c_int, C.c_int, dp, dp]),
@@ -113,7 +114,7 @@ def load():
 
 EXPORTS = ["phd_api_version", "phd_default_params", "phd_create", "phd_create_error", "phd_destroy", "phd_last_error",
            "phd_reset", "phd_set_poses", "phd_set_weights", "phd_set_map", "phd_slam_update", "phd_set_measurements",
-           "phd_step_async", "phd_sync", "phd_set_frozen", "phd_update_motion", "phd_quasi_set_loglik", "phd_quasi_set_loglik_grad", "phd_test_pairing", "phd_set_split", "phd_weights", "phd_best_particle", "phd_poses",
+           "phd_step_async", "phd_sync", "phd_set_frozen", "phd_set_association_workspace", "phd_update_motion", "phd_quasi_set_loglik", "phd_quasi_set_loglik_grad", "phd_test_pairing", "phd_set_split", "phd_weights", "phd_best_particle", "phd_poses",
            "phd_particle_count", "phd_map", "phd_resample_sources", "phd_stage_run", "phd_stage_map", "phd_stage_alpha",
            "phd_stage_setloglik", "phd_resample", "phd_particle_depleted", "phd_step_local_async",
            "phd_device_local_weights", "phd_device_global_weights", "phd_step_global_async", "phd_migration_plan",

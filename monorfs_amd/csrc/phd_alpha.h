@@ -96,19 +96,83 @@ __device__ double cluster_enumerate(const double* mat, int ms, int n, int models
 }
 
 // ---- clusters with more than 5 rows: MurtyPairing (GraphCombinatorics.cs:241-272) run by one wave ----
-#define MURTY_NMAX 32     // rows of the largest cluster solved on the device
-#define MURTY_OUT  200    // logcomp.Length (PHDNavigator.cs:469)
-#define MURTY_POOL 208    // frontier (<= 201 live entries) + the node being expanded + its child
+// Lane l owns rows and columns l, l + 64, ... (NT of each, in registers): clusters of up to 64 rows (NT = 1) work in
+// the particle's own workspace, larger ones (NT = 2: <= 128 rows, NT = 4: <= 256) in a block taken from the handle's
+// association slab (StepBufs::bigws). The reference has no size limit; a 256-row cluster costs it 200 x 255 Hungarian
+// solutions of 256^3 steps each — beyond that the step fails with PHD_ERR_ASSOCIATION (the state is kept).
+#define MURTY_NMAX  64    // rows of a cluster solved in the per-particle workspace
+#define MURTY_NBIG  256   // rows of the largest cluster solved at all (column indices are bytes)
+#define MURTY_OUT   200   // logcomp.Length (PHDNavigator.cs:469)
+#define MURTY_POOL  208   // frontier (<= 201 live entries) + the node being expanded + its child
+#define MURTY_ELCAP 208   // eliminated edges a node can hold: one per generation, at most MURTY_OUT generations
 
-struct MurtyNodes {       // per-particle workspace in HBM, touched only when such a cluster exists
-	unsigned char asg[MURTY_POOL][MURTY_NMAX];    // assignment (row -> column)
-	unsigned int  elim[MURTY_POOL][MURTY_NMAX];   // eliminated columns of every row, as a bit mask
-	unsigned int  forced[MURTY_POOL];             // forced rows; a forced edge is (row, asg[row])
-	double        profit[MURTY_NMAX * MURTY_NMAX];    // the cluster's matrix
-	double        reduced[MURTY_NMAX * MURTY_NMAX];   // and the copy a child node solves on
-	double        dvec[MURTY_OUT][6];                 // gradient mode: dlogcompdp of the enumerated pairings (PHDNavigator.cs:675)
-	double        jp[MURTY_NMAX][18];                 // gradient mode: MeasurementJacobianP of the cluster's landmarks
+struct MurtyNodes {       // per-particle workspace in HBM, touched only when a cluster of more than 5 rows exists
+	unsigned char      asg[MURTY_POOL * MURTY_NMAX];     // assignment (row -> column) of every node
+	unsigned long long forced[MURTY_POOL];               // forced rows (bit = row); a forced edge is (row, asg[row])
+	unsigned short     elist[MURTY_POOL * MURTY_ELCAP];  // eliminated edges, row << 8 | column
+	int                nelim[MURTY_POOL];
+	double             profit[MURTY_NMAX * MURTY_NMAX];  // the cluster's matrix
+	double             reduced[MURTY_NMAX * MURTY_NMAX]; // and the copy a child node solves on
+	double             dvec[MURTY_OUT][6];               // gradient mode: dlogcompdp of the enumerated pairings (PHDNavigator.cs:675)
+	double             jp[MURTY_NMAX * 18];              // gradient mode: MeasurementJacobianP of the cluster's landmarks
+	int                L[MURTY_NMAX], Z[MURTY_NMAX];     // the cluster's landmarks / measurements (test surface: unused)
 };
+
+// The same arrays for a cluster of n rows, wherever they live (`stride` = row capacity of asg).
+struct MurtyWs {
+	unsigned char*      asg;
+	unsigned long long* forced;    // [POOL][NT]
+	unsigned short*     elist;
+	int*                nelim;
+	double*             profit;
+	double*             reduced;
+	double*             jp;
+	int*                L;
+	int*                Z;
+	int                 stride;
+};
+
+__device__ __forceinline__ MurtyWs murty_ws_particle(MurtyNodes* nd)
+{
+	MurtyWs w;
+	w.asg = nd->asg; w.forced = nd->forced; w.elist = nd->elist; w.nelim = nd->nelim;
+	w.profit = nd->profit; w.reduced = nd->reduced; w.jp = nd->jp; w.L = nd->L; w.Z = nd->Z;
+	w.stride = MURTY_NMAX;
+	return w;
+}
+
+// bytes of a slab block for a cluster of n rows (multiple of 16)
+__host__ __device__ inline size_t murty_big_bytes(int n)
+{
+	const size_t nt = (size_t) ((n + 63) / 64);
+	size_t b = 0;
+	b += 2 * (size_t) n * n * 8;                 // profit, reduced
+	b += (size_t) n * 18 * 8;                    // jp
+	b += (size_t) MURTY_POOL * nt * 8;           // forced
+	b += (size_t) MURTY_POOL * 4;                // nelim
+	b += 2 * (size_t) n * 4;                     // L, Z
+	b += (size_t) MURTY_POOL * MURTY_ELCAP * 2;  // elist
+	b += (size_t) MURTY_POOL * n;                // asg
+	return (b + 63) & ~(size_t) 63;
+}
+
+__device__ __forceinline__ MurtyWs murty_ws_carve(char* base, int n)
+{
+	const size_t nt = (size_t) ((n + 63) / 64);
+	MurtyWs w;
+	char* q = base;
+	w.profit  = (double*) q; q += (size_t) n * n * 8;
+	w.reduced = (double*) q; q += (size_t) n * n * 8;
+	w.jp      = (double*) q; q += (size_t) n * 18 * 8;
+	w.forced  = (unsigned long long*) q; q += (size_t) MURTY_POOL * nt * 8;
+	w.nelim   = (int*) q; q += (size_t) MURTY_POOL * 4;
+	w.L       = (int*) q; q += (size_t) n * 4;
+	w.Z       = (int*) q; q += (size_t) n * 4;
+	w.elist   = (unsigned short*) q; q += (size_t) MURTY_POOL * MURTY_ELCAP * 2;
+	w.asg     = (unsigned char*) q;
+	w.stride  = n;
+	return w;
+}
 
 __device__ __forceinline__ double wave_min(double v)
 {
@@ -117,101 +181,161 @@ __device__ __forceinline__ double wave_min(double v)
 	return v;
 }
 
-__device__ __forceinline__ unsigned int wave_or(unsigned int v)
-{
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) v |= (unsigned int) __shfl_xor((int) v, o, 64);
-	return v;
-}
-
 __device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 
-// Hungarian (GraphCombinatorics.cs:64-175) with lane i owning row i (labelx, matchx, visitx) and
-// column i (labely, matchy, visity, slack, parent). Every arithmetic step is the serial algorithm's,
-// the argmin keeps its first-minimum tie-break, so the assignment is the reference's.
-__device__ bool wave_hungarian(const double* mat, int n, int lane, int& matchx_out)
+// entry `idx` (wave-uniform) of an array spread as element lane + 64 t in x[t]
+template <int NT>
+__device__ __forceinline__ double spread_get(const double (&x)[NT], int idx)
 {
-	const bool active = lane < n;
-	double labelx = 0, labely = 0, slack = INFINITY;
-	int matchx = -1, matchy = -1, parent = 0;
-	if (active) {
+	double v = x[0];
+#pragma unroll
+	for (int t = 1; t < NT; t++) v = ((idx >> 6) == t) ? x[t] : v;
+	return __shfl(v, idx & 63, 64);
+}
+
+template <int NT>
+__device__ __forceinline__ int spread_get(const int (&x)[NT], int idx)
+{
+	int v = x[0];
+#pragma unroll
+	for (int t = 1; t < NT; t++) v = ((idx >> 6) == t) ? x[t] : v;
+	return __shfl(v, idx & 63, 64);
+}
+
+template <int NT>
+__device__ __forceinline__ void spread_set(int (&x)[NT], int idx, int val, int lane)
+{
+#pragma unroll
+	for (int t = 0; t < NT; t++) {
+		if (lane == (idx & 63) && (idx >> 6) == t) x[t] = val;
+	}
+}
+
+// Hungarian (GraphCombinatorics.cs:64-175) with lane l owning rows l + 64 t (labelx, matchx, visitx) and columns l + 64 t
+// (labely, matchy, visity, slack, parent). Every arithmetic step is the serial algorithm's, the argmin keeps its
+// first-minimum tie-break (smallest index: t first, then the lane), so the assignment is the reference's.
+template <int NT>
+__device__ bool wave_hungarian(const double* mat, int n, int lane, int (&matchx_out)[NT])
+{
+	double labelx[NT], labely[NT], slack[NT];
+	int    matchx[NT], matchy[NT], parent[NT];
+	bool   act[NT];
+#pragma unroll
+	for (int t = 0; t < NT; t++) {
+		const int i = lane + 64 * t;
+		act[t] = i < n;
 		double f = 0;   // FoldRows(Math.Max, 0)
-		for (int k = 0; k < n; k++) f = fmax(f, mat[lane * n + k]);
-		labelx = f;
+		if (act[t]) {
+			for (int k = 0; k < n; k++) f = fmax(f, mat[i * n + k]);
+		}
+		labelx[t] = f; labely[t] = 0; slack[t] = INFINITY;
+		matchx[t] = -1; matchy[t] = -1; parent[t] = 0;
 	}
 	for (;;) {
-		unsigned long long um = __ballot(active && matchx == -1);
-		if (!um) break;
-		const int root = __ffsll((long long) um) - 1;
-		const double lxr = __shfl(labelx, root, 64);
-		parent = root;
-		slack = active ? (lxr + labely - mat[root * n + lane]) : INFINITY;
-		bool visitx = lane == root, visity = false;
+		int root = -1;   // Array.IndexOf(matchx, -1)
+#pragma unroll
+		for (int t = 0; t < NT; t++) {
+			const unsigned long long um = __ballot(act[t] && matchx[t] == -1);
+			if (root < 0 && um) root = 64 * t + __ffsll((long long) um) - 1;
+		}
+		if (root < 0) break;
+		const double lxr = spread_get<NT>(labelx, root);
+		unsigned int visitx = 0, visity = 0;   // bit t <-> row / column lane + 64 t
+#pragma unroll
+		for (int t = 0; t < NT; t++) {
+			parent[t] = root;
+			slack[t] = act[t] ? (lxr + labely[t] - mat[root * n + lane + 64 * t]) : INFINITY;
+			if (lane == (root & 63) && (root >> 6) == t) visitx |= 1u << t;
+		}
 		int imin = 0;
 		for (;;) {
-			double val = (active && !visity) ? slack : INFINITY;
-			double delta = wave_min(val);
+			double val = INFINITY;
+#pragma unroll
+			for (int t = 0; t < NT; t++) {
+				if (act[t] && !((visity >> t) & 1u) && slack[t] < val) val = slack[t];
+			}
+			const double delta = wave_min(val);
 			if (isinf(delta) && delta > 0) return false;   // no solution
-			imin = __ffsll((long long) __ballot(active && !visity && val == delta)) - 1;
-			if (visitx) labelx -= delta;
-			if (active) {
-				if (visity) labely += delta;
-				else slack -= delta;
+			imin = -1;
+#pragma unroll
+			for (int t = 0; t < NT; t++) {
+				const unsigned long long bal = __ballot(act[t] && !((visity >> t) & 1u) && slack[t] == delta);
+				if (imin < 0 && bal) imin = 64 * t + __ffsll((long long) bal) - 1;
 			}
-			if (lane == imin) visity = true;
-			const int my = __shfl(matchy, imin, 64);
+#pragma unroll
+			for (int t = 0; t < NT; t++) {
+				if ((visitx >> t) & 1u) labelx[t] -= delta;
+				if (act[t]) {
+					if ((visity >> t) & 1u) labely[t] += delta;
+					else slack[t] -= delta;
+				}
+			}
+			if (lane == (imin & 63)) visity |= 1u << (imin >> 6);
+			const int my = spread_get<NT>(matchy, imin);
 			if (my == -1) break;
-			if (lane == my) visitx = true;
-			const double lxm = __shfl(labelx, my, 64);
-			if (active && !visity) {
-				double md = lxm + labely - mat[my * n + lane];
-				if (md < slack) { slack = md; parent = my; }
+			if (lane == (my & 63)) visitx |= 1u << (my >> 6);
+			const double lxm = spread_get<NT>(labelx, my);
+#pragma unroll
+			for (int t = 0; t < NT; t++) {
+				if (act[t] && !((visity >> t) & 1u)) {
+					const double md = lxm + labely[t] - mat[my * n + lane + 64 * t];
+					if (md < slack[t]) { slack[t] = md; parent[t] = my; }
+				}
 			}
 		}
-		int py = imin, px = __shfl(parent, py, 64);
+		int py = imin, px = spread_get<NT>(parent, py);
 		while (px != root) {
-			int ty = __shfl(matchx, px, 64);
-			if (lane == px) matchx = py;
-			if (lane == py) matchy = px;
+			const int ty = spread_get<NT>(matchx, px);
+			spread_set<NT>(matchx, px, py, lane);
+			spread_set<NT>(matchy, py, px, lane);
 			py = ty;
-			px = __shfl(parent, py, 64);
+			px = spread_get<NT>(parent, py);
 		}
-		if (lane == px) matchx = py;
-		if (lane == py) matchy = px;
+		spread_set<NT>(matchx, px, py, lane);
+		spread_set<NT>(matchy, py, px, lane);
 	}
-	matchx_out = matchx;
+#pragma unroll
+	for (int t = 0; t < NT; t++) matchx_out[t] = matchx[t];
 	return true;
 }
 
 // AssignmentValue (GraphCombinatorics.cs:183-197), summed in row order
-__device__ __forceinline__ double wave_assignment_value(const double* profit, int n, int matchx)
+template <int NT>
+__device__ __forceinline__ double wave_assignment_value(const double* profit, int n, const int (&matchx)[NT])
 {
 	double total = 0;
-	for (int i = 0; i < n; i++) total += profit[i * n + __shfl(matchx, i, 64)];
+	for (int i = 0; i < n; i++) total += profit[i * n + spread_get<NT>(matchx, i)];
 	return total;
 }
 
-// scratch of the Murty path: the two matrices in the particle's HBM workspace (such clusters are rare, LDS is
-// better spent on occupancy), the rest in LDS
+// LDS scratch of the Murty path (the matrices and the nodes live in HBM: such clusters are rare, LDS is better spent
+// on occupancy)
 struct MurtyLds {
-	double* profit;    // [NMAX*NMAX]
-	double* reduced;   // [NMAX*NMAX]
 	double* logcomp;   // [MURTY_OUT]
 	double* fkey;      // [MURTY_POOL] frontier priorities, ascending
 	int*    fnode;     // [MURTY_POOL] frontier node slots
 	int*    freelist;  // [MURTY_POOL]
-	int*    L;         // [NMAX]
-	int*    Z;         // [NMAX]
 };
-#define MURTY_LDS_DOUBLES (MURTY_OUT + MURTY_POOL + (2 * MURTY_POOL + 2 * MURTY_NMAX + 1) / 2)
+#define MURTY_LDS_DOUBLES (MURTY_OUT + MURTY_POOL + (2 * MURTY_POOL + 1) / 2)
+
+__device__ __forceinline__ MurtyLds murty_lds(double* base)
+{
+	MurtyLds ws;
+	ws.logcomp  = base;
+	ws.fkey     = ws.logcomp + MURTY_OUT;
+	ws.fnode    = (int*) (ws.fkey + MURTY_POOL);
+	ws.freelist = ws.fnode + MURTY_POOL;
+	return ws;
+}
 
 // Enumerate the pairings of one cluster best-first and record their values into logcomp exactly as
 // the loop of SetLogLikelihood does (PHDNavigator.cs:501-509), including its read of the stale
 // logcomp[m] left by earlier clusters. Returns the number of values written. Wave-uniform.
-template <class Hook>
-__device__ __noinline__ int wave_murty(const MurtyLds& ws, MurtyNodes* nodes, int n, int lane, Hook hook)
+// hook(m, unsolved, colof): the pairing recorded at index m; colof(row) = its column (wave-uniform row).
+template <int NT, class Hook>
+__device__ __noinline__ int wave_murty(const MurtyLds& ws, const MurtyWs& nd, int n, int lane, Hook hook)
 {
-	const double* profit = ws.profit;
+	const double* profit = nd.profit;
 	int nfree = 0;
 	if (lane == 0) {
 		for (int i = 0; i < MURTY_POOL; i++) ws.freelist[i] = MURTY_POOL - 1 - i;
@@ -268,7 +392,7 @@ __device__ __noinline__ int wave_murty(const MurtyLds& ws, MurtyNodes* nodes, in
 				if (idx >= 1 && idx < fsize) { ws.fkey[idx - 1] = kreg[u]; ws.fnode[idx - 1] = nreg[u]; }
 			}
 			fsize--;
-			if (lane == 0) ws.freelist[nfree] = dropped;
+			if (lane == 0) ws.freelist[nfree] = dropped & 0xffff;
 			nfree++;
 			lds_fence();
 		}
@@ -277,19 +401,39 @@ __device__ __noinline__ int wave_murty(const MurtyLds& ws, MurtyNodes* nodes, in
 		nfree--;
 		return ws.freelist[nfree];
 	};
+	// node `slot` <- assignment mx, forced rows (bit t of `fr` <-> row lane + 64 t), eliminated edges: those of node
+	// `parent` (none when < 0) and (er, ec) when er >= 0
+	auto store_node = [&](int slot, const int (&mx)[NT], unsigned int fr, int parent, int er, int ec) {
+#pragma unroll
+		for (int t = 0; t < NT; t++) {
+			const int i = lane + 64 * t;
+			if (i < n) nd.asg[(size_t) slot * nd.stride + i] = (unsigned char) mx[t];
+			const unsigned long long w = __ballot((fr >> t) & 1u);
+			if (lane == 0) nd.forced[slot * NT + t] = w;
+		}
+		int ne = 0;
+		if (parent >= 0) {
+			ne = nd.nelim[parent];
+			for (int e = lane; e < ne; e += 64) nd.elist[slot * MURTY_ELCAP + e] = nd.elist[parent * MURTY_ELCAP + e];
+		}
+		if (lane == 0) {
+			if (er >= 0 && ne < MURTY_ELCAP) nd.elist[slot * MURTY_ELCAP + ne] = (unsigned short) ((er << 8) | ec);
+			nd.nelim[slot] = ne + ((er >= 0 && ne < MURTY_ELCAP) ? 1 : 0);
+		}
+		__threadfence_block();
+	};
 
 	// first node: no forced, no eliminated edges
 	{
 		int slot = alloc();
-		int mx;
-		bool solved = wave_hungarian(profit, n, lane, mx);
-		if (lane < n) {
-			nodes->asg[slot][lane]  = (unsigned char) (solved ? mx : 0);
-			nodes->elim[slot][lane] = 0;
+		int mx[NT];
+		bool solved = wave_hungarian<NT>(profit, n, lane, mx);
+		if (!solved) {
+#pragma unroll
+			for (int t = 0; t < NT; t++) mx[t] = 0;
 		}
-		if (lane == 0) nodes->forced[slot] = 0;
-		__threadfence_block();
-		double value = solved ? wave_assignment_value(profit, n, mx) : -INFINITY;
+		store_node(slot, mx, 0u, -1, -1, 0);
+		double value = solved ? wave_assignment_value<NT>(profit, n, mx) : -INFINITY;
 		// an unsolved first node is yielded with value -inf and has no children (GraphCombinatorics.cs:245-249,473)
 		frontier_add(value, solved ? slot : (slot | 0x10000));
 	}
@@ -302,68 +446,97 @@ __device__ __noinline__ int wave_murty(const MurtyLds& ws, MurtyNodes* nodes, in
 		// foreach body of SetLogLikelihood (PHDNavigator.cs:502-509)
 		if (m >= MURTY_OUT || (ws.logcomp[m] - ws.logcomp[0] < -10)) break;
 		if (lane == 0) ws.logcomp[m] = value;
-		hook(m, code);                  // the pairing recorded at index m: nodes->asg[code] (code & 0x10000: unsolved)
+		const int slot = code & 0xffff;
+		hook(m, (code & 0x10000) != 0, [&](int row) { return (int) nd.asg[(size_t) slot * nd.stride + row]; });
 		m++;
 		lds_fence();
 		if (code & 0x10000) continue;   // unsolved: no children
-		const int slot = code;
 		// children (MurtyNode.Children, GraphCombinatorics.cs:469-509)
-		const int pa = (lane < n) ? nodes->asg[slot][lane] : 0;
-		const unsigned int pelim = (lane < n) ? nodes->elim[slot][lane] : 0u;
-		const unsigned int pforced = nodes->forced[slot];
-		const unsigned int rowsmask = (n >= 32) ? 0xffffffffu : ((1u << n) - 1u);
-		unsigned int remaining = ~pforced & rowsmask;
-		const int R = __popc(remaining);
-		unsigned int extra = 0;   // rows forced on top of the parent's: remaining[0 .. c-1]
+		int pa[NT];
+		unsigned int fr = 0, fc = 0;             // forced rows / forced columns of the child being built (bit t <-> lane + 64 t)
+		unsigned long long rem[NT];              // rows the parent does not force (wave-uniform)
+		int R = 0;
+#pragma unroll
+		for (int t = 0; t < NT; t++) {
+			const int i = lane + 64 * t;
+			pa[t] = (i < n) ? nd.asg[(size_t) slot * nd.stride + i] : 0;
+			const unsigned long long fw = nd.forced[slot * NT + t];
+			if ((fw >> lane) & 1ull) fr |= 1u << t;
+			const int left = n - 64 * t;
+			const unsigned long long rows = (left >= 64) ? ~0ull : ((left <= 0) ? 0ull : ((1ull << left) - 1ull));
+			rem[t] = ~fw & rows;
+			R += __popcll(rem[t]);
+		}
+		// forced columns = columns of the forced rows (reduceprofit, GraphCombinatorics.cs:206-234)
+#pragma unroll
+		for (int t = 0; t < NT; t++) {
+			unsigned long long fw = __ballot((fr >> t) & 1u);
+			while (fw) {
+				const int l = __ffsll((long long) fw) - 1;
+				fw &= fw - 1;
+				const int col = __shfl(pa[t], l, 64);
+				if (lane == (col & 63)) fc |= 1u << (col >> 6);
+			}
+		}
+		const int pne = nd.nelim[slot];
 		for (int c = 0; c < R - 1; c++) {
-			const int er = __ffs((int) remaining) - 1;   // remaining[c]
-			remaining &= remaining - 1;
-			const int ec = __shfl(pa, er, 64);
-			const unsigned int cforced = pforced | extra;
-			// reduceprofit (GraphCombinatorics.cs:206-234)
-			unsigned int fcols = wave_or((lane < n && ((cforced >> lane) & 1u)) ? (1u << pa) : 0u);
-			for (int e0 = 0; e0 < n * n; e0 += 64) {   // uniform trip count: every lane takes part in the shuffle
-				const int  e  = e0 + lane;
-				const bool in = e < n * n;
-				const int  i  = in ? e / n : 0, k = e - i * n;
-				const int  pai = __shfl(pa, i, 64);
-				if (in) {
-					double v = profit[e];
-					if ((cforced >> i) & 1u) v = (k == pai) ? 1.0 : -INFINITY;
-					else if ((fcols >> k) & 1u) v = -INFINITY;
-					ws.reduced[e] = v;
+			int er = -1;   // remaining[c]
+#pragma unroll
+			for (int t = 0; t < NT; t++) {
+				if (er < 0 && rem[t]) {
+					er = 64 * t + __ffsll((long long) rem[t]) - 1;
+					rem[t] &= rem[t] - 1;
 				}
 			}
-			lds_fence();
+			const int ec = spread_get<NT>(pa, er);
+			// reduceprofit: a forced row keeps 1 on its edge and nothing else, the other rows lose the forced columns
+			for (int i = 0; i < n; i++) {
+				const int  pai = spread_get<NT>(pa, i);
+				const bool fi  = __shfl((int) fr, i & 63, 64) & (1 << (i >> 6));
+#pragma unroll
+				for (int t = 0; t < NT; t++) {
+					const int k = lane + 64 * t;
+					if (k < n) {
+						double v = profit[i * n + k];
+						if (fi) v = (k == pai) ? 1.0 : -INFINITY;
+						else if ((fc >> t) & 1u) v = -INFINITY;
+						nd.reduced[i * n + k] = v;
+					}
+				}
+			}
+			__threadfence_block();
 			// eliminated edges: the parent's and (er, ec)
-			if (lane < n) {
-				unsigned int em = pelim | ((lane == er) ? (1u << ec) : 0u);
-				while (em) {
-					int k = __ffs((int) em) - 1;
-					em &= em - 1;
-					ws.reduced[lane * n + k] = -INFINITY;
-				}
+			for (int e = lane; e < pne; e += 64) {
+				const int ed = nd.elist[slot * MURTY_ELCAP + e];
+				nd.reduced[(ed >> 8) * n + (ed & 255)] = -INFINITY;
 			}
-			lds_fence();
-			int mx;
-			bool solved = wave_hungarian(ws.reduced, n, lane, mx);
+			if (lane == 0) nd.reduced[er * n + ec] = -INFINITY;
+			__threadfence_block();
+			int mx[NT];
+			const bool solved = wave_hungarian<NT>(nd.reduced, n, lane, mx);
 			if (solved) {
-				int cs = alloc();
-				if (lane < n) {
-					nodes->asg[cs][lane]  = (unsigned char) mx;
-					nodes->elim[cs][lane] = pelim | ((lane == er) ? (1u << ec) : 0u);
-				}
-				if (lane == 0) nodes->forced[cs] = cforced;
-				__threadfence_block();
-				frontier_add(wave_assignment_value(profit, n, mx), cs);
+				const int cs = alloc();
+				store_node(cs, mx, fr, slot, er, ec);
+				frontier_add(wave_assignment_value<NT>(profit, n, mx), cs);
 			}
-			extra |= 1u << er;
+			// the next child also forces (er, ec)
+			if (lane == (er & 63)) fr |= 1u << (er >> 6);
+			if (lane == (ec & 63)) fc |= 1u << (ec >> 6);
 		}
 		if (lane == 0) ws.freelist[nfree] = slot;
 		nfree++;
 		lds_fence();
 	}
 	return m;
+}
+
+// the same for any cluster size the solver takes: the number of rows picks the register layout
+template <class Hook>
+__device__ __forceinline__ int wave_murty_any(const MurtyLds& ws, const MurtyWs& nd, int n, int lane, Hook hook)
+{
+	if (n <= 64) return wave_murty<1>(ws, nd, n, lane, hook);
+	if (n <= 128) return wave_murty<2>(ws, nd, n, lane, hook);
+	return wave_murty<4>(ws, nd, n, lane, hook);
 }
 
 // ---- gradient mode of QuasiSetLogLikelihood (PHDNavigator.cs:543-713 with calcgradient) ----
@@ -444,23 +617,16 @@ __device__ int cluster_enumerate_wave(const double* mat, int n, int modelsize, d
 // Test surface (phd_test_pairing): the pairing enumerators on a matrix handed in by the host, so that the vectors of
 // GraphCombinatoricsTest.cs reach the device code itself. One wave. mode 0: MurtyPairing (best first; the cut of
 // SetLogLikelihood's loop is kept out by pre-filling logcomp), mode 1: LexicographicalPairing(matrix, modelsize), n <= 5.
-__global__ __launch_bounds__(64) void k_test_pairing(MurtyNodes* nodes, const double* matrix, int n, int mode, int modelsize,
+__global__ __launch_bounds__(64) void k_test_pairing(MurtyNodes* nodes, char* bigws, const double* matrix, int n, int mode, int modelsize,
                                                      int maxcount, int* assignments, double* values, int* count)
 {
 	__shared__ double lds[MURTY_LDS_DOUBLES + 2];
 	const int lane = threadIdx.x;
-	MurtyLds ws;
-	ws.profit  = nodes->profit;
-	ws.reduced = nodes->reduced;
-	ws.logcomp = lds;
-	ws.fkey    = ws.logcomp + MURTY_OUT;
-	ws.fnode   = (int*) (ws.fkey + MURTY_POOL);
-	ws.freelist = ws.fnode + MURTY_POOL;
-	ws.L = ws.freelist + MURTY_POOL;
-	ws.Z = ws.L + MURTY_NMAX;
+	const MurtyLds ws = murty_lds(lds);
+	const MurtyWs nd = (n <= MURTY_NMAX) ? murty_ws_particle(nodes) : murty_ws_carve(bigws, n);   // (host: bigws holds murty_big_bytes(n))
 	for (int i = lane; i < MURTY_OUT; i += 64) ws.logcomp[i] = 1e300;
 	const int stride = (mode == 1) ? 5 : n;
-	double* mat = (mode == 1) ? ws.reduced : ws.profit;
+	double* mat = (mode == 1) ? nd.reduced : nd.profit;
 	for (int e = lane; e < n * n; e += 64) mat[(e / n) * stride + (e % n)] = matrix[e];
 	lds_fence();
 	int m;
@@ -470,8 +636,9 @@ __global__ __launch_bounds__(64) void k_test_pairing(MurtyNodes* nodes, const do
 		});
 	}
 	else {
-		m = wave_murty(ws, nodes, n, lane, [&](int k, int code) {
-			if (k < maxcount && lane < n) assignments[k * n + lane] = (code & 0x10000) ? -1 : (int) nodes->asg[code][lane];
+		m = wave_murty_any(ws, nd, n, lane, [&](int k, bool unsolved, auto colof) {
+			if (k >= maxcount) return;
+			for (int r = lane; r < n; r += 64) assignments[k * n + r] = unsolved ? -1 : colof(r);
 		});
 	}
 	for (int k = lane; k < m && k < maxcount; k += 64) values[k] = ws.logcomp[k];
@@ -1100,15 +1267,7 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 			// before it. So wave 0 replays the clusters in order up to the last such cluster, keeping the
 			// shared logcomp array; the other waves wait.
 			if (wv == 0) {
-				MurtyLds ws;
-				ws.profit  = a.murty[p].profit;
-				ws.reduced = a.murty[p].reduced;
-				ws.logcomp = xreg;
-				ws.fkey    = ws.logcomp + MURTY_OUT;
-				ws.fnode   = (int*) (ws.fkey + MURTY_POOL);
-				ws.freelist = ws.fnode + MURTY_POOL;
-				ws.L = ws.freelist + MURTY_POOL;
-				ws.Z = ws.L + MURTY_NMAX;
+				const MurtyLds ws = murty_lds(xreg);
 				for (int i = lane; i < MURTY_OUT; i += 64) ws.logcomp[i] = 0;   // new double[200], :469
 				lds_fence();
 				int lastbig = GRAD ? nroots - 1 : -1;
@@ -1121,12 +1280,30 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 				for (int ri = 0; ri <= lastbig; ri++) {
 					const int root = roots[ri];
 					int nl = 0, nz = 0;
+					for (int j0 = root; j0 < J; j0 += 64) nl += __popcll(__ballot(j0 + lane < J && labl[j0 + lane] == root));
+					for (int k0 = 0; k0 < M; k0 += 64) nz += __popcll(__ballot(k0 + lane < M && labz[k0 + lane] == root));
+					const int nrow = nl + nz;
+					// workspace: the particle's own for clusters of up to MURTY_NMAX rows, a block of the association slab beyond
+					MurtyWs nd = murty_ws_particle(nodes);
+					if (nrow > MURTY_NMAX) {
+						const unsigned long long need = murty_big_bytes(nrow);
+						unsigned long long off = 0;
+						if (lane == 0 && a.bigws && nrow <= MURTY_NBIG) off = atomicAdd(a.bigws_used, need);
+						off = __shfl(off, 0, 64);
+						if (!a.bigws || nrow > MURTY_NBIG || off + need > a.bigws_bytes) {
+							// more rows than the solver takes, or the slab is used up: the step is dropped (PHD_ERR_ASSOCIATION)
+							if (lane == 0) { atomicOr(a.flags, PHD_FLAG_BIG_CLUSTER); res[ri] = 0; }
+							continue;
+						}
+						nd = murty_ws_carve(a.bigws + off, nrow);
+					}
+					nl = 0; nz = 0;
 					for (int j0 = root; j0 < J; j0 += 64) {
 						int j = j0 + lane;
 						bool in = j < J && labl[j] == root;
 						unsigned long long bal = __ballot(in);
 						int pos = nl + __popcll(bal & lanemask_lt());
-						if (in && pos < MURTY_NMAX) ws.L[pos] = j;
+						if (in) nd.L[pos] = j;
 						nl += __popcll(bal);
 					}
 					for (int k0 = 0; k0 < M; k0 += 64) {
@@ -1134,26 +1311,21 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 						bool in = k < M && labz[k] == root;
 						unsigned long long bal = __ballot(in);
 						int pos = nz + __popcll(bal & lanemask_lt());
-						if (in && pos < MURTY_NMAX) ws.Z[pos] = k;
+						if (in) nd.Z[pos] = k;
 						nz += __popcll(bal);
 					}
-					lds_fence();
-					const int nrow = nl + nz;
-					if (nrow > MURTY_NMAX) {
-						if (lane == 0) { atomicOr(a.flags, PHD_FLAG_BIG_CLUSTER); res[ri] = 0; }
-						continue;
-					}
+					__threadfence_block();
 					// the cluster's square matrix: rows = landmarks then clutter rows, columns = measurements
 					// then misdetection columns (Compact, SparseMatrix.cs:592-628; zero quadrant :480-488)
 					const int stride = (nrow <= 5) ? 5 : nrow;
-					double* mat = (nrow <= 5) ? ws.reduced : ws.profit;
+					double* mat = (nrow <= 5) ? nd.reduced : nd.profit;
 					for (int e = lane; e < nrow * nrow; e += 64) {
 						int x = e / nrow, y = e - x * nrow;
 						double v = -INFINITY;
 						if (x < nl) {
-							int j = ws.L[x];
+							int j = nd.L[x];
 							if (y < nz) {
-								int k = ws.Z[y];
+								int k = nd.Z[y];
 								if ((adj[(size_t) j * MW + (k >> 6)] >> (k & 63)) & 1ull) {
 									double dist = sqrt(quad_gen(prm.Rinv, zh[j] - zs[k * 3], zh[JS + j] - zs[k * 3 + 1],
 									                            zh[2 * JS + j] - zs[k * 3 + 2]));
@@ -1168,26 +1340,26 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 						}
 						mat[x * stride + y] = v;
 					}
-					lds_fence();
+					__threadfence_block();
 					// gradient mode: dlogcompdp[m] = sum over the rows of dcomp[row, pairing[row]] (:676-678); lane t keeps
 					// component t. Only landmark rows paired with a gated measurement hold a vector (the rest is the default 0).
 					if (GRAD) {
-						if (lane < nl) {
-							const int j = ws.L[lane];
+						for (int x = lane; x < nl; x += 64) {
+							const int j = nd.L[x];
 							const double m3[3] = {lm[j], lm[JS + j], lm[2 * JS + j]};
-							jacobian_p(prm, pose, m3, nodes->jp[lane]);   // :591
+							jacobian_p(prm, pose, m3, nd.jp + x * 18);   // :591
 						}
-						lds_fence();
+						__threadfence_block();
 					}
 					auto pairing_gradient = [&](auto colof) {
 						double acc = 0;
 						for (int x = 0; x < nl; x++) {
 							const int y = colof(x);
 							if (y >= nz) continue;
-							const int j = ws.L[x], k = ws.Z[y];
+							const int j = nd.L[x], k = nd.Z[y];
 							if (!((adj[(size_t) j * MW + (k >> 6)] >> (k & 63)) & 1ull)) continue;
 							const double nu[3] = {zs[k * 3] - zh[j], zs[k * 3 + 1] - zh[JS + j], zs[k * 3 + 2] - zh[2 * JS + j]};
-							acc += pair_gradient(prm, nu, nodes->jp[x], gt);
+							acc += pair_gradient(prm, nu, nd.jp + x * 18, gt);
 						}
 						return acc;
 					};
@@ -1206,10 +1378,10 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 						}
 					}
 					else {
-						mcount = wave_murty(ws, nodes, nrow, lane, [&](int m, int code) {
+						mcount = wave_murty_any(ws, nd, nrow, lane, [&](int m, bool unsolved, auto colof) {
 							if (!GRAD) return;
 							double g = 0;
-							if (!(code & 0x10000)) g = pairing_gradient([&](int x) { return (int) nodes->asg[code][x]; });
+							if (!unsolved) g = pairing_gradient(colof);
 							if (lane < 6) nodes->dvec[m][lane] = g;
 						});
 					}

@@ -141,6 +141,7 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 	__shared__ int    s_i16[16];
 	__shared__ int    s_res, s_ok, s_best;
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	if (tid == 0 && a.bigws_used && *a.bigws_used) *a.bigws_used = 0;   // the association slab is free again (every k_alpha_assoc of the step is over)
 	// A kernel of this step raised a flag (emit capacity, landmark scratch): what it wrote into the OUT bank is not a
 	// valid state. The step is dropped as a whole — the roles stay, nothing of the current state was touched — and the host
 	// finds the flag at its next phd_sync. (Every thread reads the same word, written by earlier launches.)

@@ -56,6 +56,7 @@ struct phd_navigator {
 	double* d_alpha = nullptr; double* d_setll = nullptr;
 	int*    d_flags = nullptr; int* d_src = nullptr; int* d_info = nullptr;
 	MurtyNodes* d_murty = nullptr;
+	char* d_bigws = nullptr; unsigned long long bigws_bytes = 0; unsigned long long* d_bigws_used = nullptr;   // association slab (clusters beyond 64 rows)
 	double* d_jscratch = nullptr;
 	int cmcap = 0;
 	int* d_cand_count = nullptr; double* d_denom = nullptr;
@@ -198,6 +199,7 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.emit_w = nav->d_emit_w; b.emit_idx = nav->d_emit_idx; b.emit_rec = nav->d_emit_rec; b.emit_count = nav->d_emit_count;
 	b.born_count = nav->d_born_count; b.born_k = nav->d_born_k; b.born_mean = nav->d_born_mean;
 	b.alpha = nav->d_alpha; b.setll = nav->d_setll; b.flags = nav->d_flags; b.murty = nav->d_murty; b.jscratch = nav->d_jscratch;
+	b.bigws = nav->d_bigws; b.bigws_bytes = nav->bigws_bytes; b.bigws_used = nav->d_bigws_used;
 	b.cand_count = nav->d_cand_count; b.denom = nav->d_denom;
 	b.cand = nav->d_cand; b.candcap = nav->candcap;
 	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account; b.srec = nav->d_srec; b.wcopy = nav->d_wcopy; b.cover = nav->d_cover; b.stamps = nav->d_stamps; b.stamp_kernel = getenv("PHD_STAMP_KERNEL") ? atoi(getenv("PHD_STAMP_KERNEL")) : 2;
@@ -356,7 +358,9 @@ int check_flags(phd_navigator* nav)
 		return nav->fail(PHD_ERR_CAPACITY, "map estimate larger than the landmark scratch (" + std::to_string(nav->Jcap) + ")");
 	}
 	if (f & PHD_FLAG_BIG_CLUSTER) {
-		return nav->fail(PHD_ERR_ASSOCIATION, "data-association cluster with more than " + std::to_string(MURTY_NMAX) + " rows: beyond the on-device solver");
+		return nav->fail(PHD_ERR_ASSOCIATION, "a data-association cluster has more than " + std::to_string(MURTY_NBIG) + " rows, or the clusters beyond " +
+		                 std::to_string(MURTY_NMAX) + " rows used up the association workspace (" + std::to_string(nav->bigws_bytes >> 20) +
+		                 " MiB, phd_set_association_workspace); the step was dropped, the state is the one before it");
 	}
 	return PHD_OK;
 }
@@ -574,6 +578,9 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	ok = ok && dalloc((void**) &nav->d_flags, 4) && dalloc((void**) &nav->d_info, 8);
 	ok = ok && dalloc((void**) &nav->d_src, (size_t) nav->Pcap * 4);
 	ok = ok && dalloc((void**) &nav->d_murty, (size_t) nav->Pcap * sizeof(MurtyNodes));
+	nav->bigws_bytes = 128ull << 20;
+	ok = ok && dalloc((void**) &nav->d_bigws, nav->bigws_bytes) && dalloc((void**) &nav->d_bigws_used, 8);
+	if (ok) hipMemset(nav->d_bigws_used, 0, 8);
 	nav->cmcap = nav->cap + nav->Mcap;
 	ok = ok && dalloc((void**) &nav->d_cand_count, (size_t) nav->Pcap * 4) && dalloc((void**) &nav->d_denom, (size_t) nav->Pcap * nav->Mcap * 8);
 	nav->candcap = 16 * nav->cmcap;   // a quarter of all pairs at 64 measurements; beyond it the full second sweep runs
@@ -655,7 +662,7 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_sel); hipFree(nav->d_inslot); hipFree(nav->d_mslot); hipFree(nav->d_fslot); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
-	hipFree(nav->d_murty); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_wcopy); hipFree(nav->d_cover); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
+	hipFree(nav->d_murty); hipFree(nav->d_bigws); hipFree(nav->d_bigws_used); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_wcopy); hipFree(nav->d_cover); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
 	if (nav->h_pin) hipHostFree(nav->h_pin);
 	for (int i = 0; i < 2; i++) {
@@ -770,6 +777,7 @@ static int quasi_batch(phd_navigator* nav, const double* poses7, int nposes, con
 	b.qgrad = nav->d_quasi + og;
 	b.qavg  = average_mode;
 	const bool gradient = gradients6 != nullptr;
+	HC(hipMemsetAsync(nav->d_bigws_used, 0, 8, nav->stream));
 	int rc;
 	switch (zb_of(nmeasurements)) {
 	case 1:  rc = launch_quasi<1>(nav, b, nposes, gradient); break;
@@ -808,20 +816,21 @@ int phd_test_pairing(phd_navigator* nav, const double* matrix, int n, int mode, 
                      int32_t* assignments, double* values, int* count)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
-	if (!matrix || !assignments || !values || !count || n < 1 || n > MURTY_NMAX || maxcount < 1 || (mode == 1 && n > 5) || mode < 0 || mode > 1) {
-		return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_test_pairing: n in 1..32 (1..5 for the lexicographic order), mode 0 or 1, buffers for maxcount pairings");
+	if (!matrix || !assignments || !values || !count || n < 1 || n > MURTY_NBIG || maxcount < 1 || (mode == 1 && n > 5) || mode < 0 || mode > 1) {
+		return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_test_pairing: n in 1..256 (1..5 for the lexicographic order), mode 0 or 1, buffers for maxcount pairings");
 	}
 	hipSetDevice(nav->device);
 	HC(hipStreamSynchronize(nav->stream));
-	double* dm = nullptr; int* da = nullptr; double* dv = nullptr; int* dc = nullptr;
+	double* dm = nullptr; int* da = nullptr; double* dv = nullptr; int* dc = nullptr; char* dbig = nullptr;
 	HC(hipMalloc((void**) &dm, (size_t) n * n * 8));
+	if (n > MURTY_NMAX) HC(hipMalloc((void**) &dbig, murty_big_bytes(n)));
 	HC(hipMalloc((void**) &da, (size_t) maxcount * n * 4));
 	HC(hipMalloc((void**) &dv, (size_t) maxcount * 8));
 	HC(hipMalloc((void**) &dc, 4));
 	hipError_t e = hipMemcpy(dm, matrix, (size_t) n * n * 8, hipMemcpyHostToDevice);
 	if (e == hipSuccess) {
 		hipMemset(da, 0xff, (size_t) maxcount * n * 4);
-		hipLaunchKernelGGL(k_test_pairing, dim3(1), dim3(64), 0, nav->stream, nav->d_murty, (const double*) dm, n, mode, modelsize, maxcount, da, dv, dc);
+		hipLaunchKernelGGL(k_test_pairing, dim3(1), dim3(64), 0, nav->stream, nav->d_murty, dbig, (const double*) dm, n, mode, modelsize, maxcount, da, dv, dc);
 		e = hipStreamSynchronize(nav->stream);
 	}
 	int m = 0;
@@ -829,7 +838,7 @@ int phd_test_pairing(phd_navigator* nav, const double* matrix, int n, int mode, 
 	const int k = std::min(m, maxcount);
 	if (e == hipSuccess && k > 0) e = hipMemcpy(assignments, da, (size_t) k * n * 4, hipMemcpyDeviceToHost);
 	if (e == hipSuccess && k > 0) e = hipMemcpy(values, dv, (size_t) k * 8, hipMemcpyDeviceToHost);
-	hipFree(dm); hipFree(da); hipFree(dv); hipFree(dc);
+	hipFree(dm); hipFree(da); hipFree(dv); hipFree(dc); hipFree(dbig);
 	if (e != hipSuccess) return nav->fail(PHD_ERR_DEVICE, std::string("phd_test_pairing: ") + hipGetErrorString(e));
 	*count = m;
 	return PHD_OK;
@@ -933,6 +942,22 @@ int phd_set_split(phd_navigator* nav, int nsplit)
 {
 	if (!nav || nsplit < 0 || nsplit > phd_navigator::MAXSPLIT) return PHD_ERR_BAD_ARGUMENT;
 	nav->nsplit = nsplit;
+	return PHD_OK;
+}
+
+int phd_set_association_workspace(phd_navigator* nav, int64_t bytes)
+{
+	if (!nav || bytes < 0) return PHD_ERR_BAD_ARGUMENT;
+	hipSetDevice(nav->device);
+	HC(hipStreamSynchronize(nav->stream));
+	hipFree(nav->d_bigws);
+	nav->d_bigws = nullptr;
+	nav->bigws_bytes = 0;
+	if (bytes > 0) {
+		HC(hipMalloc((void**) &nav->d_bigws, (size_t) bytes));
+		nav->bigws_bytes = (unsigned long long) bytes;
+	}
+	HC(hipMemset(nav->d_bigws_used, 0, 8));
 	return PHD_OK;
 }
 
@@ -1055,6 +1080,7 @@ int phd_stage_run(phd_navigator* nav, const double* z3, int nmeasurements, uint8
 	rc = sync_state(nav);
 	if (rc) return rc;
 	StepBufs b = make_bufs(nav);
+	HC(hipMemsetAsync(nav->d_bigws_used, 0, 8, nav->stream));
 	rc = launch_map(nav, b, with_alpha != 0);
 	if (rc) return rc;
 	rc = sync_state(nav);

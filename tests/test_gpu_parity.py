@@ -434,8 +434,16 @@ def test_resampling_leaves_the_maps_in_place(nav_mod):
 
 def test_reweight_far_from_the_origin(nav_mod):
     """A scene 2 km from the origin: Gaussian.Merge's raw second moments (Gaussian.cs:336-344) then cost a pruned
-    singleton about eps |m|^2 = 1e-9 of its covariance, so k_prune_merge must NOT declare the corrected map's misdetection
-    copies equal to their predicted components, and k_alpha_density evaluates them itself — against the oracle."""
+    singleton about eps |m|^2 = 5e-10 of its covariance entries, so k_prune_merge must NOT declare the corrected map's
+    misdetection copies equal to their predicted components, and k_alpha_density evaluates them itself — against the oracle.
+
+    The tolerance on alpha here is the reference formula's own conditioning, measured: the rounding residue of
+    fl(fl(w (P + m m')) / w) - m m' is a pseudo-random function of the LAST BIT of w, and the weights of the detection
+    components go through exp and a 50-term sum (device and oracle agree to 1e-15, not to the bit — nor would the CLR's
+    Math.Exp with glibc's). The oracle is therefore re-run with its corrected weights moved by one ulp either way: alpha
+    moves by `spread` (a few 1e-4 at this distance; 0 at the origin, where the same check holds to 1e-6 in
+    test_stage_parity), and the device must sit within that band. Stage by stage, on identical inputs, everything is
+    checked tightly in tests/test_gpu_round2.py::test_far_from_the_origin_stage_by_stage."""
     P, C, M = 4, 50, 14
     f = Frame(P, C, M, 91, weight_profile="steady")
     shift = np.array([1500.0, -900.0, 1100.0])
@@ -445,6 +453,7 @@ def test_reweight_far_from_the_origin(nav_mod):
     nav, p = make_nav(nav_mod, f)
     nav.run_stages(f.z, with_alpha=True)
     alpha = nav.WeightAlpha()
+    rng = np.random.default_rng(5)
     for i in range(P):
         pred = orc.predict(p, f.poses[i], f.z, f.map(i))
         cor = orc.correct(p, f.poses[i], f.z, pred)
@@ -453,8 +462,12 @@ def test_reweight_far_from_the_origin(nav_mod):
         assert len(got[0]) == len(pr[0])
         assert np.allclose(got[0], pr[0], rtol=1e-7) and np.allclose(got[1], pr[1], rtol=1e-12, atol=1e-9)
         a, _ = orc.weight_alpha(p, f.poses[i], f.z, pred, pr)
-        # Merge's raw moments run without FP contraction on the device (as on the CLR and in the oracle)
-        assert np.isclose(alpha[i], a, rtol=1e-6, atol=0), "alpha[%d]: %r vs %r" % (i, alpha[i], a)
+        spread = 0.0
+        for _ in range(6):
+            wp = np.nextafter(cor[0], np.where(rng.random(len(cor[0])) < 0.5, 0.0, 2.0))   # every corrected weight one ulp down or up
+            ap, _ = orc.weight_alpha(p, f.poses[i], f.z, pred, orc.prune(p, (wp, cor[1], cor[2])))
+            spread = max(spread, abs(ap - a) / a)
+        assert abs(alpha[i] - a) / a <= max(1e-6, 3 * spread), "alpha[%d]: %r vs %r (one-ulp spread of the oracle %g)" % (i, alpha[i], a, spread)
     nav.close()
 
 

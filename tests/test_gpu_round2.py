@@ -251,3 +251,75 @@ def test_far_from_the_origin_stage_by_stage(nav_mod):
         a, _ = orc.weight_alpha(p, f.poses[i], f.z, pred, opr)
         assert np.isclose(alpha[i], a, rtol=1e-6, atol=0), "alpha[%d]: %r vs %r" % (i, alpha[i], a)
     nav.close()
+
+
+# ---- association clusters beyond 32 rows (MurtyPairing has no size limit, GraphCombinatorics.cs:241-272) ---------------
+@pytest.mark.parametrize("n", [33, 40, 64, 65, 100, 128, 129, 200])
+def test_murty_pairing_beyond_32_rows(nav_mod, n):
+    """The device's MurtyPairing on dense n x n matrices with missing entries, n up to 64 in the per-particle workspace
+    (one row and column per lane), beyond it in a slab block (two or four per lane): the first 40 pairings, assignments
+    and values, equal the oracle's (GraphCombinatorics.cs:64-272 restated) exactly."""
+    p = prm3d_defaults(max_particles=1, max_components=600, max_measurements=8)
+    nav = nav_mod.PHDNavigator(p, particlecount=1)
+    rng = np.random.default_rng(700 + n)
+    m = rng.uniform(-20, 0, (n, n))
+    m[rng.uniform(size=m.shape) < 0.6] = -np.inf
+    m[np.arange(n), np.arange(n)] = rng.uniform(-5, 0, n)       # a finite diagonal: solvable
+    asg, val = nav.test_pairing(m, maxcount=40)
+    oasg, oval = orc.murty(m, maxcount=40)
+    assert len(asg) == len(oasg) == 40
+    assert asg == oasg
+    assert np.array_equal(val, oval)
+    # no perfect matching at all: the first node is yielded unsolved with value -inf and has no children (:245-249, :473)
+    m2 = m.copy()
+    m2[n // 2, :] = -np.inf
+    asg2, val2 = nav.test_pairing(m2, maxcount=5)
+    assert len(asg2) == 1 and val2[0] == -np.inf and all(a == -1 for a in asg2[0])
+    nav.close()
+
+
+@pytest.mark.parametrize("seed,per_group,mpg,P,rows", [(66, 20, 20, 2, 41), (67, 30, 60, 1, 88), (69, 60, 150, 1, 172)])
+def test_association_clusters_of_40_to_170_rows(nav_mod, seed, per_group, mpg, P, rows):
+    """One cluster of 41 rows (the per-particle workspace, a row per lane), of 88 and of 172 rows (the association slab,
+    two and four rows per lane): set log-likelihood and particle weight against the oracle, through the whole stage chain."""
+    from test_gpu_parity import clustered_frame
+    f = clustered_frame(seed, 1, per_group, mpg, spread_px=3.0)
+    f.P = P
+    f.poses, f.mean, f.cov, f.w, f.counts, f.weights = f.poses[:P], f.mean[:P], f.cov[:P], f.w[:P], f.counts[:P], np.full(P, 1.0 / P)
+    nav, p = make_nav(nav_mod, f, merge_threshold=1e-3, emit_capacity=12000)
+    nav.run_stages(f.z, with_alpha=True)
+    setll, alpha = nav.SetLogLikelihood(), nav.WeightAlpha()
+    biggest = 0
+    for i in range(P):
+        pred = orc.predict(p, f.poses[i], f.z, f.map(i))
+        pr = orc.prune(p, orc.correct(p, f.poses[i], f.z, pred))
+        assert_map_close(nav.PruneModel(i), pr, 1e-7, "prune[%d]" % i)
+        lm, _ = orc.best_map_estimate(pr)
+        v, ncl, mx = orc.set_log_likelihood(p, f.poses[i], lm, f.z)
+        biggest = max(biggest, mx)
+        assert np.isclose(setll[i], v, rtol=1e-9, atol=1e-9), "set log-likelihood[%d]: %r vs %r (largest cluster %d)" % (i, setll[i], v, mx)
+        a, _ = orc.weight_alpha(p, f.poses[i], f.z, pred, pr)
+        assert np.isclose(alpha[i], a, rtol=1e-6, atol=0)
+    assert biggest == rows, "the frame did not produce the large cluster it was built for (largest %d)" % biggest
+    nav.close()
+
+
+def test_association_workspace_exhausted_is_an_error_that_keeps_the_state(nav_mod):
+    """Without an association slab a cluster of more than 64 rows cannot be solved: PHD_ERR_ASSOCIATION, the state stays
+    (the step is dropped as a whole); with the slab back the same step runs."""
+    from test_gpu_parity import clustered_frame
+    f = clustered_frame(67, 1, 30, 60, spread_px=3.0)
+    nav, p = make_nav(nav_mod, f, merge_threshold=1e-3, emit_capacity=12000)
+    before = (nav.VehicleWeights, [nav.MapModel(i) for i in range(f.P)])
+    nav._check(nav._lib.phd_set_association_workspace(nav._h, 0))
+    with pytest.raises(nav_mod.PHDError) as e:
+        nav.SlamUpdate(None, f.z)
+    assert e.value.status == 3 and e.value.module == "association"
+    after = (nav.VehicleWeights, [nav.MapModel(i) for i in range(f.P)])
+    assert np.array_equal(before[0], after[0])
+    for x, y in zip(before[1], after[1]):
+        assert all(np.array_equal(a, b) for a, b in zip(x, y))
+    nav._check(nav._lib.phd_set_association_workspace(nav._h, 64 << 20))
+    nav.SlamUpdate(None, f.z)
+    assert np.isclose(nav.VehicleWeights.sum(), 1.0)
+    nav.close()
