@@ -102,6 +102,19 @@ void phd_default_params(phd_params* p, int max_particles, int max_components, in
  * ISAM2Lib.newnavigator (ISAM2Navigator.cs:603). `device` is the HIP ordinal. NULL on failure;
  * phd_create_error() then holds the reason.                                                     */
 phd_navigator* phd_create(const phd_params* params, int device);
+/* The same over several devices of one node (SURVEY §8b "device list", §8e): ONE handle, ONE caller thread — what a C# host
+ * can drive (Simulation.Update runs the solver from one thread, Simulation.cs:636-673; it has no RCCL). The particles are
+ * sharded contiguously, ndevices equal shards: params->max_particles and every particle count are TOTALS and multiples of
+ * ndevices. A step runs the shards' kernels concurrently, all-gathers the un-normalised weights with peer copies over xGMI
+ * (16 KB per pair at 2048 particles per GPU), computes the identical normalisation / BestParticle / systematic resampling on
+ * every device and migrates the particles whose source lives elsewhere, again with peer copies: results are bit-identical
+ * to a single-device handle holding all particles, for any ndevices. A device may be listed more than once (tests).
+ * Available on such a handle: phd_reset, phd_set_poses / _weights / _map, phd_update_motion, phd_slam_update,
+ * phd_set_measurements / phd_step_async / phd_sync (the step returns once the resampling plan is known: it is not fully
+ * asynchronous), the getters, phd_upload / download_state_soa, phd_set_frozen / _split / _association_workspace,
+ * phd_quasi_set_loglik[_grad], phd_resample / phd_particle_depleted, the timing calls (first shard); the stage-level KAT entry
+ * points and the per-rank sharding primitives below return PHD_ERR_BAD_ARGUMENT.                                       */
+phd_navigator* phd_create_multi(const phd_params* params, const int* devices, int ndevices);
 const char*    phd_create_error(void);
 /* ≙ Navigator.Dispose (Navigator.cs:395) / ISAM2Lib.deletenavigator.                             */
 void           phd_destroy(phd_navigator* nav);

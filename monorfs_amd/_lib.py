@@ -58,6 +58,7 @@ def load():
         "phd_api_version": (C.c_int, []),
         "phd_default_params": (None, [C.POINTER(PhdParams), C.c_int, C.c_int, C.c_int]),
         "phd_create": (P, [C.POINTER(PhdParams), C.c_int]),
+        "phd_create_multi": (P, [C.POINTER(PhdParams), C.POINTER(C.c_int), C.c_int]),
         "phd_create_error": (C.c_char_p, []),
         "phd_destroy": (None, [P]),
         "phd_last_error": (C.c_char_p, [P]),
@@ -112,7 +113,7 @@ def load():
     return lib
 
 
-EXPORTS = ["phd_api_version", "phd_default_params", "phd_create", "phd_create_error", "phd_destroy", "phd_last_error",
+EXPORTS = ["phd_api_version", "phd_default_params", "phd_create", "phd_create_multi", "phd_create_error", "phd_destroy", "phd_last_error",
            "phd_reset", "phd_set_poses", "phd_set_weights", "phd_set_map", "phd_slam_update", "phd_set_measurements",
            "phd_step_async", "phd_sync", "phd_set_frozen", "phd_set_association_workspace", "phd_update_motion", "phd_quasi_set_loglik", "phd_quasi_set_loglik_grad", "phd_test_pairing", "phd_set_split", "phd_weights", "phd_best_particle", "phd_poses",
            "phd_particle_count", "phd_map", "phd_resample_sources", "phd_stage_run", "phd_stage_map", "phd_stage_alpha",

@@ -144,7 +144,7 @@ __device__ __forceinline__ MurtyWs murty_ws_particle(MurtyNodes* nd)
 // bytes of a slab block for a cluster of n rows (multiple of 16)
 __host__ __device__ inline size_t murty_big_bytes(int n)
 {
-	const size_t nt = (size_t) ((n + 63) / 64);
+	const size_t nt = (n <= 64) ? 1 : ((n <= 128) ? 2 : 4);   // forced-row words per node: the NT of wave_murty_any
 	size_t b = 0;
 	b += 2 * (size_t) n * n * 8;                 // profit, reduced
 	b += (size_t) n * 18 * 8;                    // jp
@@ -158,7 +158,7 @@ __host__ __device__ inline size_t murty_big_bytes(int n)
 
 __device__ __forceinline__ MurtyWs murty_ws_carve(char* base, int n)
 {
-	const size_t nt = (size_t) ((n + 63) / 64);
+	const size_t nt = (n <= 64) ? 1 : ((n <= 128) ? 2 : 4);
 	MurtyWs w;
 	char* q = base;
 	w.profit  = (double*) q; q += (size_t) n * n * 8;

@@ -25,7 +25,10 @@ struct Timer {          // one record per kernel launch since the last phd_timin
 
 }  // namespace
 
+struct MultiState;   // phd_create_multi: the shards of a multi-device handle (phd_multi.inc)
+
 struct phd_navigator {
+	MultiState* multi = nullptr;       // non-NULL: this handle only dispatches to its shards
 	phd_params  prm;
 	DevParams   dp;
 	int         device = 0;
@@ -474,6 +477,26 @@ int materialise(phd_navigator* nav)
 
 }  // namespace
 
+// ---- multi-device handle (phd_create_multi, phd_multi.inc): every entry point that means something for it dispatches here
+int multi_reset(phd_navigator* nav, int nparticles, const double* pose7, const double* w, const double* mean3, const double* cov9, int ncomp);
+int multi_set_small(phd_navigator* nav, const double* poses7, const double* weights, int nparticles);
+int multi_update_motion(phd_navigator* nav, const double* odometry6, const double* noise6, int nparticles, uint8_t perfect_still);
+int multi_set_map(phd_navigator* nav, int particle, const double* w, const double* mean3, const double* cov9, int ncomp);
+int multi_upload(phd_navigator* nav, int nparticles, int stride, const double* planes, const int32_t* counts, const double* poses7, const double* weights);
+int multi_download(phd_navigator* nav, int stride, double* planes, int32_t* counts, double* poses7, double* weights);
+int multi_set_measurements(phd_navigator* nav, const double* z3, int nmeasurements);
+int multi_step(phd_navigator* nav, uint8_t onlymapping, double u_resample);
+int multi_sync(phd_navigator* nav);
+int multi_forward_int(phd_navigator* nav, int what, long long value);
+const double* multi_weights(phd_navigator* nav, int* length);
+const double* multi_poses(phd_navigator* nav, int* length);
+int multi_best_particle(phd_navigator* nav);
+int multi_map(phd_navigator* nav, int particle, int* ncomp, const double** w, const double** mean3, const double** cov9);
+const int32_t* multi_resample_sources(phd_navigator* nav, int* length, uint8_t* resampled);
+void multi_destroy(phd_navigator* nav);
+phd_navigator* multi_shard0(phd_navigator* nav);
+#define MULTI_UNSUPPORTED(nav, what) if ((nav) && (nav)->multi) return (nav)->fail(PHD_ERR_BAD_ARGUMENT, what ": not available on a multi-device handle (use a single-device handle)")
+
 // =================================================================================================
 extern "C" {
 
@@ -654,6 +677,7 @@ phd_navigator* phd_create(const phd_params* params, int device)
 void phd_destroy(phd_navigator* nav)
 {
 	if (!nav) return;
+	if (nav->multi) { multi_destroy(nav); return; }
 	hipSetDevice(nav->device);
 	if (nav->stream) hipStreamSynchronize(nav->stream);
 	for (int i = 0; i < 3; i++) {
@@ -683,10 +707,10 @@ const char* phd_last_error(const phd_navigator* nav) { return nav ? nav->err.c_s
 
 int phd_particle_count(phd_navigator* nav) { return nav ? nav->P : 0; }
 
-int phd_reset(phd_navigator* nav, int nparticles, const double* pose7, const double* w, const double* mean3,
-              const double* cov9, int ncomp)
+// phd_reset with the particle weight given (a shard of a multi-device handle holds 1 / the TOTAL count)
+static int reset_impl(phd_navigator* nav, int nparticles, const double* pose7, const double* w, const double* mean3,
+                      const double* cov9, int ncomp, double weight)
 {
-	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	if (nparticles < 1 || nparticles > nav->Pcap || !pose7 || ncomp < 0) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_reset: bad particle count / pose / ncomp");
 	hipSetDevice(nav->device);
 	int rc = sync_state(nav);
@@ -699,7 +723,7 @@ int phd_reset(phd_navigator* nav, int nparticles, const double* pose7, const dou
 	HC(hipMemcpy(nav->bank[I].poses, pose7, 7 * 8, hipMemcpyHostToDevice));
 	nav->P = nparticles;
 	StepBufs b = make_bufs(nav);
-	hipLaunchKernelGGL(k_replicate, dim3(nparticles), dim3(256), 0, nav->stream, b, 1.0 / nparticles);
+	hipLaunchKernelGGL(k_replicate, dim3(nparticles), dim3(256), 0, nav->stream, b, weight);
 	HC(hipGetLastError());
 	// the replicated state is in the OUT bank: make it current
 	const int O = nav->h_sel[SEL_OUT], T = nav->h_sel[SEL_TMP];
@@ -713,9 +737,18 @@ int phd_reset(phd_navigator* nav, int nparticles, const double* pose7, const dou
 	return PHD_OK;
 }
 
+int phd_reset(phd_navigator* nav, int nparticles, const double* pose7, const double* w, const double* mean3,
+              const double* cov9, int ncomp)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) return multi_reset(nav, nparticles, pose7, w, mean3, cov9, ncomp);
+	return reset_impl(nav, nparticles, pose7, w, mean3, cov9, ncomp, 1.0 / std::max(nparticles, 1));
+}
+
 int phd_set_poses(phd_navigator* nav, const double* poses7, int nparticles)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) return multi_set_small(nav, poses7, nullptr, nparticles);
 	if (nparticles != nav->P || !poses7) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_poses: particle count mismatch");
 	hipSetDevice(nav->device);
 	// the bank that holds the current poses is known to the device (the roles rotate there, at the end of a step): the poses
@@ -736,6 +769,7 @@ int phd_set_poses(phd_navigator* nav, const double* poses7, int nparticles)
 int phd_update_motion(phd_navigator* nav, const double* odometry6, const double* noise6, int nparticles, uint8_t perfect_still)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) return multi_update_motion(nav, odometry6, noise6, nparticles, perfect_still);
 	if (nav->prm.model != PHD_MODEL_PRM3D) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_update_motion: Pose3D odometry, the PRM3D model only");
 	if (!odometry6 || nparticles != nav->P) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_update_motion: particle count mismatch");
 	hipSetDevice(nav->device);
@@ -759,6 +793,7 @@ static int quasi_batch(phd_navigator* nav, const double* poses7, int nposes, con
                        const double* z3, int nmeasurements, double* out, double* gradients6, int average_mode)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) nav = multi_shard0(nav);   // a batch of candidate poses against one landmark set does not touch the particle state
 	if (nposes < 1 || nposes > nav->Pcap || nlandmarks < 0 || nlandmarks > nav->Jcap || nmeasurements < 0 ||
 	    nmeasurements > nav->prm.max_measurements || !poses7 || !out || (nlandmarks && !landmarks3) || (nmeasurements && !z3)) {
 		return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_quasi_set_loglik: sizes out of range (poses <= max_particles, landmarks <= min(1024, max_quantity), measurements <= max_measurements)");
@@ -816,6 +851,7 @@ int phd_test_pairing(phd_navigator* nav, const double* matrix, int n, int mode, 
                      int32_t* assignments, double* values, int* count)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) nav = multi_shard0(nav);
 	if (!matrix || !assignments || !values || !count || n < 1 || n > MURTY_NBIG || maxcount < 1 || (mode == 1 && n > 5) || mode < 0 || mode > 1) {
 		return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_test_pairing: n in 1..256 (1..5 for the lexicographic order), mode 0 or 1, buffers for maxcount pairings");
 	}
@@ -847,6 +883,7 @@ int phd_test_pairing(phd_navigator* nav, const double* matrix, int n, int mode, 
 int phd_set_weights(phd_navigator* nav, const double* weights, int nparticles)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) return multi_set_small(nav, nullptr, weights, nparticles);
 	if (nparticles != nav->P || !weights) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_weights: particle count mismatch");
 	hipSetDevice(nav->device);
 	double* hs = stage_acquire(nav);
@@ -863,6 +900,7 @@ int phd_set_weights(phd_navigator* nav, const double* weights, int nparticles)
 int phd_set_map(phd_navigator* nav, int particle, const double* w, const double* mean3, const double* cov9, int ncomp)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) return multi_set_map(nav, particle, w, mean3, cov9, ncomp);
 	if (particle < 0 || particle >= nav->P) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_map: particle out of range");
 	hipSetDevice(nav->device);
 	int rc = sync_state(nav);
@@ -875,10 +913,10 @@ int phd_set_map(phd_navigator* nav, int particle, const double* w, const double*
 // bulk upload of the whole particle set in the device layout (bench / tests):
 // planes[10][nparticles][stride] (w, mx, my, mz, xx, xy, xz, yy, yz, zz), counts[nparticles],
 // poses[nparticles][7], weights[nparticles]. Sets the particle count.
-int phd_upload_state_soa(phd_navigator* nav, int nparticles, int stride, const double* planes, const int32_t* counts,
-                         const double* poses7, const double* weights)
+// (plane_stride: doubles between two planes of the host array — a shard of a multi-device handle takes its rows of every plane)
+static int upload_impl(phd_navigator* nav, int nparticles, int stride, const double* planes, size_t plane_stride, const int32_t* counts,
+                       const double* poses7, const double* weights)
 {
-	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	if (nparticles < 1 || nparticles > nav->Pcap || stride < 0 || stride > nav->cap) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_upload_state_soa: sizes out of range");
 	hipSetDevice(nav->device);
 	int rc = sync_state(nav);
@@ -888,7 +926,7 @@ int phd_upload_state_soa(phd_navigator* nav, int nparticles, int stride, const d
 	int I = cur_bank(nav);
 	size_t plane = (size_t) nav->Pcap * nav->cap;
 	for (int f = 0; f < 10 && stride > 0; f++) {
-		HC(hipMemcpy2D(nav->bank[I].mix + f * plane, (size_t) nav->cap * 8, planes + (size_t) f * nparticles * stride,
+		HC(hipMemcpy2D(nav->bank[I].mix + f * plane, (size_t) nav->cap * 8, planes + (size_t) f * plane_stride,
 		               (size_t) stride * 8, (size_t) stride * 8, nparticles, hipMemcpyHostToDevice));
 	}
 	HC(hipMemcpy(nav->bank[I].count, counts, (size_t) nparticles * 4, hipMemcpyHostToDevice));
@@ -899,10 +937,17 @@ int phd_upload_state_soa(phd_navigator* nav, int nparticles, int stride, const d
 	return PHD_OK;
 }
 
-// bulk download in the same layout; planes must hold [10][P][stride] with stride >= the largest count
-int phd_download_state_soa(phd_navigator* nav, int stride, double* planes, int32_t* counts, double* poses7, double* weights)
+int phd_upload_state_soa(phd_navigator* nav, int nparticles, int stride, const double* planes, const int32_t* counts,
+                         const double* poses7, const double* weights)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) return multi_upload(nav, nparticles, stride, planes, counts, poses7, weights);
+	return upload_impl(nav, nparticles, stride, planes, (size_t) nparticles * stride, counts, poses7, weights);
+}
+
+// bulk download in the same layout; planes must hold [10][P][stride] with stride >= the largest count
+static int download_impl(phd_navigator* nav, int stride, double* planes, size_t plane_stride, int32_t* counts, double* poses7, double* weights)
+{
 	hipSetDevice(nav->device);
 	int rc = sync_state(nav);
 	if (rc) return rc;
@@ -912,7 +957,7 @@ int phd_download_state_soa(phd_navigator* nav, int stride, double* planes, int32
 	int I = cur_bank(nav);
 	size_t plane = (size_t) nav->Pcap * nav->cap;
 	for (int f = 0; f < 10 && stride > 0; f++) {
-		HC(hipMemcpy2D(planes + (size_t) f * nav->P * stride, (size_t) stride * 8, nav->bank[I].mix + f * plane,
+		HC(hipMemcpy2D(planes + (size_t) f * plane_stride, (size_t) stride * 8, nav->bank[I].mix + f * plane,
 		               (size_t) nav->cap * 8, (size_t) stride * 8, nav->P, hipMemcpyDeviceToHost));
 	}
 	HC(hipMemcpy(counts, nav->bank[I].count, (size_t) nav->P * 4, hipMemcpyDeviceToHost));
@@ -921,9 +966,17 @@ int phd_download_state_soa(phd_navigator* nav, int stride, double* planes, int32
 	return PHD_OK;
 }
 
+int phd_download_state_soa(phd_navigator* nav, int stride, double* planes, int32_t* counts, double* poses7, double* weights)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) return multi_download(nav, stride, planes, counts, poses7, weights);
+	return download_impl(nav, stride, planes, (size_t) nav->P * stride, counts, poses7, weights);
+}
+
 int phd_set_measurements(phd_navigator* nav, const double* z3, int nmeasurements)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) return multi_set_measurements(nav, z3, nmeasurements);
 	if (nmeasurements < 0 || nmeasurements > nav->prm.max_measurements || (nmeasurements > 0 && !z3)) {
 		return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_measurements: count out of range");
 	}
@@ -941,6 +994,7 @@ int phd_set_measurements(phd_navigator* nav, const double* z3, int nmeasurements
 int phd_set_split(phd_navigator* nav, int nsplit)
 {
 	if (!nav || nsplit < 0 || nsplit > phd_navigator::MAXSPLIT) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) return multi_forward_int(nav, 0, nsplit);
 	nav->nsplit = nsplit;
 	return PHD_OK;
 }
@@ -948,6 +1002,7 @@ int phd_set_split(phd_navigator* nav, int nsplit)
 int phd_set_association_workspace(phd_navigator* nav, int64_t bytes)
 {
 	if (!nav || bytes < 0) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) return multi_forward_int(nav, 1, bytes);
 	hipSetDevice(nav->device);
 	HC(hipStreamSynchronize(nav->stream));
 	hipFree(nav->d_bigws);
@@ -964,6 +1019,7 @@ int phd_set_association_workspace(phd_navigator* nav, int64_t bytes)
 int phd_set_frozen(phd_navigator* nav, uint8_t frozen)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) return multi_forward_int(nav, 2, frozen);
 	nav->frozen = frozen != 0;
 	return PHD_OK;
 }
@@ -971,6 +1027,7 @@ int phd_set_frozen(phd_navigator* nav, uint8_t frozen)
 int phd_step_async(phd_navigator* nav, uint8_t onlymapping, double u_resample)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) return multi_step(nav, onlymapping, u_resample);
 	if (nav->P < 1) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step: no particles (call phd_reset first)");
 	hipSetDevice(nav->device);
 	nav->timing_now = (nav->timing_step++ % nav->timing_period) == 0;
@@ -993,6 +1050,7 @@ int phd_step_async(phd_navigator* nav, uint8_t onlymapping, double u_resample)
 int phd_sync(phd_navigator* nav)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) return multi_sync(nav);
 	hipSetDevice(nav->device);
 	int rc = sync_state(nav);
 	if (rc) return rc;
@@ -1015,6 +1073,7 @@ int phd_slam_update(phd_navigator* nav, const double* z3, int nmeasurements, uin
 const double* phd_weights(phd_navigator* nav, int* length)
 {
 	if (!nav) return nullptr;
+	if (nav->multi) return multi_weights(nav, length);
 	hipSetDevice(nav->device);
 	if (sync_state(nav)) return nullptr;
 	int bidx = res_small(nav);
@@ -1027,6 +1086,7 @@ const double* phd_weights(phd_navigator* nav, int* length)
 int phd_best_particle(phd_navigator* nav)
 {
 	if (!nav) return -1;
+	if (nav->multi) return multi_best_particle(nav);
 	hipSetDevice(nav->device);
 	if (sync_state(nav)) return -1;
 	return nav->h_info[0];
@@ -1035,6 +1095,7 @@ int phd_best_particle(phd_navigator* nav)
 const double* phd_poses(phd_navigator* nav, int* length)
 {
 	if (!nav) return nullptr;
+	if (nav->multi) return multi_poses(nav, length);
 	hipSetDevice(nav->device);
 	if (sync_state(nav)) return nullptr;
 	int bidx = res_small(nav);
@@ -1047,6 +1108,7 @@ const double* phd_poses(phd_navigator* nav, int* length)
 int phd_map(phd_navigator* nav, int particle, int* ncomp, const double** w, const double** mean3, const double** cov9)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) return multi_map(nav, particle, ncomp, w, mean3, cov9);
 	if (particle < 0 || particle >= nav->P || !ncomp) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_map: particle out of range");
 	hipSetDevice(nav->device);
 	int rc = sync_state(nav);
@@ -1062,6 +1124,7 @@ int phd_map(phd_navigator* nav, int particle, int* ncomp, const double** w, cons
 const int32_t* phd_resample_sources(phd_navigator* nav, int* length, uint8_t* resampled)
 {
 	if (!nav) return nullptr;
+	if (nav->multi) return multi_resample_sources(nav, length, resampled);
 	hipSetDevice(nav->device);
 	if (sync_state(nav)) return nullptr;
 	nav->h_src.resize(std::max(nav->P, 1));
@@ -1074,6 +1137,7 @@ const int32_t* phd_resample_sources(phd_navigator* nav, int* length, uint8_t* re
 // ---- stage-level entry points ------------------------------------------------------------------
 int phd_stage_run(phd_navigator* nav, const double* z3, int nmeasurements, uint8_t with_alpha)
 {
+	MULTI_UNSUPPORTED(nav, "phd_stage_run");
 	int rc = phd_set_measurements(nav, z3, nmeasurements);
 	if (rc) return rc;
 	if (nav->P < 1) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_stage_run: no particles");
@@ -1095,6 +1159,7 @@ int phd_stage_map(phd_navigator* nav, int stage, int particle, int* ncomp, const
                   const double** cov9)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	MULTI_UNSUPPORTED(nav, "phd_stage_map");
 	if (!nav->stage_valid) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_stage_map: call phd_stage_run first");
 	if (particle < 0 || particle >= nav->P || !ncomp) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_stage_map: particle out of range");
 	hipSetDevice(nav->device);
@@ -1181,6 +1246,7 @@ int phd_resample(phd_navigator* nav, const double* weights, int nparticles, doub
                  int32_t* best_particle)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) nav = multi_shard0(nav);
 	if (nparticles < 1 || !weights || !sources) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_resample: bad arguments");
 	hipSetDevice(nav->device);
 	int rc = ensure_gw(nav, nparticles);
@@ -1204,6 +1270,7 @@ int phd_resample(phd_navigator* nav, const double* weights, int nparticles, doub
 int phd_particle_depleted(phd_navigator* nav, const double* weights, int nparticles, uint8_t* depleted)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) nav = multi_shard0(nav);
 	if (nparticles < 1 || !weights || !depleted) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_particle_depleted: bad arguments");
 	hipSetDevice(nav->device);
 	int rc = ensure_gw(nav, nparticles);
@@ -1232,11 +1299,12 @@ int phd_debug_stamps(phd_navigator* nav, double* out)
 }
 #endif
 
-void* phd_stream(phd_navigator* nav) { return nav ? (void*) nav->stream : nullptr; }
+void* phd_stream(phd_navigator* nav) { return (nav && !nav->multi) ? (void*) nav->stream : nullptr; }
 
 int phd_timing_reset(phd_navigator* nav, uint8_t enabled)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) nav = multi_shard0(nav);   // the kernels of the first shard are the ones timed
 	hipSetDevice(nav->device);
 	hipStreamSynchronize(nav->stream);
 	nav->ntimers = 0;
@@ -1250,6 +1318,7 @@ int phd_timing_reset(phd_navigator* nav, uint8_t enabled)
 int phd_last_timings(phd_navigator* nav, const char*** names, const double** ms)
 {
 	if (!nav) return 0;
+	if (nav->multi) nav = multi_shard0(nav);
 	hipSetDevice(nav->device);
 	hipStreamSynchronize(nav->stream);
 	nav->tnames.clear();
@@ -1276,6 +1345,7 @@ int phd_last_timings(phd_navigator* nav, const char*** names, const double** ms)
 int phd_last_timing_counts(phd_navigator* nav, const int** counts)
 {
 	if (!nav) return 0;
+	if (nav->multi) nav = multi_shard0(nav);
 	if (counts) *counts = nav->tcounts.data();
 	return (int) nav->tcounts.size();
 }
@@ -1291,6 +1361,7 @@ int phd_last_timing_counts(phd_navigator* nav, const int** counts)
 int phd_step_local_async(phd_navigator* nav, uint8_t onlymapping)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	MULTI_UNSUPPORTED(nav, "phd_step_local_async");
 	if (nav->P < 1) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step_local: no particles");
 	hipSetDevice(nav->device);
 	nav->timing_now = (nav->timing_step++ % nav->timing_period) == 0;
@@ -1319,6 +1390,7 @@ void* phd_device_global_weights(phd_navigator* nav, int world_particles)
 int phd_step_global_async(phd_navigator* nav, int rank, int world_size, double u_resample)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	MULTI_UNSUPPORTED(nav, "phd_step_global_async");
 	if (world_size < 1 || rank < 0 || rank >= world_size) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step_global: bad rank/world");
 	hipSetDevice(nav->device);
 	const int Pg = nav->P * world_size;
@@ -1379,6 +1451,7 @@ int phd_plan_migration(const int32_t* gsrc, int Pl, int world_size, int rank, in
 int phd_migration_plan(phd_navigator* nav, int rank, int world_size, int32_t* send_counts, int32_t* recv_counts)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	MULTI_UNSUPPORTED(nav, "phd_migration_plan");
 	if (world_size < 1 || rank < 0 || rank >= world_size || !send_counts || !recv_counts) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_plan: bad arguments");
 	hipSetDevice(nav->device);
 	int rc = PHD_OK;
@@ -1458,6 +1531,7 @@ void* phd_migration_recv_buffer(phd_navigator* nav) { return nav ? nav->d_recv :
 int phd_migration_pack_async(phd_navigator* nav)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	MULTI_UNSUPPORTED(nav, "phd_migration_pack_async");
 	hipSetDevice(nav->device);
 	if (nav->nsend == 0) return PHD_OK;
 	if (nav->nsend > nav->sendlistcap) {
@@ -1477,6 +1551,7 @@ int phd_migration_pack_async(phd_navigator* nav)
 int phd_migration_unpack_async(phd_navigator* nav)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	MULTI_UNSUPPORTED(nav, "phd_migration_unpack_async");
 	hipSetDevice(nav->device);
 	StepBufs b = make_bufs(nav);
 	int* sel_next = nav->d_sel + (nav->parity ^ 1) * SEL_STRIDE;
@@ -1521,6 +1596,7 @@ int phd_migration_unpack_async(phd_navigator* nav)
 int phd_set_stream(phd_navigator* nav, void* stream, uint8_t lend)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	MULTI_UNSUPPORTED(nav, "phd_set_stream");
 	hipSetDevice(nav->device);
 	HC(hipStreamSynchronize(nav->stream));
 	nav->stream = lend ? (hipStream_t) stream : nav->own_stream;   // a NULL lent stream is the legacy default stream
@@ -1528,3 +1604,5 @@ int phd_set_stream(phd_navigator* nav, void* stream, uint8_t lend)
 }
 
 }  // extern "C"
+
+#include "phd_multi.inc"

@@ -54,11 +54,17 @@ def _ptr(a):
 
 class PHDNavigator:
     def __init__(self, params: PhdParams = None, particlecount=1, onlymapping=False, device=0,
-                 pose=(0, 0, 0, 1, 0, 0, 0)):
-        """≙ new PHDNavigator(vehicle, particlecount, onlymapping) (PHDNavigator.cs:192-208)."""
+                 pose=(0, 0, 0, 1, 0, 0, 0), devices=None):
+        """≙ new PHDNavigator(vehicle, particlecount, onlymapping) (PHDNavigator.cs:192-208).
+        devices: a list of HIP ordinals -> one multi-device handle (phd_create_multi), the particles sharded
+        contiguously over them; params.max_particles and the particle count are then totals (multiples of len(devices))."""
         self._lib = _lib.load()
         self.params = params if params is not None else prm3d_defaults(max_particles=max(1, particlecount))
-        self._h = self._lib.phd_create(C.byref(self.params), device)
+        if devices is not None:
+            devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+            self._h = self._lib.phd_create_multi(C.byref(self.params), devs, len(devices))
+        else:
+            self._h = self._lib.phd_create(C.byref(self.params), device)
         if not self._h:
             raise PHDError(-1, self._lib.phd_create_error().decode())
         self.ParticleCount = particlecount

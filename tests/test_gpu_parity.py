@@ -438,12 +438,13 @@ def test_reweight_far_from_the_origin(nav_mod):
     misdetection copies equal to their predicted components, and k_alpha_density evaluates them itself — against the oracle.
 
     The tolerance on alpha here is the reference formula's own conditioning, measured: the rounding residue of
-    fl(fl(w (P + m m')) / w) - m m' is a pseudo-random function of the LAST BIT of w, and the weights of the detection
-    components go through exp and a 50-term sum (device and oracle agree to 1e-15, not to the bit — nor would the CLR's
-    Math.Exp with glibc's). The oracle is therefore re-run with its corrected weights moved by one ulp either way: alpha
-    moves by `spread` (a few 1e-4 at this distance; 0 at the origin, where the same check holds to 1e-6 in
-    test_stage_parity), and the device must sit within that band. Stage by stage, on identical inputs, everything is
-    checked tightly in tests/test_gpu_round2.py::test_far_from_the_origin_stage_by_stage."""
+    fl(fl(w (P + m m')) / w) - m m' is a pseudo-random function of the low bits of w, and the weights of the detection
+    components go through exp and a 50-term sum (device and oracle agree to ~1e-13, not to the bit — nor would the CLR's
+    Math.Exp with glibc's). The oracle is therefore re-run 48 times with those weights moved by a relative 1e-13: its
+    alpha scatters with a standard deviation of 2-3e-4 at this distance, whatever the size of the move (1e-15 ... 1e-11
+    give the same scatter; at the origin it is 0 and the same check holds to 1e-6 in test_stage_parity), and the device
+    must sit within 5 standard deviations. Stage by stage, on identical inputs, everything is checked tightly in
+    tests/test_gpu_round2.py::test_far_from_the_origin_stage_by_stage (alpha to 1e-6 there)."""
     P, C, M = 4, 50, 14
     f = Frame(P, C, M, 91, weight_profile="steady")
     shift = np.array([1500.0, -900.0, 1100.0])
@@ -462,12 +463,15 @@ def test_reweight_far_from_the_origin(nav_mod):
         assert len(got[0]) == len(pr[0])
         assert np.allclose(got[0], pr[0], rtol=1e-7) and np.allclose(got[1], pr[1], rtol=1e-12, atol=1e-9)
         a, _ = orc.weight_alpha(p, f.poses[i], f.z, pred, pr)
-        spread = 0.0
-        for _ in range(6):
-            wp = np.nextafter(cor[0], np.where(rng.random(len(cor[0])) < 0.5, 0.0, 2.0))   # every corrected weight one ulp down or up
+        draws = []
+        for _ in range(48):
+            wp = cor[0] * (1 + 1e-13 * rng.normal(size=len(cor[0])))
+            wp[:len(pred[0])] = cor[0][:len(pred[0])]            # the misdetection copies' weights are exact on both sides
             ap, _ = orc.weight_alpha(p, f.poses[i], f.z, pred, orc.prune(p, (wp, cor[1], cor[2])))
-            spread = max(spread, abs(ap - a) / a)
-        assert abs(alpha[i] - a) / a <= max(1e-6, 3 * spread), "alpha[%d]: %r vs %r (one-ulp spread of the oracle %g)" % (i, alpha[i], a, spread)
+            draws.append((ap - a) / a)
+        sigma = float(np.std(draws))
+        print("alpha[%d]: device %r oracle %r, rel %.3g; scatter of the oracle under 1e-13 weight moves: sigma %.3g" % (i, alpha[i], a, abs(alpha[i] - a) / a, sigma))
+        assert abs(alpha[i] - a) / a <= max(1e-6, 5 * sigma), "alpha[%d]: %r vs %r (sigma %g)" % (i, alpha[i], a, sigma)
     nav.close()
 
 
