@@ -38,6 +38,7 @@ public class PhdHipLib
 {
 	const string Lib = "libphdhip.so";
 	[DllImport(Lib)] public extern static IntPtr phd_create(ref PhdParams p, int device);
+	[DllImport(Lib)] public extern static IntPtr phd_create_multi(ref PhdParams p, int[] devices, int ndevices);
 	[DllImport(Lib)] public extern static IntPtr phd_create_error();
 	[DllImport(Lib)] public extern static void   phd_destroy(HandleRef nav);
 	[DllImport(Lib)] public extern static IntPtr phd_last_error(HandleRef nav);
@@ -66,7 +67,10 @@ public unsafe class HipPHDNavigator : Navigator<PRM3DMeasurer, Pose3D, PixelRang
 	public double[] VehicleWeights { get; private set; }
 	public int BestParticle { get; private set; }
 
-	public HipPHDNavigator(Vehicle<PRM3DMeasurer, Pose3D, PixelRangeMeasurement> vehicle, int particlecount, bool onlymapping = false)
+	/// <summary>gpus: how many GPUs of the node the particles are sharded over (devices 0 .. gpus - 1, one handle, this
+	/// thread: phd_create_multi); particlecount must then be a multiple of it. 1, or a mapping-only navigator (one particle):
+	/// a single-device handle.</summary>
+	public HipPHDNavigator(Vehicle<PRM3DMeasurer, Pose3D, PixelRangeMeasurement> vehicle, int particlecount, bool onlymapping = false, int gpus = 1)
 		: base(vehicle, onlymapping)
 	{
 		ParticleCount = particlecount;
@@ -84,7 +88,9 @@ public unsafe class HipPHDNavigator : Navigator<PRM3DMeasurer, Pose3D, PixelRang
 		p.merge_threshold = Config.MergeThreshold; p.exploration_threshold = Config.ExplorationThreshold;
 		p.density_distance_threshold = Config.DensityDistanceThreshold;
 		p.max_particles = particlecount; p.max_components = Math.Max(Config.MaxQuantity, 640); p.max_measurements = 256;
-		IntPtr h = PhdHipLib.phd_create(ref p, 0);
+		int[] devices = new int[Math.Max(gpus, 1)];
+		for (int i = 0; i < devices.Length; i++) devices[i] = i;
+		IntPtr h = (gpus > 1 && !onlymapping) ? PhdHipLib.phd_create_multi(ref p, devices, devices.Length) : PhdHipLib.phd_create(ref p, 0);
 		if (h == IntPtr.Zero) { throw Fail(Marshal.PtrToStringAnsi(PhdHipLib.phd_create_error()), -1); }
 		nav = new HandleRef(this, h);
 		reset(RefVehicle, new double[0], new double[0], new double[0], onlymapping ? 1 : particlecount);

@@ -45,6 +45,15 @@ public:
 		if (!nav_) throw PhdError(PHD_ERR_NO_DEVICE, phd_create_error());
 		reset(pose, Map(), onlymapping ? 1 : particlecount);   // :201-207
 	}
+	// the particles sharded over several GPUs of the node behind one handle (phd_create_multi): params.max_particles and
+	// particlecount are totals, multiples of devices.size()
+	PHDNavigator(const phd_params& params, const Pose3D& pose, int particlecount, const std::vector<int>& devices, bool onlymapping = false)
+		: ParticleCount(particlecount), OnlyMapping(onlymapping)
+	{
+		nav_ = phd_create_multi(&params, devices.data(), (int) devices.size());
+		if (!nav_) throw PhdError(PHD_ERR_NO_DEVICE, phd_create_error());
+		reset(pose, Map(), particlecount);
+	}
 	~PHDNavigator() { Dispose(); }
 	PHDNavigator(const PHDNavigator&) = delete;
 	PHDNavigator& operator=(const PHDNavigator&) = delete;
