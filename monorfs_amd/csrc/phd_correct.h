@@ -47,7 +47,12 @@ __global__ __launch_bounds__(256) void k_emit_finish(const DevParams prm, const 
 	const Bank bin = bank_of(a, SEL_IN);
 	const int n = vin.count[p], np = n + a.born_count[p];
 	const int nmis = a.emit_count[p];
-	const int ncand = a.cand_count[p];
+	// the candidate queue: four segments, one per wave of k_sweep
+	const int segcap = a.candcap >> 2;
+	const int nc0 = a.cand_count[(size_t) p * 4], nc1 = a.cand_count[(size_t) p * 4 + 1], nc2 = a.cand_count[(size_t) p * 4 + 2],
+	          nc3 = a.cand_count[(size_t) p * 4 + 3];
+	const bool overflow = nc0 > segcap || nc1 > segcap || nc2 > segcap || nc3 > segcap;
+	const int ncand = nc0 + nc1 + nc2 + nc3;
 	exp_tab_init(etab, tid);
 	if (tid == 0) s_npair = 0;
 	__syncthreads();   // every thread has read emit_count before thread 0 rewrites it
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(256) void k_emit_finish(const DevParams prm, const 
 #pragma unroll
 		for (int t = 0; t < 6; t++) r[3 + t] = Pn[t];
 	};
-	if (ncand <= a.candcap) {
+	if (!overflow) {
 		// Most queued pairs fail once the real denominator is known. Their exponent x = log(PD w q) travels with
 		// them as a float32: x - log(denom) < log(MinWeight) by more than the float32 rounding settles it; the
 		// others are compacted into a list so that the waves run the heavy path on full lanes.
@@ -99,7 +104,9 @@ __global__ __launch_bounds__(256) void k_emit_finish(const DevParams prm, const 
 			bool keep = false;
 			int  code = 0;
 			if (j < ncand) {
-				const int2 cd = cands[j];
+				// entry j of the four segments laid end to end
+				const int js = (j < nc0) ? j : ((j < nc0 + nc1) ? j - nc0 + segcap : ((j < nc0 + nc1 + nc2) ? j - nc0 - nc1 + 2 * segcap : j - nc0 - nc1 - nc2 + 3 * segcap));
+				const int2 cd = cands[js];
 				code = cd.x;
 				const double x = (double) __int_as_float(cd.y);
 				keep = !(x - ldenom[code & 255] < lminw - 1e-3 - 1e-6 * fabs(x));
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(256) void k_emit_finish(const DevParams prm, const 
 		}
 	}
 	else {
-		// the queue overflowed (more than a quarter of all pairs are candidates): every pair, gate included
+		// a segment of the queue overflowed (more than a quarter of a wave's pairs are candidates): every pair, gate included
 		for (int j = tid; j < np * M; j += 256) {
 			const int c = j / M, k = j - c * M;
 			double w, m[3], P[6], x[3];

@@ -280,6 +280,31 @@ __device__ __forceinline__ double exp_neg(double x, const double* __restrict__ T
 	return ldexp(t * p, ni >> 8);
 }
 
+// The same for the dense pair loops (k_sweep's weight sums, k_alpha_density), three instructions leaner at the front: the
+// argument is clamped by one v_max_f64 and rounded by adding 1.5 * 2^52, which leaves the integer in the low word of the
+// sum (no v_rndne / v_cvt). Same table, same polynomial, same results as exp_neg for finite arguments and -inf; a NaN
+// argument counts as exp(-800) = 0 here (v_max_f64 returns the other operand), where exp_neg keeps it a NaN.
+// keep = false: the result is 0 (the exponent handed to v_ldexp_f64 is replaced: one 32-bit select instead of two on the value)
+__device__ __forceinline__ double exp_pair(double x, const double* __restrict__ T, bool keep = true)
+{
+	// (written out: fmax() puts a canonicalising v_max_f64 in front of the clamp, and the compiler turns the first step of
+	// the polynomial into a register copy + v_fmac_f64 — two instructions each where one does)
+	const double lo = -800.0, c4 = 0.041666666666666664, c3 = 0.16666666666666666;
+	asm("v_max_f64 %0, %1, %2" : "=v"(x) : "v"(x), "s"(lo));
+	const double nd = fma(x, 369.3299304675746, 6755399441055744.0);   // 256 / ln 2; 1.5 * 2^52
+	const int ni = __double2loint(nd);
+	const double n = nd - 6755399441055744.0;
+	double r = fma(-n, 0.002707606166950427, x);
+	r = fma(-n, 7.111859369156821e-12, r);
+	const double t = T[ni & (EXPTAB_N - 1)];
+	double p;
+	asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "s"(c4), "v"(r), "v"(c3));
+	p = fma(p, r, 0.5);
+	p = fma(p, r, 1.0);
+	p = fma(p, r, 1.0);
+	return ldexp(t * p, keep ? (ni >> 8) : -4096);
+}
+
 // A weighted Gaussian w N(x; m, P) in the form the dense evaluation loops use: exp(g9 + d^T G d), d = x - m, with
 // G = -P^-1 / 2 folded for the upper-triangle sum (off-diagonal entries doubled) and g9 = log(w mult).
 __device__ __forceinline__ void gauss_record(double w, const double m[3], const double Pi[6], double mult, double* g)
@@ -398,6 +423,10 @@ __device__ __forceinline__ void kalman_cov(const CompMeas& cm, const double K[9]
 
 // wave-level helpers (wave = 64)
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// The lanes for which `p` holds, as a mask. (HIP's __ballot takes an int and compares it with 0 again: two vector
+// instructions per call in the pair loops; this one is the compare's own result.)
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 __device__ __forceinline__ unsigned long long lanemask_lt()
 {

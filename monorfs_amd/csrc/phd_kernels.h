@@ -80,12 +80,13 @@ struct StepBufs {
 	// (component, measurement) pairs that may reach MinWeight, queued by k_sweep for k_emit_finish
 	int*    cand;        // [P][candcap]
 	int     candcap;
-	int*    cand_count;  // [P] (above candcap: the queue overflowed)
+	int*    cand_count;  // [P][4] entries in each wave's segment of the queue (above candcap / 4: it overflowed)
 	double* denom;       // [P][Mcap] kappa + weightsum[z]
 	double* srec;        // [P][10][cutcap] k_prune_merge: the kept records in sorted order (mean, covariance, weight)
 	// map estimate handed from k_alpha_assoc to k_alpha_density
 	double* alm;         // [P][3][Jcap] landmark means
 	int*    aJ;          // [P] landmarks
+	int*    apick;       // [P][Jcap] corrected component behind landmark j
 	double* account;     // [P] expected size of the corrected map
 	// QuasiSetLogLikelihood batches (k_quasi_setll): candidate poses, the landmark set, its size
 	const double* qposes;   // [P][7]
@@ -94,7 +95,7 @@ struct StepBufs {
 	double* qgrad;       // [P][6] pose gradients (k_quasi_setll_grad)
 	int     qavg;        // TemperedAverage normalisation: 0 as the source reads, 1 weights / their sum
 	double* wcopy;       // [P][cap + Mcap] weight of the surviving misdetection copy of predicted component c (0: none), k_prune_merge -> k_alpha_density
-	int*    cover;       // [P][cap] 1: this pruned component is such a copy
+	int*    cover;       // [P][cap] bit 0: this pruned component is such a copy; above it: its canonical index (of its leader for a merge)
 	double* stamps;      // [P][16] phase stamps of the diagnostic build (NULL otherwise)
 	int     stamp_kernel; // which kernel writes them (env PHD_STAMP_KERNEL): 2 prune, 3 assoc, 4 density, 1 correct
 };

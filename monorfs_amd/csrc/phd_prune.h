@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 				int c = 0;
 				for (int f = 0; f < n; f++) {
 #ifdef PHD_STAMP_COUNTERS
-					if (a.stamps && a.stamp_kernel == 2 && (int) (__ffsll((long long) __ballot(1)) - 1) == lane) atomicAdd(&a.stamps[(size_t) p * 16 + 15], 1.0);   // wave-level trips
+					if (a.stamps && a.stamp_kernel == 2 && (int) (__ffsll((long long) ballot64(1)) - 1) == lane) atomicAdd(&a.stamps[(size_t) p * 16 + 15], 1.0);   // wave-level trips
 #endif
 					if (left == 0) {
 						unsigned int q = nz[0];
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 				return d0 * d0 + d1 * d1 + d2 * d2 <= bound && quad_sym(Pi, d0, d1, d2) < merge_thr2;
 			};
 			auto collect = [&](bool close, int k) {   // the close rows found by the lanes, into the sorted list all lanes keep
-				unsigned long long bal = __ballot(close);
+				unsigned long long bal = ballot64(close);
 				while (bal) {
 					const int l = __ffsll((long long) bal) - 1;
 					bal &= bal - 1;
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 			const int lolo = (int) (unsigned int) vlo, lohi = (int) (unsigned int) (vlo >> 32);
 			const int hilo = (int) (unsigned int) vhi, hihi = (int) (unsigned int) (vhi >> 32);
 			// only rows that have close later rows can change anything: walk those, in order
-			unsigned long long todo = __ballot((lolo & 0xffff) != 0);
+			unsigned long long todo = ballot64((lolo & 0xffff) != 0);
 			while (todo) {
 				const int l = __ffsll((long long) todo) - 1;
 				todo &= todo - 1;
@@ -700,7 +700,7 @@ __global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const 
 	for (int r0 = 0; r0 < cut; r0 += 256) {
 		const int  i = r0 + tid;
 		const bool surv = i < cut && !(((unsigned int) absb[i & 63] >> (i >> 6)) & 1u);
-		unsigned long long bal = __ballot(surv);
+		unsigned long long bal = ballot64(surv);
 		if (lane == 0) scan[wv] = __popcll(bal);
 		__syncthreads();
 		int base = nsurv_before;
@@ -771,7 +771,7 @@ PHD_REF_ARITH
 				for (int t = 0; t < 6; t++) same = same && fabs(oP[t] - rec[3 + t]) <= pscale;
 				if (same) { wcopy[cidx] = ow; covered = 1; }
 			}
-			a.cover[ob] = covered;
+			a.cover[ob] = covered | (cidx << 1);
 		}
 		nsurv_before += total;
 	}

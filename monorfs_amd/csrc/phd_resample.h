@@ -186,7 +186,7 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 		double m = wmax;
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
-		unsigned long long bal = __ballot(wmax == m && c0 < c1);
+		unsigned long long bal = ballot64(wmax == m && c0 < c1);
 		int firstl = bal ? __ffsll((long long) bal) - 1 : 0;
 		int idx = __shfl(imax, firstl, 64);
 		__syncthreads();

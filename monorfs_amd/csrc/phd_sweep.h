@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 	__shared__ double tile[TD];                 // [SW_TILE][20] prior components | [births][13] in the tail
 	__shared__ double etab[EXPTAB_N];
 	__shared__ int    born[MP];
-	__shared__ int    s_ncand, s_nb, s_nmis, s_nu;
+	__shared__ int    s_nb, s_nmis, s_nu;
 	__shared__ int    s_ulist[SW_UMAX];
 	__shared__ double s_du[SW_UMAX];
 
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 	double rq[9];
 	conj_matrix(pose, rq);
 	exp_tab_init(etab, tid);
-	if (tid == 0) { s_ncand = 0; s_nb = 0; s_nmis = 0; s_nu = 0; }
+	if (tid == 0) { s_nb = 0; s_nmis = 0; s_nu = 0; }
 	for (int k = tid; k < MP; k += 256) {
 		double z[3] = {0, 0, 1}, x[3] = {0, 0, 0};
 		if (k < M) {
@@ -67,26 +67,36 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 		wsum[b] = 0; dens[b] = 0;
 	}
 	const double g2c = prm.g2_correct, g2e = prm.g2_explore, thr = prm.expl_thr;
-	int2* cands = (int2*) a.cand + (size_t) p * a.candcap;   // (component << 8 | measurement, exponent as float32) of the pairs worth a second look
+	// (component << 8 | measurement, exponent as float32) of the pairs worth a second look. Every wave appends to a
+	// segment of its own (a quarter of the queue) and counts in a scalar register: no atomic, no LDS round trip in the loop.
+	const int segcap = a.candcap >> 2;
+	int2* cands = (int2*) a.cand + (size_t) p * a.candcap + (size_t) wv * segcap;
+	int ncand_w = 0;   // wave-uniform
 
-	// a pair can only reach MinWeight when PD w q(z) >= MinWeight kappa, i.e. its exponent reaches emit_log_floor (half a
-	// unit of margin for the rounding of the folded form): those are queued for k_emit_finish
-	const double xcut = prm.emit_log_floor - 0.5;
+	// A pair can only reach MinWeight when PD w q(z) >= MinWeight (kappa + weightsum[z]) (:899). The sum is not known
+	// yet, but its terms are >= 0 and this lane's own partial sum only grows: a pair below MinWeight (kappa + partial sum so
+	// far) e^-1/2 — the factor is the margin for the rounding of the folded form — cannot make it. The others are queued
+	// for k_emit_finish, which knows the whole sum.
+	const double cfac = prm.minw * 0.6065306597126334, ckap = cfac * prm.kappa;
 	// the weight-sum part of a visit: component record tt = [zh(3) G(6) lw], squared distance in map space sq
+	// (the masks are built from the bare compares — a ballot of a compound condition costs two vector instructions — and
+	// combined in scalar registers; zvm[b] = the lanes that hold a measurement)
+	unsigned long long zvm[ZB];
+#pragma unroll
+	for (int b = 0; b < ZB; b++) zvm[b] = ballot64(zv[b]);
 	auto weigh = [&](const double* tt, int b, double sq, int c) {
-		double x = gauss_logw(tt, zx[b] - tt[0], zy[b] - tt[1], zr[b] - tt[2]);
-		double v = exp_neg(x, etab);   // PD w * mc.Evaluate(z)
-		const bool near = zv[b] && sq <= g2c;
-		if (near) wsum[b] += v;
-		const bool cand = near && x >= xcut;
-		unsigned long long bal = __ballot(cand);
-		if (bal) {
-			int base = 0, first = __ffsll((long long) bal) - 1;
-			if (lane == first) base = atomicAdd(&s_ncand, __popcll(bal));
-			base = __shfl(base, first, 64);
-			if (cand) {
-				int slot = base + __popcll(bal & lanemask_lt());
-				if (slot < a.candcap) cands[slot] = make_int2((c << 8) | (b * 64 + lane), __float_as_int((float) x));
+		const double x = gauss_logw(tt, zx[b] - tt[0], zy[b] - tt[1], zr[b] - tt[2]);
+		const unsigned long long nm = ballot64(sq <= g2c) & zvm[b];
+		if (nm) {   // (wave-uniform)
+			const double v = exp_pair(x, etab, zv[b] && sq <= g2c);   // PD w * mc.Evaluate(z); 0 outside the gate
+			wsum[b] += v;
+			const unsigned long long bal = ballot64(v >= fma(cfac, wsum[b], ckap)) & nm;
+			if (bal) {
+				if ((bal >> lane) & 1ull) {
+					const int slot = ncand_w + __popcll(bal & lanemask_lt());
+					if (slot < segcap) cands[slot] = make_int2((c << 8) | (b * 64 + lane), __float_as_int((float) x));
+				}
+				ncand_w += __popcll(bal);
 			}
 		}
 	};
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 				}
 			}
 			if (tid >= SW_TILE) {   // (wave-uniform) the misdetection copies that survive MinWeight
-				unsigned long long bal = __ballot(mis);
+				unsigned long long bal = ballot64(mis);
 				if (bal) {
 					int base = 0, first = __ffsll((long long) bal) - 1;
 					if (lane == first) base = atomicAdd(&s_nmis, __popcll(bal));
@@ -199,7 +209,7 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 			for (int b = 0; b < ZB; b++) {
 				const int k = b * 64 + lane;
 				const double d = part2[k] + part2[MP + k] + part2[2 * MP + k] + part2[3 * MP + k];
-				open[b] = __ballot(zv[b] && !(d >= thr));
+				open[b] = ballot64(zv[b] && !(d >= thr));
 				nopen += __popcll(open[b]);
 			}
 			if (nopen <= SW_UMAX) {
@@ -282,7 +292,7 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 				wm  = (1 - q.pd) * prm.birthw;
 				mis = !(wm < prm.minw);
 			}
-			unsigned long long bal = __ballot(mis);
+			unsigned long long bal = ballot64(mis);
 			if (bal) {
 				int base = 0, first = __ffsll((long long) bal) - 1;
 				if (lane == first) base = atomicAdd(&s_nmis, __popcll(bal));
@@ -318,8 +328,8 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 	for (int k = tid; k < M; k += 256) {
 		a.denom[(size_t) p * a.Mcap + k] = prm.kappa + (part[k] + part[MP + k] + part[2 * MP + k] + part[3 * MP + k]);
 	}
+	if (lane == 0) a.cand_count[(size_t) p * 4 + wv] = ncand_w;   // above segcap: the segment overflowed
 	if (tid == 0) {
-		a.cand_count[p] = s_ncand;
 		int ne = nmis0 + s_nmis;
 		if (ne > a.ecap) { atomicOr(a.flags, PHD_FLAG_EMIT_OVERFLOW); ne = a.ecap; }
 		a.emit_count[p] = ne;

@@ -64,7 +64,7 @@ struct phd_navigator {
 	int cmcap = 0;
 	int* d_cand_count = nullptr; double* d_denom = nullptr;
 	int* d_cand = nullptr; int candcap = 0;
-	double* d_alm = nullptr; int* d_aJ = nullptr; double* d_account = nullptr;
+	double* d_alm = nullptr; int* d_aJ = nullptr; double* d_account = nullptr; int* d_apick = nullptr;
 	double* d_stamps = nullptr;
 	double* d_srec = nullptr;
 	double* d_wcopy = nullptr; int* d_cover = nullptr;   // k_prune_merge -> k_alpha_density (see StepBufs)
@@ -205,7 +205,7 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.bigws = nav->d_bigws; b.bigws_bytes = nav->bigws_bytes; b.bigws_used = nav->d_bigws_used;
 	b.cand_count = nav->d_cand_count; b.denom = nav->d_denom;
 	b.cand = nav->d_cand; b.candcap = nav->candcap;
-	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account; b.srec = nav->d_srec; b.wcopy = nav->d_wcopy; b.cover = nav->d_cover; b.stamps = nav->d_stamps; b.stamp_kernel = getenv("PHD_STAMP_KERNEL") ? atoi(getenv("PHD_STAMP_KERNEL")) : 2;
+	b.alm = nav->d_alm; b.apick = nav->d_apick; b.aJ = nav->d_aJ; b.account = nav->d_account; b.srec = nav->d_srec; b.wcopy = nav->d_wcopy; b.cover = nav->d_cover; b.stamps = nav->d_stamps; b.stamp_kernel = getenv("PHD_STAMP_KERNEL") ? atoi(getenv("PHD_STAMP_KERNEL")) : 2;
 	return b;
 }
 
@@ -605,15 +605,15 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	ok = ok && dalloc((void**) &nav->d_bigws, nav->bigws_bytes) && dalloc((void**) &nav->d_bigws_used, 8);
 	if (ok) hipMemset(nav->d_bigws_used, 0, 8);
 	nav->cmcap = nav->cap + nav->Mcap;
-	ok = ok && dalloc((void**) &nav->d_cand_count, (size_t) nav->Pcap * 4) && dalloc((void**) &nav->d_denom, (size_t) nav->Pcap * nav->Mcap * 8);
-	nav->candcap = 16 * nav->cmcap;   // a quarter of all pairs at 64 measurements; beyond it the full second sweep runs
+	ok = ok && dalloc((void**) &nav->d_cand_count, (size_t) nav->Pcap * 4 * 4) && dalloc((void**) &nav->d_denom, (size_t) nav->Pcap * nav->Mcap * 8);
+	nav->candcap = 16 * nav->cmcap;   // a quarter of all pairs at 64 measurements (four wave segments); beyond it the full second sweep runs
 	ok = ok && dalloc((void**) &nav->d_cand, (size_t) nav->Pcap * nav->candcap * 8);
 #ifdef PHD_STAMPS
 	ok = ok && dalloc((void**) &nav->d_stamps, (size_t) nav->Pcap * 16 * 8);
 #endif
 	ok = ok && dalloc((void**) &nav->d_srec, (size_t) nav->Pcap * 11 * nav->cutcap * 8);
 	ok = ok && dalloc((void**) &nav->d_wcopy, (size_t) nav->Pcap * (nav->cap + nav->Mcap) * 8) && dalloc((void**) &nav->d_cover, (size_t) nav->Pcap * nav->cap * 4);
-	ok = ok && dalloc((void**) &nav->d_alm, (size_t) nav->Pcap * 3 * nav->Jcap * 8);
+	ok = ok && dalloc((void**) &nav->d_alm, (size_t) nav->Pcap * 3 * nav->Jcap * 8) && dalloc((void**) &nav->d_apick, (size_t) nav->Pcap * nav->Jcap * 4);
 	ok = ok && dalloc((void**) &nav->d_aJ, (size_t) nav->Pcap * 4) && dalloc((void**) &nav->d_account, (size_t) nav->Pcap * 8);
 	ok = ok && dalloc((void**) &nav->d_jscratch, (size_t) nav->Pcap * alpha_jscratch_doubles(nav->Jcap) * 8);
 	nav->stagecap = std::max((size_t) nav->Pcap * 8 + 8, (size_t) 256 * 3);   // poses + weights | odometry + noise | measurements
@@ -686,7 +686,7 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_sel); hipFree(nav->d_inslot); hipFree(nav->d_mslot); hipFree(nav->d_fslot); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
-	hipFree(nav->d_murty); hipFree(nav->d_bigws); hipFree(nav->d_bigws_used); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_wcopy); hipFree(nav->d_cover); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
+	hipFree(nav->d_murty); hipFree(nav->d_bigws); hipFree(nav->d_bigws_used); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_wcopy); hipFree(nav->d_cover); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_apick); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
 	if (nav->h_pin) hipHostFree(nav->h_pin);
 	for (int i = 0; i < 2; i++) {
