@@ -991,7 +991,6 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 			lm[j] = l0; lm[JS + j] = l1; lm[2 * JS + j] = l2;
 			double* glm = a.alm + (size_t) p * 3 * a.Jcap;   // for k_alpha_density
 			glm[j] = l0; glm[a.Jcap + j] = l1; glm[2 * a.Jcap + j] = l2;
-			a.apick[(size_t) p * a.Jcap + j] = c;
 		}
 	}
 	__threadfence_block();
@@ -1486,40 +1485,20 @@ __global__ __launch_bounds__(256, 4) void k_quasi_setll(const DevParams prm, con
 // k_alpha_density — the two mixture-density sums of WeightAlpha (PHDNavigator.cs:381-384) and its last line:
 //   alpha = exp( L(Z | map estimate, pose) + [sum_j log v_pred(m_j) - sum w_pred] - [sum_j log v_corr(m_j) - sum w_corr] )
 // with v(.) the full, ungated mixture density (Map.Evaluate(point), Map.cs:192-202) and m_j the landmarks of
-// the map estimate left in HBM by k_alpha_assoc.
-//
-// J landmarks x (np + no) components are 58 x 1200 Gaussians on the bench frame, of which a few percent carry the
-// sums: a component further than ~8 sigma from a landmark adds less than 1e-15 of what the landmark's own
-// component adds. So the pairs are SCREENED first and only the survivors are evaluated:
-//   * a lower bound of each sum is known beforehand: landmark j IS the mean of corrected component pick[j], whose own
-//     term is w mult (exponent 0), and the predicted component it descends from (its canonical index, left by
-//     k_prune_merge) gives one term of v_pred(m_j);
-//   * component c can add more than e^-34 of that bound at m_j only if
-//         |m_j - m_c|^2 <= 2 trace(P_c) (log(w_c mult_c) - log bound_j + 34)
-//     (d' P^-1 d >= |d|^2 / lambda_max >= |d|^2 / trace for a positive definite P; otherwise the pair always passes):
-//     8 vector instructions per (64 components, landmark) with the components' fields in registers, against 35 for an
-//     evaluation;
-//   * the passing (component, landmark) pairs are appended to a per-wave list (ballot compaction) and evaluated 64 at
-//     a time, every lane a pair; a wave owns the landmarks j = wave (mod 4), so the sums of a landmark are only ever
-//     touched by one wave, in list order (LDS floating-point adds, same-address lanes in lane order): the result does
-//     not depend on timing.
-// What is left out is below 1200 x e^-34 = 2e-12 of each sum (tests/test_gpu_parity.py holds alpha to 1e-6).
+// the map estimate left in HBM by k_alpha_assoc. Landmark per lane, component tiles broadcast from LDS.
 // =================================================================================================
-#define DENS_JL 128      // landmarks whose sums and bounds stay in LDS
-#define DENS_REC 13      // gauss_record (10), weight ratio of the surviving misdetection copy, hc = 2 trace(P), hg = hc (lw + margin)
-#define DENS_MARGIN 34.0
-#define DENS_PEND 128
+#define DENS_JL 128   // landmarks whose partial sums stay in LDS
+#define DENS_REC 12   // gauss_record + the weight ratio of the component's surviving misdetection copy (+ 1: records stay 16-byte aligned)
 
-__global__ __launch_bounds__(256) void k_alpha_density(const DevParams prm, const StepBufs a)
+__device__ __forceinline__ void alpha_density_body(const DevParams& prm, const StepBufs& a)
 {
 	constexpr int JL = DENS_JL;
-	__shared__ double tile[TILE * DENS_REC];
-	__shared__ double accl[2 * JL];               // sums of v_pred | v_corr (HBM slab when J > JL)
-	__shared__ double lml[5 * JL];                // landmark x y z, log bound for the first sweep, log bound for the second
+	__shared__ double tile[TILE * DENS_REC];     // [TILE][12]
+	__shared__ double partpl[(JL / 64) * 256];   // [JB][4][64] partial densities of v_pred (HBM slab when J > JL)
+	__shared__ double partcl[(JL / 64) * 256];   // the same for v_corr
 	__shared__ double etab[EXPTAB_N];
-	__shared__ unsigned int pend[4][DENS_PEND];   // per wave: (component of the tile << 16) | landmark
 	__shared__ int s_wc[4];
-	double* red = tile;                           // reduction scratch once the sweeps are over
+	double* red = tile;                          // reduction scratch once the sweeps are over
 
 	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int cap = a.cap;
@@ -1531,179 +1510,139 @@ __global__ __launch_bounds__(256) void k_alpha_density(const DevParams prm, cons
 	const size_t sbi = in_base(a, p), sbo = (size_t) p * cap;
 	const int J = a.aJ[p];
 	const int JS = a.Jcap;
-	const bool jl = J <= JL;
-	const double* glm = a.alm + (size_t) p * 3 * JS;   // [3][Jcap]
-	double* gj = a.jscratch + (size_t) p * alpha_jscratch_doubles(a.Jcap);   // (the association kernel's arrays in the slab are dead by now)
-	double* accp = jl ? accl : gj;
-	double* accc = jl ? accl + JL : gj + (size_t) JS;
-	const int LS = jl ? JL : JS;
-	double* lmx = jl ? lml : const_cast<double*>(glm);          // landmark coordinates: [3][LS]
-	double* lb1 = jl ? lml + 3 * JL : gj + 2 * (size_t) JS;     // log of the bound of min(v_pred, v_corr) at landmark j
-	double* lb2 = jl ? lml + 4 * JL : gj + 3 * (size_t) JS;     // log of the bound of v_corr
+	const double* lm = a.alm + (size_t) p * 3 * JS;   // [3][Jcap]
+	double* gj = a.jscratch + (size_t) p * alpha_jscratch_doubles(a.Jcap);
+	double* partp = (J <= JL) ? partpl : gj + 13 * (size_t) JS;   // (the association kernel's arrays in the slab are dead by now)
+	double* partc = (J <= JL) ? partcl : gj;
 	const double* wcopy = a.wcopy + (size_t) p * (cap + a.Mcap);
 	const int* cover = a.cover + sbo;
-	const int* apick = a.apick + (size_t) p * JS;
 	exp_tab_init(etab, tid);
-
-	// component c of the predicted mixture: prior slab entry or a birth
-	auto predicted = [&](int c, double& w, double m[3], double P[6]) {
-		if (c < n) {
-			w = vin.w[sbi + c];
-#pragma unroll
-			for (int t = 0; t < 3; t++) m[t] = vin.m[t][sbi + c];
-#pragma unroll
-			for (int t = 0; t < 6; t++) P[t] = vin.P[t][sbi + c];
-		}
-		else {
-			const double* bm = a.born_mean + ((size_t) p * a.Mcap + (c - n)) * 3;
-			w = prm.birthw;
-			m[0] = bm[0]; m[1] = bm[1]; m[2] = bm[2];
-#pragma unroll
-			for (int t = 0; t < 6; t++) P[t] = prm.birthP[t];
-		}
-	};
-
-	// ---- the landmarks, their sums and the lower bounds
-	for (int j = tid; j < J; j += 256) {
-		const double x0 = glm[j], x1 = glm[JS + j], x2 = glm[2 * JS + j];
-		accp[j] = 0; accc[j] = 0;
-		if (jl) { lmx[j] = x0; lmx[LS + j] = x1; lmx[2 * LS + j] = x2; }
-		const int cp = apick[j];
-		double w, m[3], P[6], Pi[6], det, g[10];
-		w = vout.w[sbo + cp];
-#pragma unroll
-		for (int t = 0; t < 6; t++) P[t] = vout.P[t][sbo + cp];
-		inv_sym3(P, Pi, det);
-		const double lc = log(w * (PHD_INV_2PI / sqrt(fabs(det))));   // the landmark's own component at its own mean
-		const int cidx = cover[cp] >> 1;                              // canonical index of that component (of its leader when it is a merge)
-		const int c = (cidx < np) ? cidx : (cidx - np) % np;          // the predicted component it descends from
-		predicted(c, w, m, P);
-		inv_sym3(P, Pi, det);
-		gauss_record(w, m, Pi, PHD_INV_2PI / sqrt(fabs(det)), g);
-		const double lp = gauss_logw(g, x0 - m[0], x1 - m[1], x2 - m[2]);
-		lb2[j] = lc;
-		lb1[j] = (lp < lc) ? lp : lc;   // (a NaN bound leaves lc)
-	}
-	double pcount_part = 0;
-	for (int c = tid; c < n; c += 256) pcount_part += vin.w[sbi + c];
-	__threadfence_block();
 	__syncthreads();
 
-	// evaluate the first nbt pairs of this wave's list: every lane a pair
-	auto eval_batch = [&](int nbt, int src) {
-		lds_fence();
-		__builtin_amdgcn_wave_barrier();
-		if (lane < nbt) {
-			const unsigned int code = pend[wv][lane];
-			const int cc = (int) (code >> 16), j = (int) (code & 0xffffu);
-			const double* tt = tile + cc * DENS_REC;
-			const double v = exp_pair(gauss_logw(tt, lmx[j] - tt[0], lmx[LS + j] - tt[1], lmx[2 * LS + j] - tt[2]), etab);
-			const double ratio = tt[10];
-			if (jl) {   // (LDS adds: ds_add_f64)
+	// ---- phase 2: sum_j log v_pred(m_j), sum_j log v_corr(m_j) with v = full ungated mixture density (Map.cs:192-202)
+	// Component tiles are staged once and swept for every block of 64 landmarks (landmark per lane, the
+	// component broadcast from LDS). A last block with few landmarks is packed: LJ = 2^k lanes carry the
+	// landmarks and the 64 / LJ lane groups take different components, then the groups are summed.
+	//
+	// Most components of the corrected map are the misdetection copies of predicted components that came through
+	// PruneModel alone: the same Gaussian with the weight (1 - PD) w. Their densities are not evaluated again: the sweep
+	// over the predicted mixture adds ratio_c * (w_c N_c(m_j)) to the corrected sum as well, ratio_c = wcopy[c] / w_c
+	// (k_prune_merge, which also checks that the copy's moments are the component's up to Merge's rounding). The second
+	// sweep takes only the other corrected components (updated by a measurement, merged).
+	double plog_part = 0, clog_part = 0, pcount_part = 0;
+	{
+		const int JB = (J + 63) >> 6;
+		for (int c = tid; c < n; c += 256) pcount_part += vin.w[sbi + c];
+		for (int i = tid; i < JB * 256; i += 256) { partp[i] = 0; partc[i] = 0; }
+		for (int src = 0; src < 2; src++) {
+			const int total = (src == 0) ? np : no;
+			for (int c0 = 0; c0 < total; c0 += TILE) {
+				int c = c0 + tid;
+				int cend;
 				if (src == 0) {
-					unsafeAtomicAdd(&accl[j], v);
-					if (ratio != 0.0) unsafeAtomicAdd(&accl[JL + j], ratio * v);
-				}
-				else unsafeAtomicAdd(&accl[JL + j], v);
-			}
-			else {
-				if (src == 0) {
-					unsafeAtomicAdd(&accp[j], v);
-					if (ratio != 0.0) unsafeAtomicAdd(&accc[j], ratio * v);
-				}
-				else unsafeAtomicAdd(&accc[j], v);
-			}
-		}
-	};
-
-	// ---- the two sweeps: the predicted mixture (which also stands for the corrected components that are its misdetection
-	// copies come through PruneModel alone: the same Gaussian with the weight (1 - PD) w, ratio = wcopy[c] / w_c, see
-	// k_prune_merge), then the other corrected components (updated by a measurement, merged), compacted in map order
-	for (int src = 0; src < 2; src++) {
-		const int total = (src == 0) ? np : no;
-		const double* lb = (src == 0) ? lb1 : lb2;
-		for (int c0 = 0; c0 < total; c0 += TILE) {
-			const int c = c0 + tid;
-			int cend, slot = tid;
-			bool mine = c < total;
-			if (src == 0) cend = min(TILE, total - c0);
-			else {
-				mine = mine && !(cover[c] & 1);
-				const unsigned long long bal = ballot64(mine);
-				if (lane == 0) s_wc[wv] = __popcll(bal);
-				__syncthreads();
-				slot = __popcll(bal & lanemask_lt());
-				for (int q = 0; q < wv; q++) slot += s_wc[q];
-				cend = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
-			}
-			if (mine) {
-				double w, m[3], P[6], Pi[6], det;
-				if (src == 0) predicted(c, w, m, P);
-				else {
-					w = vout.w[sbo + c];
+					if (c < total) {
+						double w, m[3], P[6], Pi[6], det;
+						if (c < n) {
+							w = vin.w[sbi + c];
 #pragma unroll
-					for (int t = 0; t < 3; t++) m[t] = vout.m[t][sbo + c];
+							for (int t = 0; t < 3; t++) m[t] = vin.m[t][sbi + c];
 #pragma unroll
-					for (int t = 0; t < 6; t++) P[t] = vout.P[t][sbo + c];
-				}
-				inv_sym3(P, Pi, det);
-				double* tt = tile + slot * DENS_REC;
-				gauss_record(w, m, Pi, PHD_INV_2PI / sqrt(fabs(det)), tt);
-				tt[10] = (src == 0 && w > 0) ? wcopy[c] / w : 0.0;
-				const bool pd = P[0] > 0 && (P[0] * P[3] - P[1] * P[1]) > 0 && det > 0;   // Sylvester
-				const double hc = pd ? 2.0 * (P[0] + P[3] + P[5]) : 1e-300;                // (no bound: the pair always passes)
-				tt[11] = hc;
-				tt[12] = pd ? hc * (tt[9] + DENS_MARGIN) : INFINITY;
-			}
-			__syncthreads();
-			if (cend > 0) {
-				// this lane's components of the tile (one per group of 64), their screening fields in registers
-				double cx[4], cy[4], cz[4], ch[4], cg[4];
-				unsigned long long cvm[4];
-#pragma unroll
-				for (int g = 0; g < 4; g++) {
-					const int cc = g * 64 + lane;
-					const bool v = cc < cend;
-					cvm[g] = ballot64(v);
-					const double* tt = tile + (v ? cc : 0) * DENS_REC;
-					cx[g] = tt[0]; cy[g] = tt[1]; cz[g] = tt[2]; ch[g] = tt[11]; cg[g] = tt[12];
-				}
-				int npend = 0;   // wave-uniform
-				for (int j = wv; j < J; j += 4) {
-					const double lx = lmx[j], ly = lmx[LS + j], lz = lmx[2 * LS + j], lL = lb[j];
-#pragma unroll
-					for (int g = 0; g < 4; g++) {
-						if (!cvm[g]) continue;   // (uniform)
-						const double d0 = cx[g] - lx, d1 = cy[g] - ly, d2 = cz[g] - lz;
-						const double sq = fma(d2, d2, fma(d1, d1, d0 * d0));
-						const unsigned long long bal = ballot64(sq <= fma(-ch[g], lL, cg[g])) & cvm[g];
-						if (bal) {
-							if ((bal >> lane) & 1ull) pend[wv][npend + __popcll(bal & lanemask_lt())] = ((unsigned int) (g * 64 + lane) << 16) | (unsigned int) j;
-							npend += __popcll(bal);
-							if (npend >= 64) {
-								eval_batch(64, src);
-								const unsigned int rest = (lane < npend - 64) ? pend[wv][64 + lane] : 0u;
-								lds_fence();
-								__builtin_amdgcn_wave_barrier();
-								if (lane < npend - 64) pend[wv][lane] = rest;
-								npend -= 64;
-							}
+							for (int t = 0; t < 6; t++) P[t] = vin.P[t][sbi + c];
 						}
+						else {
+							const double* bm = a.born_mean + ((size_t) p * a.Mcap + (c - n)) * 3;
+							w = prm.birthw;
+							m[0] = bm[0]; m[1] = bm[1]; m[2] = bm[2];
+#pragma unroll
+							for (int t = 0; t < 6; t++) P[t] = prm.birthP[t];
+						}
+						inv_sym3(P, Pi, det);
+						gauss_record(w, m, Pi, PHD_INV_2PI / sqrt(fabs(det)), tile + tid * DENS_REC);
+						tile[tid * DENS_REC + 10] = (w > 0) ? wcopy[c] / w : 0.0;
+					}
+					cend = min(TILE, total - c0);
+				}
+				else {
+					// the corrected components not accounted for by the first sweep, compacted in map order
+					const bool other = c < total && !cover[c];
+					const unsigned long long bal = ballot64(other);
+					if (lane == 0) s_wc[wv] = __popcll(bal);
+					__syncthreads();
+					int slot = __popcll(bal & lanemask_lt());
+					for (int q = 0; q < wv; q++) slot += s_wc[q];
+					cend = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
+					if (other) {
+						double w, m[3], P[6], Pi[6], det;
+						w = vout.w[sbo + c];
+#pragma unroll
+						for (int t = 0; t < 3; t++) m[t] = vout.m[t][sbo + c];
+#pragma unroll
+						for (int t = 0; t < 6; t++) P[t] = vout.P[t][sbo + c];
+						inv_sym3(P, Pi, det);
+						gauss_record(w, m, Pi, PHD_INV_2PI / sqrt(fabs(det)), tile + slot * DENS_REC);
 					}
 				}
-				if (npend > 0) eval_batch(npend, src);
+				__syncthreads();
+				for (int jb = 0; jb < JB && cend > 0; jb++) {
+					const int rem = min(64, J - jb * 64);
+					const int LJ  = (rem > 32) ? 64 : ((rem <= 1) ? 1 : (1 << (32 - __clz(rem - 1))));
+					const int G   = 64 / LJ, g = lane / LJ, jl = lane & (LJ - 1);
+					const bool jv = jl < rem;
+					const int  j  = jb * 64 + jl;
+					const double x0 = jv ? lm[j] : 0, x1 = jv ? lm[JS + j] : 0, x2 = jv ? lm[2 * JS + j] : 0;
+					// w * (mult * exp(-d^T Pinv d / 2)) of component cc at this lane's landmark (Map.cs:198)
+					auto dens = [&](int cc) {
+						const double* tt = tile + cc * DENS_REC;
+						return exp_pair(gauss_logw(tt, x0 - tt[0], x1 - tt[1], x2 - tt[2]), etab);
+					};
+					double acc = 0, acc2 = 0, cacc = 0, cacc2 = 0;
+					int cc = wv * G + g;
+					const int step = 4 * G;
+					if (src == 0) {
+						for (; cc + step < cend; cc += 2 * step) {   // two independent components per trip
+							const double e1 = dens(cc), e2 = dens(cc + step);
+							acc  += e1;
+							acc2 += e2;
+							cacc  = fma(tile[cc * DENS_REC + 10], e1, cacc);
+							cacc2 = fma(tile[(cc + step) * DENS_REC + 10], e2, cacc2);
+						}
+						if (cc < cend) {
+							const double e1 = dens(cc);
+							acc += e1;
+							cacc = fma(tile[cc * DENS_REC + 10], e1, cacc);
+						}
+						partp[(jb * 4 + wv) * 64 + lane] += acc + acc2;   // own slot
+						partc[(jb * 4 + wv) * 64 + lane] += cacc + cacc2;
+					}
+					else {
+						for (; cc + step < cend; cc += 2 * step) {
+							acc  += dens(cc);
+							acc2 += dens(cc + step);
+						}
+						if (cc < cend) acc += dens(cc);
+						partc[(jb * 4 + wv) * 64 + lane] += acc + acc2;
+					}
+				}
+				__syncthreads();
+			}
+			__threadfence_block();
+			__syncthreads();
+			const double* part = (src == 0) ? partp : partc;
+			for (int jb = wv; jb < JB; jb += 4) {
+				const int rem = min(64, J - jb * 64);
+				const int LJ  = (rem > 32) ? 64 : ((rem <= 1) ? 1 : (1 << (32 - __clz(rem - 1))));
+				const int jl = lane & (LJ - 1);
+				double v = part[(jb * 4 + 0) * 64 + lane] + part[(jb * 4 + 1) * 64 + lane] + part[(jb * 4 + 2) * 64 + lane] +
+				           part[(jb * 4 + 3) * 64 + lane];
+				for (int o = LJ; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+				if (lane < LJ && jl < rem) {
+					if (src == 0) plog_part += log(v);
+					else          clog_part += log(v);
+				}
 			}
 			__syncthreads();
 		}
 	}
-	__threadfence_block();
-	__syncthreads();
-	double plog_part = 0, clog_part = 0;
-	for (int j = tid; j < J; j += 256) {
-		plog_part += log(accp[j]);
-		clog_part += log(accc[j]);
-	}
-	__syncthreads();
 	// block reductions (fixed order)
 	auto block_sum = [&](double v) {
 		red[tid] = v;
@@ -1726,4 +1665,9 @@ __global__ __launch_bounds__(256) void k_alpha_density(const DevParams prm, cons
 		a.alpha[p] = alpha;
 		bout.weights[p] = bin.weights[p] * alpha;           // :335
 	}
+}
+
+__global__ __launch_bounds__(256) void k_alpha_density(const DevParams prm, const StepBufs a)
+{
+	alpha_density_body(prm, a);
 }

@@ -37,7 +37,7 @@ __device__ __forceinline__ void load_predicted(const DevParams& prm, const StepB
 }
 
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_emit_finish(const DevParams prm, const StepBufs a)
+__device__ __forceinline__ void emit_finish_body(const DevParams& prm, const StepBufs& a)
 {
 	__shared__ double etab[EXPTAB_N];
 	__shared__ int    s_npair;
@@ -140,4 +140,9 @@ __global__ __launch_bounds__(256) void k_emit_finish(const DevParams prm, const 
 		if (nmis + s_npair > a.ecap) atomicOr(a.flags, PHD_FLAG_EMIT_OVERFLOW);
 		a.emit_count[p] = min(nmis + s_npair, a.ecap);
 	}
+}
+
+__global__ __launch_bounds__(256) void k_emit_finish(const DevParams prm, const StepBufs a)
+{
+	emit_finish_body(prm, a);
 }

@@ -86,7 +86,6 @@ struct StepBufs {
 	// map estimate handed from k_alpha_assoc to k_alpha_density
 	double* alm;         // [P][3][Jcap] landmark means
 	int*    aJ;          // [P] landmarks
-	int*    apick;       // [P][Jcap] corrected component behind landmark j
 	double* account;     // [P] expected size of the corrected map
 	// QuasiSetLogLikelihood batches (k_quasi_setll): candidate poses, the landmark set, its size
 	const double* qposes;   // [P][7]
@@ -95,7 +94,7 @@ struct StepBufs {
 	double* qgrad;       // [P][6] pose gradients (k_quasi_setll_grad)
 	int     qavg;        // TemperedAverage normalisation: 0 as the source reads, 1 weights / their sum
 	double* wcopy;       // [P][cap + Mcap] weight of the surviving misdetection copy of predicted component c (0: none), k_prune_merge -> k_alpha_density
-	int*    cover;       // [P][cap] bit 0: this pruned component is such a copy; above it: its canonical index (of its leader for a merge)
+	int*    cover;       // [P][cap] 1: this pruned component is such a copy
 	double* stamps;      // [P][16] phase stamps of the diagnostic build (NULL otherwise)
 	int     stamp_kernel; // which kernel writes them (env PHD_STAMP_KERNEL): 2 prune, 3 assoc, 4 density, 1 correct
 };
@@ -143,6 +142,29 @@ __device__ __forceinline__ size_t in_base(const StepBufs& a, int p) { return (si
 #include "phd_alpha.h"
 
 #include "phd_resample.h"
+
+// The per-particle chain of a step as ONE launch, for small particle sets (the real-time regime of the reference: 20 - 800
+// particles at 30 Hz, plots/scripts/chap3/S4-particles.sh:14-15; BASELINE config A): a particle's predict / correct / prune /
+// reweight touch nothing of another particle, so its workgroup runs the five kernels' bodies back to back, with a
+// workgroup barrier where a launch boundary was. With at most one or two workgroups per CU the kernels were latency-bound
+// launches of 8 - 30 us each with a ramp and a tail; here there are no boundaries until the particle weights meet in
+// k_normalise_resample. One workgroup per CU (the bodies' LDS arrays add up to ~115 KB), registers to spare.
+template <int ZB>
+__global__ __launch_bounds__(256, 1) void k_particle_chain(const DevParams prm, const StepBufs a, int cutcap, int with_alpha)
+{
+	extern __shared__ __align__(16) double smem[];
+	sweep_body<ZB>(prm, a);
+	__syncthreads();   // (workgroup scope: the global writes of the step before are visible to this workgroup's loads)
+	emit_finish_body(prm, a);
+	__syncthreads();
+	prune_merge_body(prm, a, cutcap, smem);
+	if (with_alpha) {
+		__syncthreads();
+		alpha_assoc_body<ZB, false>(prm, a, cutcap, smem);
+		__syncthreads();
+		alpha_density_body(prm, a);
+	}
+}
 
 // The sharded step's rotation when no rank resampled (the single-handle step does this inside k_normalise_resample,
 // rotate_roles in phd_resample.h, where the rules are written down): roles (IN, OUT, TMP, INMIX) = (O, I, T, O), slots

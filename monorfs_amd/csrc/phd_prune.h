@@ -169,9 +169,8 @@ __device__ __forceinline__ void prune_sort(unsigned long long* sv, int n, int ti
 	}
 }
 
-__global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const StepBufs a, int cutcap)
+__device__ __forceinline__ void prune_merge_body(const DevParams& prm, const StepBufs& a, int cutcap, double* smem)
 {
-	extern __shared__ __align__(16) double smem[];
 	const PruneLds lay = prune_lds(cutcap);
 	const int cc = (cutcap + 1) & ~1, NS = lay.NS;
 	double* rad2  = smem + lay.rad2;                       // [cut] squared Euclidean bound of row i (inf: none)
@@ -771,11 +770,17 @@ PHD_REF_ARITH
 				for (int t = 0; t < 6; t++) same = same && fabs(oP[t] - rec[3 + t]) <= pscale;
 				if (same) { wcopy[cidx] = ow; covered = 1; }
 			}
-			a.cover[ob] = covered | (cidx << 1);
+			a.cover[ob] = covered;
 		}
 		nsurv_before += total;
 	}
 	PHD_STAMP(5);
 	if (tid == 0) vout.count[p] = nsurv_before;
 	PHD_STAMP_FLUSH(2, 11);
+}
+
+__global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const StepBufs a, int cutcap)
+{
+	extern __shared__ __align__(16) double smem[];
+	prune_merge_body(prm, a, cutcap, smem);
 }

@@ -18,7 +18,7 @@
 
 // =================================================================================================
 template <int ZB>
-__global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const StepBufs a)
+__device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs& a)
 {
 	constexpr int MP = ZB * 64;
 	constexpr int TD = (SW_TILE * SW_REC > MP * 13) ? SW_TILE * SW_REC : MP * 13;
@@ -334,4 +334,10 @@ __global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const Ste
 		if (ne > a.ecap) { atomicOr(a.flags, PHD_FLAG_EMIT_OVERFLOW); ne = a.ecap; }
 		a.emit_count[p] = ne;
 	}
+}
+
+template <int ZB>
+__global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const StepBufs a)
+{
+	sweep_body<ZB>(prm, a);
 }

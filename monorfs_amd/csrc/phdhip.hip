@@ -36,6 +36,7 @@ struct phd_navigator {
 	hipStream_t own_stream = nullptr;  // created by phd_create; `stream` unless the host lent its own
 	static const int MAXSPLIT = 4;
 	int         nsplit = 0;            // sub-ranges a step's per-particle kernels are split into (0: chosen from the particle count)
+	int         chain_max = 320;       // up to this many particles a step's per-particle kernels run as one launch (k_particle_chain; env PHD_CHAIN_MAX)
 	hipStream_t aux[MAXSPLIT - 1] = {nullptr, nullptr, nullptr};   // streams of the sub-ranges after the first
 	hipEvent_t  ev_fork = nullptr, ev_join[MAXSPLIT - 1] = {nullptr, nullptr, nullptr};
 	bool sel_host_valid = false;       // h_sel mirrors the device-side bank roles without a round trip
@@ -64,7 +65,7 @@ struct phd_navigator {
 	int cmcap = 0;
 	int* d_cand_count = nullptr; double* d_denom = nullptr;
 	int* d_cand = nullptr; int candcap = 0;
-	double* d_alm = nullptr; int* d_aJ = nullptr; double* d_account = nullptr; int* d_apick = nullptr;
+	double* d_alm = nullptr; int* d_aJ = nullptr; double* d_account = nullptr;
 	double* d_stamps = nullptr;
 	double* d_srec = nullptr;
 	double* d_wcopy = nullptr; int* d_cover = nullptr;   // k_prune_merge -> k_alpha_density (see StepBufs)
@@ -205,7 +206,7 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.bigws = nav->d_bigws; b.bigws_bytes = nav->bigws_bytes; b.bigws_used = nav->d_bigws_used;
 	b.cand_count = nav->d_cand_count; b.denom = nav->d_denom;
 	b.cand = nav->d_cand; b.candcap = nav->candcap;
-	b.alm = nav->d_alm; b.apick = nav->d_apick; b.aJ = nav->d_aJ; b.account = nav->d_account; b.srec = nav->d_srec; b.wcopy = nav->d_wcopy; b.cover = nav->d_cover; b.stamps = nav->d_stamps; b.stamp_kernel = getenv("PHD_STAMP_KERNEL") ? atoi(getenv("PHD_STAMP_KERNEL")) : 2;
+	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account; b.srec = nav->d_srec; b.wcopy = nav->d_wcopy; b.cover = nav->d_cover; b.stamps = nav->d_stamps; b.stamp_kernel = getenv("PHD_STAMP_KERNEL") ? atoi(getenv("PHD_STAMP_KERNEL")) : 2;
 	return b;
 }
 
@@ -263,6 +264,7 @@ const char* T_WA = "k_alpha_assoc";
 const char* T_WD = "k_alpha_density";
 const char* T_NR = "k_normalise_resample";
 const char* T_GR = "k_gather_rotate";
+const char* T_CH = "k_particle_chain";
 
 // The per-particle kernels of a step. With nsplit > 1 the particle range is cut into sub-ranges whose kernel
 // chains run on concurrent streams (forked from and joined back into the handle's stream), so that the
@@ -276,6 +278,14 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha)
 	const int S = std::max(1, std::min(std::min(want, (int) phd_navigator::MAXSPLIT), P));
 	const size_t lp = (size_t) prune_lds(nav->cutcap).bytes;
 	const AlphaLds lay = alpha_lds(ZB * 64, nav->cutcap);   // (the dynamic LDS limits of the kernels were raised once, in phd_create)
+	if (P <= nav->chain_max) {
+		// a small particle set: the whole per-particle chain as one launch
+		timer_begin(nav, T_CH);
+		hipLaunchKernelGGL(k_particle_chain<ZB>, dim3(P), dim3(256), std::max(lp, (size_t) lay.bytes), nav->stream, nav->dp, b0, nav->cutcap, with_alpha ? 1 : 0);
+		timer_end(nav, T_CH);
+		HC(hipGetLastError());
+		return PHD_OK;
+	}
 	if (S > 1) {
 		HC(hipEventRecord(nav->ev_fork, nav->stream));
 		for (int s = 1; s < S; s++) HC(hipStreamWaitEvent(nav->aux[s - 1], nav->ev_fork, 0));
@@ -577,6 +587,7 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	}
 	ok = ok && hipEventCreateWithFlags(&nav->ev_fork, hipEventDisableTiming) == hipSuccess;
 	if (const char* e = getenv("PHD_SPLIT")) nav->nsplit = std::max(0, atoi(e));
+	if (const char* e = getenv("PHD_CHAIN_MAX")) nav->chain_max = std::max(0, atoi(e));
 	size_t plane = (size_t) nav->Pcap * nav->cap;
 	for (int i = 0; i < 3 && ok; i++) {
 		ok = ok && dalloc((void**) &nav->bank[i].mix, plane * 10 * 8);
@@ -613,7 +624,7 @@ phd_navigator* phd_create(const phd_params* params, int device)
 #endif
 	ok = ok && dalloc((void**) &nav->d_srec, (size_t) nav->Pcap * 11 * nav->cutcap * 8);
 	ok = ok && dalloc((void**) &nav->d_wcopy, (size_t) nav->Pcap * (nav->cap + nav->Mcap) * 8) && dalloc((void**) &nav->d_cover, (size_t) nav->Pcap * nav->cap * 4);
-	ok = ok && dalloc((void**) &nav->d_alm, (size_t) nav->Pcap * 3 * nav->Jcap * 8) && dalloc((void**) &nav->d_apick, (size_t) nav->Pcap * nav->Jcap * 4);
+	ok = ok && dalloc((void**) &nav->d_alm, (size_t) nav->Pcap * 3 * nav->Jcap * 8);
 	ok = ok && dalloc((void**) &nav->d_aJ, (size_t) nav->Pcap * 4) && dalloc((void**) &nav->d_account, (size_t) nav->Pcap * 8);
 	ok = ok && dalloc((void**) &nav->d_jscratch, (size_t) nav->Pcap * alpha_jscratch_doubles(nav->Jcap) * 8);
 	nav->stagecap = std::max((size_t) nav->Pcap * 8 + 8, (size_t) 256 * 3);   // poses + weights | odometry + noise | measurements
@@ -625,7 +636,7 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	{
 		// dynamic LDS limits, once: they depend on the handle's capacities only (the same kernels serve every handle of the
 		// process: the limit is only ever raised)
-		static int lim_prune = 0, lim_alpha[3] = {0, 0, 0};
+		static int lim_prune = 0, lim_alpha[3] = {0, 0, 0}, lim_chain[3] = {0, 0, 0};
 		const int lp = prune_lds(nav->cutcap).bytes;
 		if (lp > lim_prune) { ok = ok && hipFuncSetAttribute((const void*) k_prune_merge, hipFuncAttributeMaxDynamicSharedMemorySize, lp) == hipSuccess; lim_prune = lp; }
 		const int la[3] = {alpha_lds(64, nav->cutcap).bytes, alpha_lds(128, nav->cutcap).bytes, alpha_lds(256, nav->cutcap).bytes};
@@ -647,6 +658,10 @@ phd_navigator* phd_create(const phd_params* params, int device)
 			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll_grad<4>, hipFuncAttributeMaxDynamicSharedMemorySize, la[2]) == hipSuccess;
 			lim_alpha[2] = la[2];
 		}
+		const int lc[3] = {std::max(lp, la[0]), std::max(lp, la[1]), std::max(lp, la[2])};
+		if (lc[0] > lim_chain[0]) { ok = ok && hipFuncSetAttribute((const void*) k_particle_chain<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lc[0]) == hipSuccess; lim_chain[0] = lc[0]; }
+		if (lc[1] > lim_chain[1]) { ok = ok && hipFuncSetAttribute((const void*) k_particle_chain<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lc[1]) == hipSuccess; lim_chain[1] = lc[1]; }
+		if (lc[2] > lim_chain[2]) { ok = ok && hipFuncSetAttribute((const void*) k_particle_chain<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lc[2]) == hipSuccess; lim_chain[2] = lc[2]; }
 		hipFuncAttributes fa;
 		if (ok && hipFuncGetAttributes(&fa, (const void*) k_normalise_resample) == hipSuccess) {
 			nav->nr_static_lds = (int) fa.sharedSizeBytes;
@@ -686,7 +701,7 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_sel); hipFree(nav->d_inslot); hipFree(nav->d_mslot); hipFree(nav->d_fslot); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
-	hipFree(nav->d_murty); hipFree(nav->d_bigws); hipFree(nav->d_bigws_used); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_wcopy); hipFree(nav->d_cover); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_apick); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
+	hipFree(nav->d_murty); hipFree(nav->d_bigws); hipFree(nav->d_bigws_used); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_wcopy); hipFree(nav->d_cover); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
 	if (nav->h_pin) hipHostFree(nav->h_pin);
 	for (int i = 0; i < 2; i++) {

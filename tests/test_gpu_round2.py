@@ -336,3 +336,27 @@ def test_association_workspace_exhausted_is_an_error_that_keeps_the_state(nav_mo
     nav.SlamUpdate(None, f.z)
     assert np.isclose(nav.VehicleWeights.sum(), 1.0)
     nav.close()
+
+
+def test_one_launch_chain_equals_the_separate_kernels(nav_mod, monkeypatch):
+    """Small particle sets run predict / correct / prune / reweight as one launch (k_particle_chain: the five kernels'
+    bodies back to back in the particle's workgroup); the same steps through the five separate launches must give the
+    same bits."""
+    f = Frame(40, 90, 20, 321, weight_profile="steady")
+    rng = np.random.default_rng(9)
+    zs = [f.z + rng.normal(size=f.z.shape) * np.sqrt([2.0, 2.0, 1e-3]) * 0.3 for _ in range(3)]
+
+    def run(chain_max):
+        monkeypatch.setenv("PHD_CHAIN_MAX", str(chain_max))
+        nav, _ = make_nav(nav_mod, f)
+        out = []
+        for k, z in enumerate(zs):
+            nav.SlamUpdate(None, z, u_resample=0.2 + 0.3 * k)
+            out.append((nav.VehicleWeights, nav.resample_sources(), nav.BestParticle, [nav.MapModel(i) for i in (0, 13, 39)]))
+        nav.close()
+        return out
+
+    for (wa, sa, ba, ma), (wb, sb, bb, mb) in zip(run(0), run(1000)):
+        assert np.array_equal(wa, wb) and np.array_equal(sa[0], sb[0]) and sa[1] == sb[1] and ba == bb
+        for x, y in zip(ma, mb):
+            assert all(np.array_equal(u, v) for u, v in zip(x, y))
