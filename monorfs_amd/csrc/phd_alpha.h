@@ -332,7 +332,9 @@ __device__ __forceinline__ MurtyLds murty_lds(double* base)
 // the loop of SetLogLikelihood does (PHDNavigator.cs:501-509), including its read of the stale
 // logcomp[m] left by earlier clusters. Returns the number of values written. Wave-uniform.
 // hook(m, unsolved, colof): the pairing recorded at index m; colof(row) = its column (wave-uniform row).
-template <int NT, class Hook>
+// (TAG: kernels with different register budgets — the one-launch chain against the four-workgroups-per-CU kernels — must
+// not share one out-of-line copy: it would be compiled for the larger budget and drag the others' occupancy down)
+template <int NT, int TAG, class Hook>
 __device__ __noinline__ int wave_murty(const MurtyLds& ws, const MurtyWs& nd, int n, int lane, Hook hook)
 {
 	const double* profit = nd.profit;
@@ -531,12 +533,12 @@ __device__ __noinline__ int wave_murty(const MurtyLds& ws, const MurtyWs& nd, in
 }
 
 // the same for any cluster size the solver takes: the number of rows picks the register layout
-template <class Hook>
+template <int TAG, class Hook>
 __device__ __forceinline__ int wave_murty_any(const MurtyLds& ws, const MurtyWs& nd, int n, int lane, Hook hook)
 {
-	if (n <= 64) return wave_murty<1>(ws, nd, n, lane, hook);
-	if (n <= 128) return wave_murty<2>(ws, nd, n, lane, hook);
-	return wave_murty<4>(ws, nd, n, lane, hook);
+	if (n <= 64) return wave_murty<1, TAG>(ws, nd, n, lane, hook);
+	if (n <= 128) return wave_murty<2, TAG>(ws, nd, n, lane, hook);
+	return wave_murty<4, TAG>(ws, nd, n, lane, hook);
 }
 
 // ---- gradient mode of QuasiSetLogLikelihood (PHDNavigator.cs:543-713 with calcgradient) ----
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(64) void k_test_pairing(MurtyNodes* nodes, char* bi
 		});
 	}
 	else {
-		m = wave_murty_any(ws, nd, n, lane, [&](int k, bool unsolved, auto colof) {
+		m = wave_murty_any<0>(ws, nd, n, lane, [&](int k, bool unsolved, auto colof) {
 			if (k >= maxcount) return;
 			for (int r = lane; r < n; r += 64) assignments[k * n + r] = unsolved ? -1 : colof(r);
 		});
@@ -710,7 +712,7 @@ __host__ __device__ inline size_t alpha_jscratch_doubles(int Jcap)
 // GRAD (with QUASI): also the pose gradient (:543-548). Every cluster is then enumerated literally and in the
 //                reference's order by wave 0 — TemperedAverage rewrites logcomp in place (MatrixExtensions.cs:429-431)
 //                and normalises over the whole array, so each cluster sees what the previous ones left.
-template <int ZB, bool QUASI, bool GRAD = false>
+template <int ZB, bool QUASI, bool GRAD = false, int TAG = 0>
 __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const StepBufs& a, int ncap, double* smem)
 {
 	constexpr int MP = ZB * 64;
@@ -1378,7 +1380,7 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 						}
 					}
 					else {
-						mcount = wave_murty_any(ws, nd, nrow, lane, [&](int m, bool unsolved, auto colof) {
+						mcount = wave_murty_any<TAG>(ws, nd, nrow, lane, [&](int m, bool unsolved, auto colof) {
 							if (!GRAD) return;
 							double g = 0;
 							if (!unsolved) g = pairing_gradient(colof);

@@ -160,9 +160,29 @@ __global__ __launch_bounds__(256, 1) void k_particle_chain(const DevParams prm, 
 	prune_merge_body(prm, a, cutcap, smem);
 	if (with_alpha) {
 		__syncthreads();
-		alpha_assoc_body<ZB, false>(prm, a, cutcap, smem);
+		alpha_assoc_body<ZB, false, false, 1>(prm, a, cutcap, smem);
 		__syncthreads();
 		alpha_density_body(prm, a);
+	}
+}
+
+// Test surface (phd_stage_map, PHD_STAGE_CORRECTED): the emitted list carries no mean / covariance for the misdetection
+// copies (k_sweep writes their weight and index only); this fills them in from the predicted components.
+__global__ __launch_bounds__(256) void k_expand_emit(const DevParams prm, const StepBufs a)
+{
+	const int p = a.p0 + blockIdx.x, tid = threadIdx.x;
+	const MixView vin = bank_view(a, SEL_IN);
+	const int n = vin.count[p], np = n + a.born_count[p], ne = a.emit_count[p];
+	const size_t eb = (size_t) p * a.ecap;
+	for (int e = tid; e < ne; e += 256) {
+		const int cidx = a.emit_idx[eb + e];
+		if (cidx < np) {
+			double w, v[9];
+			load_predicted(prm, a, vin, p, n, cidx, w, v, v + 3);
+			double* r = a.emit_rec + (eb + e) * 9;
+#pragma unroll
+			for (int t = 0; t < 9; t++) r[t] = v[t];
+		}
 	}
 }
 

@@ -245,17 +245,27 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 	// A pair can only be close when |m_i - m_k|^2 <= T^2 trace(P_i) (d^T P_i^-1 d >= |d|^2 / lambda_max(P_i) >=
 	// |d|^2 / trace(P_i) for a positive definite P_i).
 	double lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY, rmx = 0;
+	const MixView vpre = bank_view(a, SEL_IN);
+	const int nprior = vpre.count[p], npredicted = nprior + a.born_count[p];
 	for (int r = tid; r < cut; r += 256) {
 		const int slt = prune_slot(sv[r]);
-		const double* rec = a.emit_rec + (eb + slt) * 9;
+		const int cidx = a.emit_idx[eb + slt];   // position in the reference's `corrected` list
 		double v[9];
+		if (cidx < npredicted) {
+			// a misdetection copy (PHDNavigator.cs:837-840): the predicted component with another weight, read where it is
+			double wp_;
+			load_predicted(prm, a, vpre, p, nprior, cidx, wp_, v, v + 3);
+		}
+		else {
+			const double* rec = a.emit_rec + (eb + slt) * 9;
 #pragma unroll
-		for (int t = 0; t < 9; t++) v[t] = rec[t];
+			for (int t = 0; t < 9; t++) v[t] = rec[t];
+		}
 		const double w = a.emit_w[eb + slt];
 #pragma unroll
 		for (int t = 0; t < 9; t++) srec[(size_t) t * cutcap + r] = v[t];
 		srec[(size_t) 9 * cutcap + r] = w;
-		srec[(size_t) 10 * cutcap + r] = (double) a.emit_idx[eb + slt];   // position in the reference's `corrected` list
+		srec[(size_t) 10 * cutcap + r] = (double) cidx;
 		const double P0 = v[3], P1 = v[4], P2 = v[5], P3 = v[6], P4 = v[7], P5 = v[8];
 		double det = P0 * (P3 * P5 - P4 * P4) - P1 * (P1 * P5 - P4 * P2) + P2 * (P1 * P4 - P3 * P2);
 		bool pd = P0 > 0 && (P0 * P3 - P1 * P1) > 0 && det > 0;   // Sylvester

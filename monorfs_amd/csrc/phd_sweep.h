@@ -149,13 +149,11 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 					if (mis) {
 						int slot = base + __popcll(bal & lanemask_lt());
 						if (slot < a.ecap) {
+							// (weight and index only: the copy's mean and covariance are the predicted component's, which
+							// k_prune_merge reads where they are — 12 bytes instead of 84 per copy)
 							size_t e = (size_t) p * a.ecap + slot;
 							a.emit_w[e]   = wm;
 							a.emit_idx[e] = c;
-							double* r = a.emit_rec + e * 9;
-							r[0] = m[0]; r[1] = m[1]; r[2] = m[2];
-#pragma unroll
-							for (int t = 0; t < 6; t++) r[3 + t] = P[t];
 						}
 					}
 				}
@@ -303,10 +301,6 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 						size_t e = (size_t) p * a.ecap + slot;
 						a.emit_w[e]   = wm;
 						a.emit_idx[e] = n + bi;
-						double* r = a.emit_rec + e * 9;
-						r[0] = m[0]; r[1] = m[1]; r[2] = m[2];
-#pragma unroll
-						for (int t = 0; t < 6; t++) r[3 + t] = prm.birthP[t];
 					}
 				}
 			}

@@ -1162,6 +1162,8 @@ int phd_stage_run(phd_navigator* nav, const double* z3, int nmeasurements, uint8
 	HC(hipMemsetAsync(nav->d_bigws_used, 0, 8, nav->stream));
 	rc = launch_map(nav, b, with_alpha != 0);
 	if (rc) return rc;
+	hipLaunchKernelGGL(k_expand_emit, dim3(nav->P), dim3(256), 0, nav->stream, nav->dp, b);   // PHD_STAGE_CORRECTED reads whole records
+	HC(hipGetLastError());
 	rc = sync_state(nav);
 	if (rc) return rc;
 	nav->stage_valid = true;

@@ -55,22 +55,6 @@ class DeviceSolver:
         return self.nav.poses()[b], self.nav.MapModel(b)
 
 
-class OracleSolver:
-    def __init__(self, p, pose, particles):
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import orc
-        self.orc, self.p = orc, p
-        self.st = orc.State(particles, 900)
-        self.st.poses[:] = pose
-        self.best = 0
-
-    def step(self, reading, noise, z, u):
-        self.st.poses[:] = self.orc.update_motion(self.st.poses, reading, noise)
-        if len(z):
-            self.best, _, _, _ = self.orc.slam_update(self.p, self.st, z, u=u, threads=8)
-        return self.st.poses[self.best].copy(), tuple(np.array(x) for x in self.st.map(self.best))   # copies: the slab moves on
-
-
 def replay(rec, particles, seed, solver_cls):
     frames = frames_of(rec)
     p, pose = params_of(rec, particles, max(len(z) for _, _, z in frames))
@@ -95,13 +79,14 @@ def replay(rec, particles, seed, solver_cls):
 def make_synthetic_record(path, frames=12, landmarks=14, seed=3):
     """a vehicle drifting forward past a handful of landmarks; measurements = MeasurePerfect + N(0, R) of the visible
     ones (+ one clutter point now and then), written exactly as Simulation.SaveToFile would"""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import orc
+    from monorfs_amd import prm3d
+    from monorfs_amd.pose3d import add_odometry
     rng = np.random.default_rng(seed)
     p = prm3d_defaults()
+    focal, measurer, ramp = p.measurer[0], list(p.measurer), list(p.visibility_ramp)
     pose = np.array([0, 0, 0, 1.0, 0, 0, 0])
     zs = np.column_stack([rng.uniform(-260, 260, landmarks), rng.uniform(-190, 190, landmarks), rng.uniform(0.5, 1.6, landmarks)])
-    lm = np.array([orc.measure_to_map(p, pose, z) for z in zs])
+    lm = np.array([prm3d.measure_to_map(pose, z, focal) for z in zs])
     scene = rio.serialize_scene(pose, p.measurer, lm)
     _, _, lm = rio.scene_from_descriptor(scene)                     # what a reader of the file sees
     odo, meas, traj = [], [], []
@@ -109,11 +94,11 @@ def make_synthetic_record(path, frames=12, landmarks=14, seed=3):
     for k in range(frames):
         t = k / 30.0
         reading = np.array([0.004, 0.001 * np.sin(k), 0.006, 0.002, -0.001, 0.0005]) if k else np.zeros(6)
-        pose = orc.add_odometry(pose, reading)
+        pose = add_odometry(pose, reading)
         pts = []
         for x in lm:
-            z = orc.measure_perfect(p, pose, x)
-            if orc.detection_probability(p, pose, x) > 0 and rng.uniform() < 0.9:
+            z = prm3d.measure_perfect(pose, x, focal)
+            if prm3d.fuzzy_visible(z, measurer, ramp) > 0 and rng.uniform() < 0.9:
                 pts.append(z + rng.normal(size=3) * np.sqrt(np.diag(R)))
         if k % 4 == 1:
             pts.append([rng.uniform(-300, 300), rng.uniform(-220, 220), rng.uniform(0.3, 1.8)])
@@ -134,7 +119,6 @@ def main():
     ap.add_argument("--particles", type=int, default=32)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--out")
-    ap.add_argument("--oracle", action="store_true", help="also run the CPU oracle on the same stream and compare")
     a = ap.parse_args()
     if a.make:
         print("wrote", make_synthetic_record(a.make, a.frames))
@@ -146,10 +130,6 @@ def main():
         rio.write_record(a.out, dict(rec, **out))
     maps = rio.map_history_from_descriptor(out["maps.out"])
     print("replayed %d frames, final map: %d components, expected size %.3f" % (len(maps), len(maps[-1][1][0]), maps[-1][1][0].sum()))
-    if a.oracle:
-        ref = replay(rec, a.particles, a.seed, OracleSolver)
-        same = sum(x == y for x, y in zip(out["maps.out"].split("\n"), ref["maps.out"].split("\n")))
-        print("oracle on the same stream: %d of %d map lines identical as text" % (same, len(ref["maps.out"].split("\n"))))
 
 
 if __name__ == "__main__":

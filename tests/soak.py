@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Soak: long randomized SlamUpdate sequences, device against the oracle at every step (GPU box only).
-    python scripts/soak.py [sequences] [steps] [first sequence number]
+    python tests/soak.py [sequences] [steps] [first sequence number]
 Every sequence draws its own sizes, pose motion, measurement noise and resampling numbers; the maps evolve (births,
 merges, cuts), so the device meets states no fixed fixture has. Stops at the first disagreement."""
 import os

@@ -1,4 +1,4 @@
-"""A short run of scripts/soak.py: randomized SlamUpdate sequences whose maps evolve over many steps (births, merges,
+"""A short run of tests/soak.py: randomized SlamUpdate sequences whose maps evolve over many steps (births, merges,
 MaxQuantity cuts, resampling), device against the oracle at every step."""
 import os
 import sys
@@ -7,7 +7,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_randomized_sequences_follow_the_oracle():

@@ -61,8 +61,25 @@ def test_replay_of_a_record_matches_the_oracle(tmp_path):
     import replay
     path = replay.make_synthetic_record(str(tmp_path / "rec.zip"), frames=10)
     rec = rio.read_record(path)
+    import orc
+
+    class OracleSolver:
+        """the CPU oracle behind the interface scripts/replay.py drives its solver through"""
+
+        def __init__(self, p, pose, particles):
+            self.p = p
+            self.st = orc.State(particles, 900)
+            self.st.poses[:] = pose
+            self.best = 0
+
+        def step(self, reading, noise, z, u):
+            self.st.poses[:] = orc.update_motion(self.st.poses, reading, noise)
+            if len(z):
+                self.best, _, _, _ = orc.slam_update(self.p, self.st, z, u=u, threads=8)
+            return self.st.poses[self.best].copy(), tuple(np.array(x) for x in self.st.map(self.best))   # copies: the slab moves on
+
     dev = replay.replay(rec, 24, 5, replay.DeviceSolver)
-    ref = replay.replay(rec, 24, 5, replay.OracleSolver)
+    ref = replay.replay(rec, 24, 5, OracleSolver)
     dmaps, rmaps = rio.map_history_from_descriptor(dev["maps.out"]), rio.map_history_from_descriptor(ref["maps.out"])
     assert len(dmaps) == len(rmaps) == 10
     for (td, md), (tr, mr) in zip(dmaps, rmaps):
