@@ -8,8 +8,8 @@ from .abi import PhdParams
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libphdhip.so")
-SOURCES = ["phdhip.hip", "phd_kernels.h", "phd_correct.h", "phd_sweep.h", "phd_prune.h", "phd_alpha.h", "phd_resample.h", "phd_device.h"]
+SO_PATH = os.environ.get("PHDHIP_SO") or os.path.join(CSRC, "libphdhip.so")   # (PHDHIP_SO: another build of the same library, for A/B timing)
+SOURCES = ["phdhip.hip", "phd_multi.inc", "phd_kernels.h", "phd_correct.h", "phd_sweep.h", "phd_prune.h", "phd_alpha.h", "phd_resample.h", "phd_device.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
 
 dp = C.POINTER(C.c_double)
@@ -17,8 +17,13 @@ ip = C.POINTER(C.c_int32)
 u8p = C.POINTER(C.c_uint8)
 
 
-def build(force=False):
-    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+def build(force=False, out=None, defines=()):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU). `out` / `defines`: a variant build
+    (tuning macros of the kernels) next to the product one, selected at run time with PHDHIP_SO."""
+    if out:
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        subprocess.check_call([hipcc] + HIPCC_FLAGS + ["-D" + d for d in defines] + ["-o", out, os.path.join(CSRC, "phdhip.hip")], cwd=CSRC)
+        return out
     srcs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(os.path.dirname(HERE), "include", "phdhip.h")]
     if not force and os.path.exists(SO_PATH) and all(os.path.getmtime(SO_PATH) >= os.path.getmtime(s) for s in srcs):
         return SO_PATH

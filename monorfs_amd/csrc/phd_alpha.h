@@ -1461,8 +1461,11 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 	}
 }
 
+#ifndef PHD_ASSOC_WAVES
+#define PHD_ASSOC_WAVES 4
+#endif
 template <int ZB>
-__global__ __launch_bounds__(256, 4) void k_alpha_assoc(const DevParams prm, const StepBufs a, int ncap)
+__global__ __launch_bounds__(256, PHD_ASSOC_WAVES) void k_alpha_assoc(const DevParams prm, const StepBufs a, int ncap)
 {
 	extern __shared__ __align__(16) double smem[];
 	alpha_assoc_body<ZB, false>(prm, a, ncap, smem);

@@ -142,7 +142,10 @@ __device__ __forceinline__ void emit_finish_body(const DevParams& prm, const Ste
 	}
 }
 
-__global__ __launch_bounds__(256) void k_emit_finish(const DevParams prm, const StepBufs a)
+#ifndef PHD_EF_WAVES
+#define PHD_EF_WAVES 3   // waves per SIMD the register allocation of k_emit_finish aims at (tuning: scripts/ab_variants.sh)
+#endif
+__global__ __launch_bounds__(256, PHD_EF_WAVES) void k_emit_finish(const DevParams prm, const StepBufs a)
 {
 	emit_finish_body(prm, a);
 }

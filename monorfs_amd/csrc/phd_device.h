@@ -433,6 +433,14 @@ __device__ __forceinline__ unsigned long long lanemask_lt()
 	return (1ull << lane_id()) - 1ull;
 }
 
+// A value that is the same in every lane (a particle's pose, its rotation matrix), moved to scalar registers: it then
+// costs no vector registers for the rest of the kernel.
+__device__ __forceinline__ double uniform_d(double v)
+{
+	const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+	return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll

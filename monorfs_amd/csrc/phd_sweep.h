@@ -38,12 +38,16 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 	const int n = vin.count[p];
 	const size_t sb = in_base(a, p);   // the particle's prior mixture in the INMIX bank
 	const Bank bout = bank_of(a, SEL_OUT);
-	const PoseD pose = load_pose(bin.poses + (size_t) p * 7);
+	PoseD pose = load_pose(bin.poses + (size_t) p * 7);
+	pose.t[0] = uniform_d(pose.t[0]); pose.t[1] = uniform_d(pose.t[1]); pose.t[2] = uniform_d(pose.t[2]);
+	pose.qw = uniform_d(pose.qw); pose.qx = uniform_d(pose.qx); pose.qy = uniform_d(pose.qy); pose.qz = uniform_d(pose.qz);
 	// the particle keeps its pose and (until the reweight kernel runs) its weight in the output bank
 	if (tid < 7) bout.poses[(size_t) p * 7 + tid] = bin.poses[(size_t) p * 7 + tid];
 	if (tid == 7) bout.weights[p] = bin.weights[p];
 	double rq[9];
 	conj_matrix(pose, rq);
+#pragma unroll
+	for (int t = 0; t < 9; t++) rq[t] = uniform_d(rq[t]);
 	exp_tab_init(etab, tid);
 	if (tid == 0) { s_nb = 0; s_nmis = 0; s_nu = 0; }
 	for (int k = tid; k < MP; k += 256) {
@@ -60,12 +64,19 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 	bool   zv[ZB];
 #pragma unroll
 	for (int b = 0; b < ZB; b++) {
-		int k = b * 64 + lane;
-		zv[b] = k < M;
-		zx[b] = zs[k * 3]; zy[b] = zs[k * 3 + 1]; zr[b] = zs[k * 3 + 2];
-		wx[b] = zmap[k * 3]; wy[b] = zmap[k * 3 + 1]; wz[b] = zmap[k * 3 + 2];
+		zv[b] = b * 64 + lane < M;
 		wsum[b] = 0; dens[b] = 0;
 	}
+	// this lane's measurements, from LDS into registers: done anew behind every staging phase (which needs the registers
+	// for the 3 x 3 algebra of a component) rather than once, so that the values are not live across it
+	auto load_z = [&]() {
+#pragma unroll
+		for (int b = 0; b < ZB; b++) {
+			const int k = b * 64 + lane;
+			zx[b] = zs[k * 3]; zy[b] = zs[k * 3 + 1]; zr[b] = zs[k * 3 + 2];
+			wx[b] = zmap[k * 3]; wy[b] = zmap[k * 3 + 1]; wz[b] = zmap[k * 3 + 2];
+		}
+	};
 	const double g2c = prm.g2_correct, g2e = prm.g2_explore, thr = prm.expl_thr;
 	// (component << 8 | measurement, exponent as float32) of the pairs worth a second look. Every wave appends to a
 	// segment of its own (a quarter of the queue) and counts in a scalar register: no atomic, no LDS round trip in the loop.
@@ -160,6 +171,7 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 			}
 		}
 		__syncthreads();
+		load_z();
 		const int cend = min(SW_TILE, n - c0);
 		if (compact) {
 			const int nu = s_nu;
@@ -307,6 +319,7 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 		}
 	}
 	__syncthreads();
+	load_z();
 	// the births' share of the weight sums (they were born from this frame's measurements: :804, :886-890)
 	for (int bi = (wv - n) & 3; bi < nb; bi += 4) {   // component n + bi belongs to wave (n + bi) mod 4, as the prior ones do
 		const double* tt = tile + bi * 13;
@@ -330,8 +343,11 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 	}
 }
 
+#ifndef PHD_SWEEP_WAVES
+#define PHD_SWEEP_WAVES 4
+#endif
 template <int ZB>
-__global__ __launch_bounds__(256, 4) void k_sweep(const DevParams prm, const StepBufs a)
+__global__ __launch_bounds__(256, PHD_SWEEP_WAVES) void k_sweep(const DevParams prm, const StepBufs a)
 {
 	sweep_body<ZB>(prm, a);
 }
