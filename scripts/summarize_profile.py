@@ -73,14 +73,14 @@ def main():
     json.dump(out, open(os.path.join(root, "profiles", name + ".json"), "w"), indent=1)
     # per-launch HBM bytes of every kernel, read by bench.py for `roofline.traffic`
     if len(sys.argv) > 3:
-        tfile = os.path.join(root, "profiles", "r01_hbm_traffic.json")
+        tfile = os.path.join(root, "profiles", name.split("_")[0] + "_hbm_traffic.json")   # r02_...: from a one-stream profile, per whole-range launch
         traffic = json.load(open(tfile)) if os.path.exists(tfile) else {}
         traffic[sys.argv[3]] = {k: (v["hbm_read_bytes"] or 0) + (v["hbm_write_bytes"] or 0) for k, v in out["kernels"].items()
                                 if v["hbm_read_bytes"] is not None}
         traffic["_note"] = "HBM bytes per launch = 2 x FETCH_SIZE x 1024 + WRITE_SIZE x 1024 (rocprofv3 --pmc, separate passes; gfx950 FETCH_SIZE correction)"
         json.dump(traffic, open(tfile, "w"), indent=1)
         # vector-ALU instructions per launch (SQ_INSTS_VALU summed over the waves), read by bench.py for the issue-rate view
-        vfile = os.path.join(root, "profiles", "r01_valu_insts.json")
+        vfile = os.path.join(root, "profiles", name.split("_")[0] + "_valu_insts.json")
         valu = json.load(open(vfile)) if os.path.exists(vfile) else {}
         valu[sys.argv[3]] = {}
         for k, v in out["kernels"].items():
