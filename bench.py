@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--events-every", type=int, default=8, help="time the launches of every n-th step of the timed region (each event costs the device a few microseconds)")
     ap.add_argument("--force-dist", action="store_true", help="take the sharded (RCCL) step path even with one rank (rehearsal)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs of the N = 1 run (isolated kernel times, other modes)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N GPUs behind ONE handle in this process (phd_create_multi: peer copies instead of RCCL, the path a C# host drives); "
+                         "2048 particles per device as in the sharded run")
+    ap.add_argument("--devices", default="", help="with --single-process: the HIP ordinals, comma separated (default 0..N-1; a device may repeat: rehearsal on one GPU)")
     return ap.parse_args()
 
 
@@ -139,6 +143,8 @@ def main():
     args = parse()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.single_process:
+        return single_process(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return launch_ranks(args)   # plain `python bench.py --gpus N`: this process only starts the ranks
     rank = int(os.environ.get("RANK", "0"))
@@ -391,6 +397,50 @@ def main():
     nav.close()
     if use_dist:
         dist.destroy_process_group()
+    return 0
+
+
+def single_process(args):
+    """`--single-process`: the same weak-scaling workload through one multi-device handle (phd_create_multi)."""
+    import torch
+    devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    if len(devices) != args.gpus:
+        raise SystemExit("--devices must name --gpus devices")
+    if max(devices) >= torch.cuda.device_count():
+        raise SystemExit("bench.py --single-process: device %d asked for, %d visible" % (max(devices), torch.cuda.device_count()))
+    from monorfs_amd import navigator
+    from monorfs_amd.abi import prm3d_defaults
+    from monorfs_amd.synth import CONFIGS, Frame
+    P, Cc, M, seed = CONFIGS[args.config]
+    n = len(devices)
+    frames = [Frame(P, Cc, M, seed, weight_profile=args.weights, shard=r) for r in range(n)]
+    maxq = max(600, Cc)
+    params = prm3d_defaults(max_particles=P * n, max_components=maxq, max_measurements=M)
+    params.max_quantity = maxq
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    nav = navigator.PHDNavigator(params, particlecount=P * n, devices=devices)
+    nav.upload_state(np.concatenate([f.planes() for f in frames], axis=1), np.concatenate([f.counts for f in frames]),
+                     np.concatenate([f.poses for f in frames]), np.full(P * n, 1.0 / (P * n)))
+    nav.set_measurements(frames[0].z)
+    nav.set_frozen(True)
+    for _ in range(args.warmup):
+        nav.step_async(0.5)
+    nav.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nav.step_async(0.5)
+    nav.sync()
+    elapsed = time.perf_counter() - t0
+    out = {"metric": "PHD updates/sec (particles x components x measurements)", "value": P * n * Cc * M * args.steps / elapsed,
+           "unit": "PHD updates/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "RB-PHD-SLAM SlamUpdate, BASELINE config %s: %d particles/GPU x %d components x %d measurements, one "
+                                  "multi-device handle (phd_create_multi, peer copies), devices %s" % (args.config, P, Cc, M, devices),
+                      "particles_per_gpu": P, "components": Cc, "measurements": M, "max_quantity": maxq,
+                      "parallelism": "particles sharded x%d in one process" % n}}
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+    nav.close()
     return 0
 
 

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PHD_API_VERSION 1
+#define PHD_API_VERSION 2   /* 2: phd_create_multi, phd_set_association_workspace; phd_migration_local_async gone */
 
 /* status codes */
 #define PHD_OK                    0
@@ -128,7 +128,11 @@ int phd_reset(phd_navigator* nav, int nparticles, const double* pose7,
               const double* w, const double* mean3, const double* cov9, int ncomp);
 
 /* The host keeps the motion model and its RNG (TrackVehicle.UpdateNoisy, TrackVehicle.cs:89-102):
- * after Navigator.Update (PHDNavigator.cs:295-314) it hands the particle poses over.             */
+ * after Navigator.Update (PHDNavigator.cs:295-314) it hands the particle poses over.
+ * Like phd_set_weights, phd_update_motion and phd_set_measurements this does NOT wait for the device: the caller's array is
+ * copied into pinned staging (free again when the call returns), the copy to the device and the store into the current
+ * state are enqueued on the handle's stream — correct right behind phd_step_async, because the bank holding the current
+ * state is looked up on the device.                                                              */
 int phd_set_poses(phd_navigator* nav, const double* poses7, int nparticles);
 /* SURVEY row f1 (next to the path): the particle motion step itself on the device. TrackVehicle.UpdateNoisy
  * (TrackVehicle.cs:89-102) = Pose3D.AddOdometry (Pose3D.cs:314-333) of the reading (dx dy dz dpitch dyaw droll),
@@ -151,8 +155,11 @@ int phd_set_map(phd_navigator* nav, int particle, const double* w, const double*
 int phd_slam_update(phd_navigator* nav, const double* z3, int nmeasurements,
                     uint8_t onlymapping, double u_resample);
 
-/* The same step split so that measurements can be resident before a timed region:
- * upload, enqueue (asynchronous on the handle's stream), wait + collect status.                  */
+/* The same step split so that measurements can be resident before a timed region, or so that a 30 Hz host never
+ * waits inside a frame: upload (asynchronous), enqueue (asynchronous on the handle's stream), wait + collect status.
+ * Steps may be queued back to back; a failed one is dropped as a whole together with those queued behind it, and
+ * phd_sync reports it. Up to 320 particles (environment PHD_CHAIN_MAX) the per-particle part of a step is one kernel
+ * launch.                                                                                        */
 int phd_set_measurements(phd_navigator* nav, const double* z3, int nmeasurements);
 int phd_step_async(phd_navigator* nav, uint8_t onlymapping, double u_resample);
 int phd_sync(phd_navigator* nav);

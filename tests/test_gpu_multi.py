@@ -127,3 +127,27 @@ def test_multi_handle_rejects_unequal_shards(nav_mod):
     p = prm3d_defaults(max_particles=10, max_components=600, max_measurements=8)
     with pytest.raises(nav_mod.PHDError):
         nav_mod.PHDNavigator(p, particlecount=10, devices=[0, 0, 0])
+
+
+def test_multi_handle_failed_step_keeps_the_state(nav_mod):
+    """emit capacity overflow on a multi-device handle: PHD_ERR_CAPACITY, nothing rotated on any shard"""
+    small = Frame(8, 40, 6, 52, weight_profile="steady")
+    p = prm3d_defaults(max_particles=small.P, max_components=600, max_measurements=32)
+    p.emit_capacity = 64
+    p.max_quantity = 64
+    nav = nav_mod.PHDNavigator(p, particlecount=small.P, devices=[0, 0])
+    nav.upload_state(small.planes(), small.counts, small.poses, small.weights)
+    nav.SlamUpdate(None, small.z, u_resample=0.3)
+    before = (nav.VehicleWeights, nav.poses(), [nav.MapModel(i) for i in range(small.P)])
+    rng = np.random.default_rng(1)
+    many = np.column_stack([rng.uniform(-300, 300, 32), rng.uniform(-220, 220, 32), rng.uniform(0.3, 1.8, 32)])
+    with pytest.raises(nav_mod.PHDError) as e:
+        nav.SlamUpdate(None, many)
+    assert e.value.status == 2
+    after = (nav.VehicleWeights, nav.poses(), [nav.MapModel(i) for i in range(small.P)])
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    for x, y in zip(before[2], after[2]):
+        assert all(np.array_equal(a, b) for a, b in zip(x, y))
+    nav.SlamUpdate(None, small.z[:3], u_resample=0.4)
+    assert np.isclose(nav.VehicleWeights.sum(), 1.0)
+    nav.close()
