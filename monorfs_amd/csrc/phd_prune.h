@@ -161,6 +161,7 @@ __device__ __forceinline__ void prune_sort_regs(unsigned long long* sv, int tid)
 __device__ __forceinline__ void prune_sort(unsigned long long* sv, int n, int tid)
 {
 	switch (n) {
+	case 256:  prune_sort_regs<1>(sv, tid); break;
 	case 512:  prune_sort_regs<2>(sv, tid); break;
 	case 1024: prune_sort_regs<4>(sv, tid); break;
 	case 2048: prune_sort_regs<8>(sv, tid); break;
@@ -198,7 +199,7 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 	PHD_STAMP(0);
 	// ---- A. order by (weight desc, canonical index asc)
 	{
-		int n = 2;
+		int n = 256;                                      // (at least the width of the register sort: small maps, too, skip the barrier-per-stage version)
 		while (n < ne && n < NS) n <<= 1;                 // width of the first pass
 		int taken = 0;                                    // emitted entries consumed so far
 		bool first = true;

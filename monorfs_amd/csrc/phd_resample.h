@@ -76,13 +76,13 @@ __device__ __forceinline__ double shfl_up_d(double v, int o) { return __shfl_up(
 // block-wide sums of a double, fixed order: thread partials -> wave butterflies -> wave 0 adds the 16 totals
 __device__ __forceinline__ double block_sum_1024(double v, double* scratch16, int tid)
 {
-	const int lane = tid & 63, wv = tid >> 6;
+	const int lane = tid & 63, wv = tid >> 6, nw = (int) (blockDim.x >> 6);
 	v = wave_sum(v);
 	__syncthreads();
 	if (lane == 0) scratch16[wv] = v;
 	__syncthreads();
 	double t = 0;
-	for (int q = 0; q < 16; q++) t += scratch16[q];
+	for (int q = 0; q < nw; q++) t += scratch16[q];
 	return t;
 }
 
@@ -107,8 +107,9 @@ __device__ __forceinline__ void rotate_roles(const StepBufs& a, const int* src, 
 	const Bank bo = bank_of(a, SEL_OUT), bt = bank_of(a, SEL_TMP);
 	// two particles per thread and trip, their loads issued together: this tail is two dependent round trips to memory
 	// per trip in a single workgroup, nothing else
-	for (int i0 = tid; i0 < a.P; i0 += 2048) {
-		const int i1 = i0 + 1024;
+	const int nt_ = (int) blockDim.x;
+	for (int i0 = tid; i0 < a.P; i0 += 2 * nt_) {
+		const int i1 = i0 + nt_;
 		const bool v1 = i1 < a.P;
 		const int s0 = resampled ? src[i0] : i0, s1 = (resampled && v1) ? src[i1] : i1;
 		if (resampled) {
@@ -140,7 +141,8 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 	__shared__ double s16[16], s16b[16];
 	__shared__ int    s_i16[16];
 	__shared__ int    s_res, s_ok, s_best;
-	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	// (launched with 1024 threads, or 256 for short weight vectors: the shape of the sums depends on the vector length only)
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = (int) blockDim.x, nw = nt >> 6;
 	if (tid == 0 && a.bigws_used && *a.bigws_used) *a.bigws_used = 0;   // the association slab is free again (every k_alpha_assoc of the step is over)
 	// A kernel of this step raised a flag (emit capacity, landmark scratch): what it wrote into the OUT bank is not a
 	// valid state. The step is dropped as a whole — the roles stay, nothing of the current state was touched — and the host
@@ -152,10 +154,10 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 	double* gwp = gw ? gw : bank_of(a, SEL_OUT).weights;
 	double* w = use_lds ? lw : gwp;
 	if (use_lds) {
-		for (int i = tid; i < P; i += 1024) lw[i] = gwp[i];
+		for (int i = tid; i < P; i += nt) lw[i] = gwp[i];
 	}
 	__syncthreads();
-	const int CH = (P + 1023) / 1024;              // contiguous chunk of every thread
+	const int CH = (P + nt - 1) / nt;              // contiguous chunk of every thread
 	const int c0 = min(P, tid * CH), c1 = min(P, c0 + CH);
 
 	// ---- normalise (:343-345)
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 	}
 	double gmax = -INFINITY;
 	int    gbest = 0;
-	for (int q = 0; q < 16; q++) {
+	for (int q = 0; q < nw; q++) {
 		if (s16b[q] > gmax) { gmax = s16b[q]; gbest = s_i16[q]; }
 	}
 	if (!(gmax > 0)) gbest = 0;   // maxweight starts at 0 and the comparison is strict (:347-353)
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 	bool   ok = !bad;
 	double mybestw = -INFINITY;
 	int    mybesti = 0x7fffffff;
-	for (int i = tid; i < P; i += 1024) {
+	for (int i = tid; i < P; i += nt) {
 		// T_i = R0 + i * invP, exactly, as a double-double
 		double ph = (double) i * invP, pl = fma((double) i, invP, -ph);
 		dd T = dd_add_d(dd{ph, pl}, R0);
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 		if (lane == 0) s16[wv] = m;
 		__syncthreads();
 		double gm = -INFINITY;
-		for (int q = 0; q < 16; q++) gm = fmax(gm, s16[q]);
+		for (int q = 0; q < nw; q++) gm = fmax(gm, s16[q]);
 		if (gm > 0 && mybestw == gm) atomicMin(&s_best, mybesti);
 		__syncthreads();
 		if (tid == 0) { info[0] = (gm > 0) ? s_best : 0; info[1] = 1; }

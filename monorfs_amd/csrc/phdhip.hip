@@ -88,6 +88,7 @@ struct phd_navigator {
 	int nsend = 0, nrecv = 0, last_world_particles = 1;
 	bool local_gather_done = false;                  // k_gather_local ran for the step being migrated
 	int* h_pin = nullptr; int h_pin_cap = 0;         // pinned: [2] resampling info + the global source vector
+	int  plan_pending = 0;                           // world size of a plan whose device-to-host copies are already enqueued (plan_begin)
 
 	// host mirrors handed out by the getters
 	std::vector<double> h_weights, h_poses, h_mw, h_mm, h_mc, h_alpha, h_setll, h_tmp;
@@ -356,7 +357,10 @@ int launch_normalise(phd_navigator* nav, const StepBufs& b, double* gw, int P, d
 	size_t lds = (size_t) P * 8;
 	int use_lds = lds + (size_t) nav->nr_static_lds + 256 <= 160 * 1024;
 	if (!use_lds) lds = 0;
-	hipLaunchKernelGGL(k_normalise_resample, dim3(1), dim3(1024), lds, nav->stream, b, gw, P, nav->dp.min_eff, u, force, skipnorm,
+	// one workgroup; 256 threads for a short weight vector (fewer waves to meet at every barrier), 1024 beyond
+	static const int nr_env = getenv("PHD_NR_THREADS") ? atoi(getenv("PHD_NR_THREADS")) : 0;
+	const int nthreads = (nr_env == 256 || nr_env == 512 || nr_env == 1024) ? nr_env : (P <= 512 ? 256 : 1024);
+	hipLaunchKernelGGL(k_normalise_resample, dim3(1), dim3(nthreads), lds, nav->stream, b, gw, P, nav->dp.min_eff, u, force, skipnorm,
 	                   use_lds, src, info, sel_next, nav->frozen ? 1 : 0, nav->d_inslot);
 	HC(hipGetLastError());
 	return PHD_OK;
@@ -1476,16 +1480,13 @@ int phd_plan_migration(const int32_t* gsrc, int Pl, int world_size, int rank, in
 	return slot;
 }
 
-int phd_migration_plan(phd_navigator* nav, int rank, int world_size, int32_t* send_counts, int32_t* recv_counts)
+// First half of phd_migration_plan: enqueue the copies of the resampling flag, the global source vector and the status
+// flags into pinned memory. A host that drives several devices (phd_create_multi) starts them on every device before it
+// waits for the first.
+static int plan_begin(phd_navigator* nav, int world_size)
 {
-	if (!nav) return PHD_ERR_BAD_ARGUMENT;
-	MULTI_UNSUPPORTED(nav, "phd_migration_plan");
-	if (world_size < 1 || rank < 0 || rank >= world_size || !send_counts || !recv_counts) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_plan: bad arguments");
 	hipSetDevice(nav->device);
-	int rc = PHD_OK;
-	if (!nav->sel_host_valid) rc = sync_state(nav);
-	if (rc) return rc;
-	const int Pl = nav->P, Pg = Pl * world_size, first = rank * Pl;
+	const int Pg = nav->P * world_size;
 	if (nav->h_pin_cap < Pg + 3) {
 		if (nav->h_pin) hipHostFree(nav->h_pin);
 		nav->h_pin = nullptr;
@@ -1496,6 +1497,23 @@ int phd_migration_plan(phd_navigator* nav, int rank, int world_size, int32_t* se
 	HC(hipMemcpyAsync(nav->h_pin, nav->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, nav->stream));
 	HC(hipMemcpyAsync(nav->h_pin + 2, nav->d_plan, (size_t) Pg * 4, hipMemcpyDeviceToHost, nav->stream));
 	HC(hipMemcpyAsync(nav->h_pin + 2 + Pg, nav->d_flags, sizeof(int), hipMemcpyDeviceToHost, nav->stream));
+	nav->plan_pending = world_size;
+	return PHD_OK;
+}
+
+int phd_migration_plan(phd_navigator* nav, int rank, int world_size, int32_t* send_counts, int32_t* recv_counts)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	MULTI_UNSUPPORTED(nav, "phd_migration_plan");
+	if (world_size < 1 || rank < 0 || rank >= world_size || !send_counts || !recv_counts) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_plan: bad arguments");
+	hipSetDevice(nav->device);
+	int rc = PHD_OK;
+	if (!nav->sel_host_valid) rc = sync_state(nav);
+	if (rc) return rc;
+	const int Pl = nav->P, Pg = Pl * world_size, first = rank * Pl;
+	if (nav->plan_pending != world_size) rc = plan_begin(nav, world_size);
+	nav->plan_pending = 0;
+	if (rc) return rc;
 	HC(hipStreamSynchronize(nav->stream));
 	if (nav->h_pin[2 + Pg]) {
 		// a kernel of the local step raised a flag: the step is dropped before anything rotates (the caller must not go on to
