@@ -790,7 +790,7 @@ PHD_REF_ARITH
 	PHD_STAMP_FLUSH(2, 11);
 }
 
-__global__ __launch_bounds__(256) void k_prune_merge(const DevParams prm, const StepBufs a, int cutcap)
+__global__ __launch_bounds__(256, 4) void k_prune_merge(const DevParams prm, const StepBufs a, int cutcap)
 {
 	extern __shared__ __align__(16) double smem[];
 	prune_merge_body(prm, a, cutcap, smem);

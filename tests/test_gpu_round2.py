@@ -360,3 +360,22 @@ def test_one_launch_chain_equals_the_separate_kernels(nav_mod, monkeypatch):
         assert np.array_equal(wa, wb) and np.array_equal(sa[0], sb[0]) and sa[1] == sb[1] and ba == bb
         for x, y in zip(ma, mb):
             assert all(np.array_equal(u, v) for u, v in zip(x, y))
+
+
+def test_a_cluster_beyond_256_rows_is_an_error_that_keeps_the_state(nav_mod):
+    """MurtyPairing has no size limit in the reference; the device solves clusters of up to 256 rows. One clump of ~25
+    landmarks and 250 measurements is beyond that: PHD_ERR_ASSOCIATION, the particle set stays as it was."""
+    from test_gpu_parity import clustered_frame
+    f = clustered_frame(70, 1, 60, 250, spread_px=3.0)
+    nav, p = make_nav(nav_mod, f, merge_threshold=1e-3, emit_capacity=24000)
+    before = (nav.VehicleWeights, [nav.MapModel(i) for i in range(f.P)])
+    with pytest.raises(nav_mod.PHDError) as e:
+        nav.SlamUpdate(None, f.z)
+    assert e.value.status == 3 and e.value.module == "association"
+    after = (nav.VehicleWeights, [nav.MapModel(i) for i in range(f.P)])
+    assert np.array_equal(before[0], after[0])
+    for x, y in zip(before[1], after[1]):
+        assert all(np.array_equal(a, b) for a, b in zip(x, y))
+    nav.SlamUpdate(None, f.z[:40])          # a frame the solver takes runs from the kept state
+    assert np.isclose(nav.VehicleWeights.sum(), 1.0)
+    nav.close()

@@ -53,13 +53,15 @@ def test_measurement_errors_carry_the_reference_messages(text, dim, msg):
 
 
 @pytest.mark.gpu
-def test_replay_of_a_record_matches_the_oracle(tmp_path):
+@pytest.mark.parametrize("frames,landmarks,particles", [(10, 14, 24), (12, 50, 20)], ids=["14-landmarks", "reference-config-20-particles-50-landmarks"])
+def test_replay_of_a_record_matches_the_oracle(tmp_path, frames, landmarks, particles):
     """the same measurements.out / odometry.out stream through the HIP solver and through the oracle: the maps.out /
-    estimate.out they write agree number by number (and almost always character by character at g6)"""
+    estimate.out they write agree number by number (and almost always character by character at g6). The second case is
+    BASELINE.json's "C# reference" configuration: 20 particles, ~50 landmarks, noisy odometry, SLAM mode, headless."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     import replay
-    path = replay.make_synthetic_record(str(tmp_path / "rec.zip"), frames=10)
+    path = replay.make_synthetic_record(str(tmp_path / "rec.zip"), frames=frames, landmarks=landmarks)
     rec = rio.read_record(path)
     import orc
 
@@ -78,10 +80,12 @@ def test_replay_of_a_record_matches_the_oracle(tmp_path):
                 self.best, _, _, _ = orc.slam_update(self.p, self.st, z, u=u, threads=8)
             return self.st.poses[self.best].copy(), tuple(np.array(x) for x in self.st.map(self.best))   # copies: the slab moves on
 
-    dev = replay.replay(rec, 24, 5, replay.DeviceSolver)
-    ref = replay.replay(rec, 24, 5, OracleSolver)
+    dev = replay.replay(rec, particles, 5, replay.DeviceSolver)
+    ref = replay.replay(rec, particles, 5, OracleSolver)
     dmaps, rmaps = rio.map_history_from_descriptor(dev["maps.out"]), rio.map_history_from_descriptor(ref["maps.out"])
-    assert len(dmaps) == len(rmaps) == 10
+    assert len(dmaps) == len(rmaps) == frames
+    if landmarks >= 50:
+        assert len(dmaps[-1][1][0]) >= 30, "the 50-landmark scene should leave a map of several dozen components"
     for (td, md), (tr, mr) in zip(dmaps, rmaps):
         assert td == tr and len(md[0]) == len(mr[0])
         for a, b in zip(md, mr):
