@@ -229,7 +229,8 @@ int   phd_migration_plan(phd_navigator* nav, int rank, int world_size,
 /* The plan itself, as a pure host function (needs no handle and no GPU): `gsrc[world * Pl]` is the
  * global source vector; send_list (<= Pl * (world - 1) entries) = local indices to pack, grouped by
  * destination rank; dst_code[Pl] = local source index, or -(k + 1) for record k of the receive
- * buffer. Returns the number of received records.                                                */
+ * buffer. Returns the number of received records. A source particle is sent to a rank once for every run of that rank's
+ * consecutive slots that take it (its copies share the record, as the copies of a local particle share its map).  */
 int   phd_plan_migration(const int32_t* gsrc, int particles_per_rank, int world_size, int rank,
                          int32_t* send_counts, int32_t* recv_counts, int32_t* send_list, int32_t* dst_code);
 void* phd_migration_send_buffer(phd_navigator* nav, int64_t* bytes_per_particle);

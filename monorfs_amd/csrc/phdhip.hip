@@ -1448,16 +1448,25 @@ int phd_step_global_async(phd_navigator* nav, int rank, int world_size, double u
 int phd_plan_migration(const int32_t* gsrc, int Pl, int world_size, int rank, int32_t* send_counts, int32_t* recv_counts,
                        int32_t* send_list, int32_t* dst_code)
 {
+	// A source particle travels to a rank ONCE, however many of that rank's slots take it: systematic resampling hands a
+	// heavy particle to a run of consecutive slots, and the copies of a particle share its map anyway (slot indirection).
+	// Sender and receiver both skip a slot whose source equals that of the slot before it (among the slots the two ranks
+	// have in common), so their lists agree; a depleted particle set, which is when resampling happens, migrates a small
+	// fraction of the records a copy per slot would.
 	const int first = rank * Pl;
 	for (int r = 0; r < world_size; r++) send_counts[r] = recv_counts[r] = 0;
 	int ns = 0;
 	for (int r = 0; r < world_size; r++) {
 		if (r == rank) continue;
+		int prev = -1;
 		for (int g = r * Pl; g < (r + 1) * Pl; g++) {
 			int s = gsrc[g];
 			if (s >= first && s < first + Pl) {
-				send_list[ns++] = s - first;
-				send_counts[r]++;
+				if (s != prev) {
+					send_list[ns++] = s - first;
+					send_counts[r]++;
+				}
+				prev = s;
 			}
 		}
 	}
@@ -1468,12 +1477,16 @@ int phd_plan_migration(const int32_t* gsrc, int Pl, int world_size, int rank, in
 	int slot = 0;
 	for (int r = 0; r < world_size; r++) {
 		if (r == rank) continue;
+		int prev = -1;
 		for (int i = 0; i < Pl; i++) {
 			int s = gsrc[first + i];
 			if (s >= r * Pl && s < (r + 1) * Pl) {
-				dst_code[i] = -(slot + 1);
-				slot++;
-				recv_counts[r]++;
+				if (s != prev) {
+					slot++;
+					recv_counts[r]++;
+				}
+				dst_code[i] = -slot;   // record slot - 1 of the receive buffer
+				prev = s;
 			}
 		}
 	}
