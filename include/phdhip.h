@@ -158,7 +158,7 @@ int phd_slam_update(phd_navigator* nav, const double* z3, int nmeasurements,
 /* The same step split so that measurements can be resident before a timed region, or so that a 30 Hz host never
  * waits inside a frame: upload (asynchronous), enqueue (asynchronous on the handle's stream), wait + collect status.
  * Steps may be queued back to back; a failed one is dropped as a whole together with those queued behind it, and
- * phd_sync reports it. Up to 320 particles (environment PHD_CHAIN_MAX) the per-particle part of a step is one kernel
+ * phd_sync reports it. Up to 512 particles (environment PHD_CHAIN_MAX) the per-particle part of a step is one kernel
  * launch.                                                                                        */
 int phd_set_measurements(phd_navigator* nav, const double* z3, int nmeasurements);
 int phd_step_async(phd_navigator* nav, uint8_t onlymapping, double u_resample);

@@ -1495,14 +1495,15 @@ __global__ __launch_bounds__(256, 4) void k_quasi_setll(const DevParams prm, con
 #define DENS_JL 128   // landmarks whose partial sums stay in LDS
 #define DENS_REC 12   // gauss_record + the weight ratio of the component's surviving misdetection copy (+ 1: records stay 16-byte aligned)
 
-__device__ __forceinline__ void alpha_density_body(const DevParams& prm, const StepBufs& a)
+#define DENS_LDS_DOUBLES (TILE * DENS_REC + 2 * (DENS_JL / 64) * 256 + EXPTAB_N + 2)
+__device__ __forceinline__ void alpha_density_body(const DevParams& prm, const StepBufs& a, double* pool)
 {
 	constexpr int JL = DENS_JL;
-	__shared__ double tile[TILE * DENS_REC];     // [TILE][12]
-	__shared__ double partpl[(JL / 64) * 256];   // [JB][4][64] partial densities of v_pred (HBM slab when J > JL)
-	__shared__ double partcl[(JL / 64) * 256];   // the same for v_corr
-	__shared__ double etab[EXPTAB_N];
-	__shared__ int s_wc[4];
+	double* const tile = pool;                                        // [TILE][12]
+	double* const partpl = tile + TILE * DENS_REC;                    // [JB][4][64] partial densities of v_pred (HBM slab when J > JL)
+	double* const partcl = partpl + (JL / 64) * 256;                  // the same for v_corr
+	double* const etab = partcl + (JL / 64) * 256;
+	int* const s_wc = (int*) (etab + EXPTAB_N);                       // [4]
 	double* red = tile;                          // reduction scratch once the sweeps are over
 
 	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1674,5 +1675,6 @@ __device__ __forceinline__ void alpha_density_body(const DevParams& prm, const S
 
 __global__ __launch_bounds__(256) void k_alpha_density(const DevParams prm, const StepBufs a)
 {
-	alpha_density_body(prm, a);
+	__shared__ __align__(16) double pool[DENS_LDS_DOUBLES];
+	alpha_density_body(prm, a, pool);
 }

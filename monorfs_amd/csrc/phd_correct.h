@@ -37,10 +37,14 @@ __device__ __forceinline__ void load_predicted(const DevParams& prm, const StepB
 }
 
 // =================================================================================================
-__device__ __forceinline__ void emit_finish_body(const DevParams& prm, const StepBufs& a)
+#define EMIT_LDS_DOUBLES (EXPTAB_N + 256 + (EMIT_LIST + 4) / 2)   // etab, ldenom[256] | ints: list[EMIT_LIST], npair, nlist
+__device__ __forceinline__ void emit_finish_body(const DevParams& prm, const StepBufs& a, double* pool)
 {
-	__shared__ double etab[EXPTAB_N];
-	__shared__ int    s_npair;
+	double* const etab = pool;
+	double* const ldenom = pool + EXPTAB_N;
+	int* const list = (int*) (pool + EXPTAB_N + 256);
+	int& s_npair = list[EMIT_LIST];
+	int& s_nlist = list[EMIT_LIST + 1];
 	const int p = a.p0 + blockIdx.x, tid = threadIdx.x;
 	const int M = a.M;
 	const MixView vin = bank_view(a, SEL_IN);
@@ -93,8 +97,6 @@ __device__ __forceinline__ void emit_finish_body(const DevParams& prm, const Ste
 		// Most queued pairs fail once the real denominator is known. Their exponent x = log(PD w q) travels with
 		// them as a float32: x - log(denom) < log(MinWeight) by more than the float32 rounding settles it; the
 		// others are compacted into a list so that the waves run the heavy path on full lanes.
-		__shared__ double ldenom[256];
-		__shared__ int    list[EMIT_LIST], s_nlist;
 		for (int k = tid; k < M; k += 256) ldenom[k] = log(denom[k]);
 		if (tid == 0) s_nlist = 0;
 		__syncthreads();
@@ -147,5 +149,6 @@ __device__ __forceinline__ void emit_finish_body(const DevParams& prm, const Ste
 #endif
 __global__ __launch_bounds__(256, PHD_EF_WAVES) void k_emit_finish(const DevParams prm, const StepBufs a)
 {
-	emit_finish_body(prm, a);
+	__shared__ __align__(16) double pool[EMIT_LDS_DOUBLES];
+	emit_finish_body(prm, a, pool);
 }

@@ -146,23 +146,38 @@ __device__ __forceinline__ size_t in_base(const StepBufs& a, int p) { return (si
 // The per-particle chain of a step as ONE launch, for small particle sets (the real-time regime of the reference: 20 - 800
 // particles at 30 Hz, plots/scripts/chap3/S4-particles.sh:14-15; BASELINE config A): a particle's predict / correct / prune /
 // reweight touch nothing of another particle, so its workgroup runs the five kernels' bodies back to back, with a
-// workgroup barrier where a launch boundary was. With at most one or two workgroups per CU the kernels were latency-bound
-// launches of 8 - 30 us each with a ramp and a tail; here there are no boundaries until the particle weights meet in
-// k_normalise_resample. One workgroup per CU (the bodies' LDS arrays add up to ~115 KB), registers to spare.
+// workgroup barrier where a launch boundary was, all of them in ONE LDS pool (the largest of their layouts,
+// chain_lds_bytes: ~38 KB). With at most two workgroups per CU the kernels were latency-bound launches of 8 - 30 us each
+// with a ramp and a tail; here there are no boundaries until the particle weights meet in k_normalise_resample, and
+// registers to spare (245). On a full machine (2048 particles) a 128-register build of it at four workgroups per CU
+// measured 0.785 ms per step against 0.71 for the separate kernels on two streams: not used there.
+template <int ZB>
+__host__ __device__ inline int chain_lds_bytes(int cutcap)
+{
+	int d = SweepLds<ZB>::doubles;
+	if (EMIT_LDS_DOUBLES > d) d = EMIT_LDS_DOUBLES;
+	if (DENS_LDS_DOUBLES > d) d = DENS_LDS_DOUBLES;
+	int b = d * 8;
+	const int pb = prune_lds(cutcap).bytes, ab = alpha_lds(ZB * 64, cutcap).bytes;
+	if (pb > b) b = pb;
+	if (ab > b) b = ab;
+	return b;
+}
+
 template <int ZB>
 __global__ __launch_bounds__(256, 1) void k_particle_chain(const DevParams prm, const StepBufs a, int cutcap, int with_alpha)
 {
 	extern __shared__ __align__(16) double smem[];
-	sweep_body<ZB>(prm, a);
+	sweep_body<ZB>(prm, a, smem);
 	__syncthreads();   // (workgroup scope: the global writes of the step before are visible to this workgroup's loads)
-	emit_finish_body(prm, a);
+	emit_finish_body(prm, a, smem);
 	__syncthreads();
 	prune_merge_body(prm, a, cutcap, smem);
 	if (with_alpha) {
 		__syncthreads();
 		alpha_assoc_body<ZB, false, false, 1>(prm, a, cutcap, smem);
 		__syncthreads();
-		alpha_density_body(prm, a);
+		alpha_density_body(prm, a, smem);
 	}
 }
 

@@ -17,19 +17,34 @@
 #define SW_UMAX   16    // measurements still unexplored when the density part leaves the pair loop (see the sweep)
 
 // =================================================================================================
+// LDS of the sweep (doubles): the bodies of a step's kernels take their arrays from a pool handed in by the kernel, so that
+// k_particle_chain can run them back to back in ONE pool (phd_kernels.h)
 template <int ZB>
-__device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs& a)
+struct SweepLds {
+	static constexpr int MP = ZB * 64;
+	static constexpr int TD = (SW_TILE * SW_REC > MP * 13) ? SW_TILE * SW_REC : MP * 13;
+	static constexpr int zs = 0, zmap = zs + 3 * MP, part = zmap + 3 * MP, part2 = part + 4 * MP, tile = part2 + 4 * MP,
+	                     etab = tile + TD, du = etab + EXPTAB_N, ints = du + SW_UMAX;   // ints: born[MP], ulist[SW_UMAX], nb, nmis, nu
+	static constexpr int doubles = ints + (MP + SW_UMAX + 4) / 2;
+};
+
+template <int ZB>
+__device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs& a, double* pool)
 {
-	constexpr int MP = ZB * 64;
-	constexpr int TD = (SW_TILE * SW_REC > MP * 13) ? SW_TILE * SW_REC : MP * 13;
-	__shared__ double zs[3 * MP], zmap[3 * MP];
-	__shared__ double part[4 * MP], part2[4 * MP];
-	__shared__ double tile[TD];                 // [SW_TILE][20] prior components | [births][13] in the tail
-	__shared__ double etab[EXPTAB_N];
-	__shared__ int    born[MP];
-	__shared__ int    s_nb, s_nmis, s_nu;
-	__shared__ int    s_ulist[SW_UMAX];
-	__shared__ double s_du[SW_UMAX];
+	using L = SweepLds<ZB>;
+	constexpr int MP = L::MP;
+	double* const zs = pool + L::zs;
+	double* const zmap = pool + L::zmap;
+	double* const part = pool + L::part;
+	double* const part2 = pool + L::part2;
+	double* const tile = pool + L::tile;                  // [SW_TILE][20] prior components | [births][13] in the tail
+	double* const etab = pool + L::etab;
+	double* const s_du = pool + L::du;
+	int* const born = (int*) (pool + L::ints);
+	int* const s_ulist = born + MP;
+	int& s_nb = born[MP + SW_UMAX];
+	int& s_nmis = born[MP + SW_UMAX + 1];
+	int& s_nu = born[MP + SW_UMAX + 2];
 
 	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int M = a.M;
@@ -349,5 +364,6 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 template <int ZB>
 __global__ __launch_bounds__(256, PHD_SWEEP_WAVES) void k_sweep(const DevParams prm, const StepBufs a)
 {
-	sweep_body<ZB>(prm, a);
+	__shared__ __align__(16) double pool[SweepLds<ZB>::doubles];
+	sweep_body<ZB>(prm, a, pool);
 }

@@ -36,7 +36,7 @@ struct phd_navigator {
 	hipStream_t own_stream = nullptr;  // created by phd_create; `stream` unless the host lent its own
 	static const int MAXSPLIT = 4;
 	int         nsplit = 0;            // sub-ranges a step's per-particle kernels are split into (0: chosen from the particle count)
-	int         chain_max = 320;       // up to this many particles a step's per-particle kernels run as one launch (k_particle_chain; env PHD_CHAIN_MAX)
+	int         chain_max = 512;       // up to this many particles a step's per-particle kernels run as one launch (k_particle_chain; env PHD_CHAIN_MAX)
 	bool        chain_ok[3] = {false, false, false};   // ... where the bodies' LDS arrays fit one workgroup (per measurement-block count 1, 2, 4)
 	hipStream_t aux[MAXSPLIT - 1] = {nullptr, nullptr, nullptr};   // streams of the sub-ranges after the first
 	hipEvent_t  ev_fork = nullptr, ev_join[MAXSPLIT - 1] = {nullptr, nullptr, nullptr};
@@ -280,10 +280,11 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha)
 	const int S = std::max(1, std::min(std::min(want, (int) phd_navigator::MAXSPLIT), P));
 	const size_t lp = (size_t) prune_lds(nav->cutcap).bytes;
 	const AlphaLds lay = alpha_lds(ZB * 64, nav->cutcap);   // (the dynamic LDS limits of the kernels were raised once, in phd_create)
-	if (P <= nav->chain_max && nav->chain_ok[ZB == 1 ? 0 : (ZB == 2 ? 1 : 2)]) {
-		// a small particle set: the whole per-particle chain as one launch
+	const int zi = ZB == 1 ? 0 : (ZB == 2 ? 1 : 2);
+	if (nav->chain_ok[zi] && P <= nav->chain_max) {
+		// a small particle set (up to two workgroups per CU): the whole per-particle chain as one launch
 		timer_begin(nav, T_CH);
-		hipLaunchKernelGGL(k_particle_chain<ZB>, dim3(P), dim3(256), std::max(lp, (size_t) lay.bytes), nav->stream, nav->dp, b0, nav->cutcap, with_alpha ? 1 : 0);
+		hipLaunchKernelGGL(k_particle_chain<ZB>, dim3(P), dim3(256), (size_t) chain_lds_bytes<ZB>(nav->cutcap), nav->stream, nav->dp, b0, nav->cutcap, with_alpha ? 1 : 0);
 		timer_end(nav, T_CH);
 		HC(hipGetLastError());
 		return PHD_OK;
@@ -663,9 +664,9 @@ phd_navigator* phd_create(const phd_params* params, int device)
 			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll_grad<4>, hipFuncAttributeMaxDynamicSharedMemorySize, la[2]) == hipSuccess;
 			lim_alpha[2] = la[2];
 		}
-		// the one-launch chain: the static LDS arrays of the five bodies plus the larger of the two dynamic layouts must fit a
-		// workgroup (160 KB); where they do not (many measurement blocks, a large MaxQuantity) the separate kernels run
-		const int lc[3] = {std::max(lp, la[0]), std::max(lp, la[1]), std::max(lp, la[2])};
+		// the one-launch chain: its bodies share one pool, the largest of their layouts, which must fit a workgroup (160 KB)
+		// with the kernel's few static words; where it does not (a large MaxQuantity) the separate kernels run
+		const int lc[3] = {chain_lds_bytes<1>(nav->cutcap), chain_lds_bytes<2>(nav->cutcap), chain_lds_bytes<4>(nav->cutcap)};
 		const void* chainfn[3] = {(const void*) k_particle_chain<1>, (const void*) k_particle_chain<2>, (const void*) k_particle_chain<4>};
 		for (int z = 0; z < 3 && ok; z++) {
 			hipFuncAttributes fc;

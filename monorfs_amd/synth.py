@@ -12,6 +12,8 @@ CONFIGS = {   # BASELINE.json configs: particles, components, measurements, seed
     "B": (2048, 512, 64, 1002),
     "C8": (16384, 512, 64, 1003),
     "S": (4096, 1024, 128, 1004),
+    # tuning shapes (where the one-launch chain stops paying: phdhip.hip chain_max), not BASELINE configs
+    "A512": (512, 128, 32, 1001), "A1024": (1024, 128, 32, 1001), "B512": (512, 512, 64, 1002), "B1024": (1024, 512, 64, 1002),
 }
 
 
