@@ -181,7 +181,6 @@ __device__ __forceinline__ double wave_min(double v)
 	return v;
 }
 
-__device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 
 // entry `idx` (wave-uniform) of an array spread as element lane + 64 t in x[t]
 template <int NT>

@@ -13,7 +13,6 @@
 #pragma once
 #include "phd_device.h"
 
-#define EMIT_LIST 1024 // pairs k_emit_finish gathers before it runs the Kalman path on them
 
 // component c of the predicted mixture = prior slab entry or a birth (mean from the explore kernel)
 __device__ __forceinline__ void load_predicted(const DevParams& prm, const StepBufs& a, const MixView& vin, int p, int n, int c,
@@ -37,14 +36,14 @@ __device__ __forceinline__ void load_predicted(const DevParams& prm, const StepB
 }
 
 // =================================================================================================
-#define EMIT_LDS_DOUBLES (EXPTAB_N + 256 + (EMIT_LIST + 4) / 2)   // etab, ldenom[256] | ints: list[EMIT_LIST], npair, nlist
+#define EMIT_LIST 512   // four per-wave lists of 128 pairs waiting for the Kalman path
+#define EMIT_LDS_DOUBLES (EXPTAB_N + 256 + (EMIT_LIST + 4) / 2)   // etab, ldenom[256] | ints: list[4][128], npair
 __device__ __forceinline__ void emit_finish_body(const DevParams& prm, const StepBufs& a, double* pool)
 {
 	double* const etab = pool;
 	double* const ldenom = pool + EXPTAB_N;
 	int* const list = (int*) (pool + EXPTAB_N + 256);
 	int& s_npair = list[EMIT_LIST];
-	int& s_nlist = list[EMIT_LIST + 1];
 	const int p = a.p0 + blockIdx.x, tid = threadIdx.x;
 	const int M = a.M;
 	const MixView vin = bank_view(a, SEL_IN);
@@ -96,33 +95,46 @@ __device__ __forceinline__ void emit_finish_body(const DevParams& prm, const Ste
 	if (!overflow) {
 		// Most queued pairs fail once the real denominator is known. Their exponent x = log(PD w q) travels with
 		// them as a float32: x - log(denom) < log(MinWeight) by more than the float32 rounding settles it; the
-		// others are compacted into a list so that the waves run the heavy path on full lanes.
+		// others are compacted into a list so that the heavy path runs on full lanes. Every wave takes the queue segment
+		// its counterpart in k_sweep wrote, with a list of its own: no workgroup barrier in the loop.
+		const int wv = tid >> 6, lane = tid & 63;
+		int* const wlist = list + wv * 128;   // up to 63 waiting + 64 new entries
 		for (int k = tid; k < M; k += 256) ldenom[k] = log(denom[k]);
-		if (tid == 0) s_nlist = 0;
 		__syncthreads();
 		const double lminw = log(prm.minw);
-		for (int j0 = 0; j0 < ncand; j0 += 256) {
-			const int j = j0 + tid;
+		const int ncw = (wv == 0) ? nc0 : ((wv == 1) ? nc1 : ((wv == 2) ? nc2 : nc3));
+		const int2* seg = cands + (size_t) wv * segcap;
+		int nl = 0;   // wave-uniform: entries waiting in the list
+		for (int j0 = 0; j0 < ncw; j0 += 64) {
+			const int j = j0 + lane;
 			bool keep = false;
 			int  code = 0;
-			if (j < ncand) {
-				// entry j of the four segments laid end to end
-				const int js = (j < nc0) ? j : ((j < nc0 + nc1) ? j - nc0 + segcap : ((j < nc0 + nc1 + nc2) ? j - nc0 - nc1 + 2 * segcap : j - nc0 - nc1 - nc2 + 3 * segcap));
-				const int2 cd = cands[js];
+			if (j < ncw) {
+				const int2 cd = seg[j];
 				code = cd.x;
 				const double x = (double) __int_as_float(cd.y);
 				keep = !(x - ldenom[code & 255] < lminw - 1e-3 - 1e-6 * fabs(x));
 			}
-			// (at most 256 new entries per trip: the list is drained whenever fewer than that are free)
-			if (keep) list[atomicAdd(&s_nlist, 1)] = code;
-			__syncthreads();
-			if (s_nlist > EMIT_LIST - 256 || j0 + 256 >= ncand) {
-				const int nl = s_nlist;
-				for (int i = tid; i < nl; i += 256) pair(list[i] >> 8, list[i] & 255);
-				__syncthreads();
-				if (tid == 0) s_nlist = 0;
-				__syncthreads();
+			const unsigned long long bal = ballot64(keep);
+			if (keep) wlist[nl + __popcll(bal & lanemask_lt())] = code;
+			nl += __popcll(bal);
+			if (nl >= 64) {
+				lds_fence();
+				__builtin_amdgcn_wave_barrier();
+				const int cd = wlist[lane];
+				const int rest = (lane < nl - 64) ? wlist[64 + lane] : 0;
+				pair(cd >> 8, cd & 255);
+				lds_fence();
+				__builtin_amdgcn_wave_barrier();
+				if (lane < nl - 64) wlist[lane] = rest;
+				nl -= 64;
 			}
+		}
+		lds_fence();
+		__builtin_amdgcn_wave_barrier();
+		if (lane < nl) {
+			const int cd = wlist[lane];
+			pair(cd >> 8, cd & 255);
 		}
 	}
 	else {

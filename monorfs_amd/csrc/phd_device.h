@@ -428,6 +428,9 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // instructions per call in the pair loops; this one is the compare's own result.)
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
+// orders a wave's LDS writes before the reads of its other lanes (with __builtin_amdgcn_wave_barrier)
+__device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
+
 __device__ __forceinline__ unsigned long long lanemask_lt()
 {
 	return (1ull << lane_id()) - 1ull;
