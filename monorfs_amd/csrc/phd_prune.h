@@ -74,11 +74,12 @@ __device__ __forceinline__ unsigned long long prune_pack(double w, int slot)
 __device__ __forceinline__ int prune_slot(unsigned long long v) { return (int) ((unsigned int) v & PRUNE_SLOT_MASK); }
 __device__ __forceinline__ unsigned long long prune_kbits(unsigned long long v) { return v >> PRUNE_SLOT_BITS; }
 
-__device__ __forceinline__ void prune_ce(unsigned long long* v, int t, int j, int k)
+template <class W>
+__device__ __forceinline__ void prune_ce(W* v, int t, int j, int k)
 {
 	int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
 	int q = i | j;
-	unsigned long long a = v[i], b = v[q];
+	W a = v[i], b = v[q];
 	bool desc = (i & k) == 0;
 	if (desc ? (a < b) : (a > b)) { v[i] = b; v[q] = a; }
 }
@@ -86,7 +87,8 @@ __device__ __forceinline__ void prune_ce(unsigned long long* v, int t, int j, in
 // bitonic sort of n (power of two) words, largest first, by 256 threads. Compare-exchange t belongs to the
 // 128-element block t / 64 for every distance j <= 64, and a wave keeps the same blocks from one distance to
 // the next, so those sub-steps need no workgroup barrier — only the distances >= 128 and the stage ends do.
-__device__ __forceinline__ void prune_bitonic(unsigned long long* v, int n, int tid)
+template <class W>
+__device__ __forceinline__ void prune_bitonic(W* v, int n, int tid)
 {
 	for (int k = 2; k <= n; k <<= 1) {
 		int j = k >> 1;
@@ -106,11 +108,11 @@ __device__ __forceinline__ void prune_bitonic(unsigned long long* v, int n, int 
 // In-register bitonic sort of n = 256 * EPT words, largest first: thread t holds the EPT consecutive words
 // sv[t * EPT ..). Distances below EPT are exchanges inside a thread, distances below 64 * EPT are lane
 // shuffles inside a wave; only the few larger ones go through LDS.
-template <int EPT>
-__device__ __forceinline__ void prune_sort_regs(unsigned long long* sv, int tid)
+template <int EPT, class W>
+__device__ __forceinline__ void prune_sort_regs(W* sv, int tid)
 {
 	constexpr int n = 256 * EPT;
-	unsigned long long v[EPT];
+	W v[EPT];
 #pragma unroll
 	for (int i = 0; i < EPT; i++) v[i] = sv[tid * EPT + i];
 	for (int k = 2; k <= n; k <<= 1) {
@@ -132,8 +134,8 @@ __device__ __forceinline__ void prune_sort_regs(unsigned long long* sv, int tid)
 #pragma unroll
 			for (int i = 0; i < EPT; i++) {
 				const bool desc = ((tid * EPT + i) & k) == 0;
-				const unsigned long long o = __shfl_xor(v[i], lx, 64);
-				const unsigned long long hi = v[i] > o ? v[i] : o, lo = v[i] > o ? o : v[i];
+				const W o = __shfl_xor(v[i], lx, 64);
+				const W hi = v[i] > o ? v[i] : o, lo = v[i] > o ? o : v[i];
 				v[i] = (lower == desc) ? hi : lo;
 			}
 		}
@@ -144,8 +146,8 @@ __device__ __forceinline__ void prune_sort_regs(unsigned long long* sv, int tid)
 				for (int i = 0; i < EPT; i++) {
 					if ((i & jj) == 0) {
 						const bool desc = ((tid * EPT + i) & k) == 0;
-						const unsigned long long x = v[i], y = v[i | jj];
-						const unsigned long long hi = x > y ? x : y, lo = x > y ? y : x;
+						const W x = v[i], y = v[i | jj];
+						const W hi = x > y ? x : y, lo = x > y ? y : x;
 						v[i]      = desc ? hi : lo;
 						v[i | jj] = desc ? lo : hi;
 					}
@@ -158,7 +160,8 @@ __device__ __forceinline__ void prune_sort_regs(unsigned long long* sv, int tid)
 	__syncthreads();
 }
 
-__device__ __forceinline__ void prune_sort(unsigned long long* sv, int n, int tid)
+template <class W>
+__device__ __forceinline__ void prune_sort(W* sv, int n, int tid)
 {
 	switch (n) {
 	case 256:  prune_sort_regs<1>(sv, tid); break;
@@ -170,12 +173,31 @@ __device__ __forceinline__ void prune_sort(unsigned long long* sv, int n, int ti
 	}
 }
 
+// The sort words of k_prune_merge are 32 bits wide: the top bits of a (positive) weight — exponent and leading mantissa
+// bits, as many as the slot leaves: 22 for up to 1024 emitted components, relative difference below 1e-3 inside a key —
+// then the slot. Half the shuffles and compares of the 64-bit words above; the runs of equal keys are a little longer
+// (they are ordered by the full weights afterwards, as there). 0 sorts last (padding); no real word is 0.
+__device__ __forceinline__ unsigned int prune_pack32(double w, int slot, int sbits)
+{
+	const int kbn = 32 - sbits;
+	unsigned int kb = (unsigned int) (((unsigned long long) __double_as_longlong(w) << 1) >> (64 - kbn));
+	const unsigned int top = (1u << kbn) - 2u;
+	kb = (kb > top ? top : kb) + 1u;
+	return (kb << sbits) | (unsigned int) slot;
+}
+// the 32 bits of the weight behind those of the key
+__device__ __forceinline__ unsigned int prune_next32(double w, int sbits)
+{
+	return (unsigned int) ((((unsigned long long) __double_as_longlong(w) << 1) << (32 - sbits)) >> 32);
+}
+
 __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const StepBufs& a, int cutcap, double* smem)
 {
 	const PruneLds lay = prune_lds(cutcap);
 	const int cc = (cutcap + 1) & ~1, NS = lay.NS;
 	double* rad2  = smem + lay.rad2;                       // [cut] squared Euclidean bound of row i (inf: none)
-	unsigned long long* sv = (unsigned long long*) (smem + lay.x);     // [NS] sort words
+	unsigned int* sw = (unsigned int*) (smem + lay.x);                 // [NS] sort words (prune_pack32)
+	unsigned int* w2 = sw + NS;                                        // [NS] the 32 weight bits behind the key of slot e < NS
 	unsigned long long* nbr = (unsigned long long*) (smem + lay.x);    // [cut][2]: count + up to 7 close later rows
 	float4* cand  = (float4*) (nbr + 2 * cc);              // [cut] rows grouped by bucket: mean relative to the box (float32), row
 	int*    owner = (int*) (cand + cc);                    // [cut] row that absorbed k (-1: none); the row's bucket while the grid is built
@@ -198,6 +220,9 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 
 	PHD_STAMP(0);
 	// ---- A. order by (weight desc, canonical index asc)
+	int sbits = 1;
+	while ((1 << sbits) < ne) sbits++;                    // bits of a slot number
+	const unsigned int smask = (1u << sbits) - 1u;
 	{
 		int n = 256;                                      // (at least the width of the register sort: small maps, too, skip the barrier-per-stage version)
 		while (n < ne && n < NS) n <<= 1;                 // width of the first pass
@@ -208,33 +233,48 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 			const int from = first ? 0 : (n >> 1);
 			for (int t = from + tid; t < n; t += 256) {
 				int e = taken + (t - from);
-				sv[t] = (e < ne) ? prune_pack(a.emit_w[eb + e], e) : 0ull;
+				unsigned int word = 0u;
+				if (e < ne) {
+					const double w = a.emit_w[eb + e];
+					word = prune_pack32(w, e, sbits);
+					if (e < NS) w2[e] = prune_next32(w, sbits);
+				}
+				sw[t] = word;
 			}
 			taken += n - from;
 			first = false;
 			__syncthreads();
-			prune_sort(sv, n, tid);
+			PHD_STAMP(6);    // (the last pass: fill | sort | runs)
+			prune_sort(sw, n, tid);
+			PHD_STAMP(11);
 			// runs that agree in the key bits: order by (weight desc, canonical index asc); the thread at the
 			// head of a run sorts it (runs are disjoint)
 			for (int r = tid; r + 1 < n; r += 256) {
-				const unsigned long long kb = prune_kbits(sv[r]);
-				if (sv[r + 1] == 0ull || prune_kbits(sv[r + 1]) != kb || (r > 0 && prune_kbits(sv[r - 1]) == kb)) continue;
+				const unsigned int kb = sw[r] >> sbits;
+				if (sw[r + 1] == 0u || (sw[r + 1] >> sbits) != kb || (r > 0 && (sw[r - 1] >> sbits) == kb)) continue;
 				int e = r + 2;
-				while (e < n && sv[e] != 0ull && prune_kbits(sv[e]) == kb) e++;
+				while (e < n && sw[e] != 0u && (sw[e] >> sbits) == kb) e++;
+				// (the 32 weight bits behind the key decide nearly every pair: they are in LDS; the full weights and the
+				// canonical indices, a dependent HBM access each, only behind a tie in all 54 bits)
+				auto next32 = [&](int sl) { return sl < NS ? w2[sl] : prune_next32(a.emit_w[eb + sl], sbits); };
 				for (int x = r + 1; x < e; x++) {   // insertion sort of the run
-					unsigned long long vx = sv[x];
-					int sx = prune_slot(vx);
-					double wx = a.emit_w[eb + sx];
-					int ix = a.emit_idx[eb + sx];
+					const unsigned int vx = sw[x];
+					const int sx = (int) (vx & smask);
+					const unsigned int nx = next32(sx);
 					int y = x - 1;
 					while (y >= r) {
-						int sy = prune_slot(sv[y]);
-						double wy = a.emit_w[eb + sy];
-						if (wy > wx || (wy == wx && a.emit_idx[eb + sy] < ix)) break;   // sy stays before sx
-						sv[y + 1] = sv[y];
+						const int sy = (int) (sw[y] & smask);
+						const unsigned int ny = next32(sy);
+						bool stays = ny > nx;   // sy stays before sx
+						if (ny == nx) {
+							const double wy = a.emit_w[eb + sy], wx = a.emit_w[eb + sx];
+							stays = wy > wx || (wy == wx && a.emit_idx[eb + sy] < a.emit_idx[eb + sx]);
+						}
+						if (stays) break;
+						sw[y + 1] = sw[y];
 						y--;
 					}
-					sv[y + 1] = vx;
+					sw[y + 1] = vx;
 				}
 			}
 			__syncthreads();
@@ -249,7 +289,7 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 	const MixView vpre = bank_view(a, SEL_IN);
 	const int nprior = vpre.count[p], npredicted = nprior + a.born_count[p];
 	for (int r = tid; r < cut; r += 256) {
-		const int slt = prune_slot(sv[r]);
+		const int slt = (int) (sw[r] & smask);
 		const int cidx = a.emit_idx[eb + slt];   // position in the reference's `corrected` list
 		double v[9];
 		if (cidx < npredicted) {
@@ -787,7 +827,7 @@ PHD_REF_ARITH
 	}
 	PHD_STAMP(5);
 	if (tid == 0) vout.count[p] = nsurv_before;
-	PHD_STAMP_FLUSH(2, 11);
+	PHD_STAMP_FLUSH(2, 12);
 }
 
 __global__ __launch_bounds__(256, 4) void k_prune_merge(const DevParams prm, const StepBufs a, int cutcap)

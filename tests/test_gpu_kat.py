@@ -72,6 +72,38 @@ def test_prune_kat_on_the_device():
     nav.close()
 
 
+@pytest.mark.parametrize("maxq", [600, 300])
+def test_prune_order_with_nearly_equal_weights(maxq):
+    """PruneModel's order (weight descending, List.Sort made stable by the position in `corrected`, PHDNavigator.cs:917-925)
+    when weights are equal, differ in the last bit, or differ below what a sort key of k_prune_merge holds (22 bits, then 32
+    more in LDS, then the weights themselves): 560 far-apart components (no merge), passed through the correction step
+    unchanged as in the test above; the cut at MaxQuantity falls inside a run of equal weights."""
+    rng = np.random.default_rng(77)
+    n = 560
+    base = rng.uniform(0.01, 2.0, 40)
+    w = np.empty(n)
+    for i in range(n):
+        b = base[i % 40]
+        kind = (i // 40) % 4
+        if kind == 0: w[i] = b                                   # exact ties with the others of the group
+        elif kind == 1: w[i] = b * (1 + 3e-6 * (i // 160))       # same 22-bit key, other bits behind it
+        elif kind == 2: w[i] = np.nextafter(b, 4.0)              # one ulp above
+        else: w[i] = b * (1 + 1e-13 * (1 + i // 160))            # equal in the first 54 bits
+    order = rng.permutation(n)
+    w = w[order]
+    gx, gy = np.meshgrid(np.arange(28) * 5.0, np.arange(20) * 5.0)
+    means = np.column_stack([gx.ravel()[:n], gy.ravel()[:n], np.zeros(n)])
+    covs = np.broadcast_to(np.diag([0.01, 0.01, 0.01]), (n, 3, 3)).copy()
+    params = dict(KAT["params"], max_quantity=maxq)
+    nav, p = device(params, [1000.0, -1000.0], (w, means, covs))
+    nav.run_stages(np.zeros((0, 3)), with_alpha=False)
+    got = nav.PruneModel(0)
+    want = orc.prune(p, (w, means, covs))
+    assert len(got[0]) == len(want[0]) == min(n, maxq)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    nav.close()
+
+
 def test_linear2d_step_against_the_oracle():
     """a whole SlamUpdate of the toy model (reweight and resampling included) on the device against the oracle"""
     rng = np.random.default_rng(61)
