@@ -232,7 +232,9 @@ __global__ __launch_bounds__(256) void k_gather_rotate(const StepBufs a, const i
 // The mixtures of the current state gathered into its own bank: particle i <- (INMIX, inslot[i]) written to (IN, i),
 // after which INMIX = IN and the slots are the identity. Run before anything that addresses mixtures by particle
 // number in bulk (uploads and downloads of whole states, single-map writes, the sharded step's migration).
-__global__ __launch_bounds__(256) void k_materialise(const StepBufs a, int* sel, int* inslot)
+// (the role INMIX = IN is written by the host once the launch has drained: a workgroup that did it here would redirect the
+// reads of the workgroups that start after it)
+__global__ __launch_bounds__(256) void k_materialise(const StepBufs a, int* inslot)
 {
 	const int i = blockIdx.x, tid = threadIdx.x;
 	const MixView from = bank_view(a, SEL_IN);
@@ -247,7 +249,6 @@ __global__ __launch_bounds__(256) void k_materialise(const StepBufs a, int* sel,
 	}
 	__syncthreads();
 	if (tid == 0) inslot[i] = i;   // only this workgroup reads inslot[i]
-	if (i == 0 && tid == 0) sel[SEL_INMIX] = a.sel[SEL_IN];
 }
 
 // Particle motion: TrackVehicle.UpdateNoisy (TrackVehicle.cs:89-102) = Pose3D.AddOdometry

@@ -483,7 +483,7 @@ int materialise(phd_navigator* nav)
 {
 	if (nav->h_sel[SEL_INMIX] == nav->h_sel[SEL_IN] || nav->P < 1) return PHD_OK;
 	StepBufs b = make_bufs(nav);
-	hipLaunchKernelGGL(k_materialise, dim3(nav->P), dim3(256), 0, nav->stream, b, nav->d_sel + nav->parity * SEL_STRIDE, nav->d_inslot);
+	hipLaunchKernelGGL(k_materialise, dim3(nav->P), dim3(256), 0, nav->stream, b, nav->d_inslot);
 	HC(hipGetLastError());
 	HC(hipStreamSynchronize(nav->stream));
 	nav->h_sel[SEL_INMIX] = nav->h_sel[SEL_IN];   // RES / RESMIX keep describing the last (frozen) step's result, which this did not touch
