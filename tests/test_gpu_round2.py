@@ -379,3 +379,26 @@ def test_a_cluster_beyond_256_rows_is_an_error_that_keeps_the_state(nav_mod):
     nav.SlamUpdate(None, f.z[:40])          # a frame the solver takes runs from the kept state
     assert np.isclose(nav.VehicleWeights.sum(), 1.0)
     nav.close()
+
+
+def test_whole_state_download_behind_a_resampling_step_of_many_particles(nav_mod):
+    """phd_download_state_soa gathers the mixtures a resampling step left behind slot numbers (k_materialise), here with
+    more workgroups than the device holds at once; checked against the per-particle getter, which reads through the
+    slots. (The gather must not depend on anything a workgroup of the same launch writes. It once did — workgroup 0 set
+    the role INMIX — and a late workgroup on a CU that had not yet cached the roles copied a stale map; seen once in
+    test_multi_handle_equals_single_handle, too rare to provoke on purpose.)"""
+    f = Frame(6000, 12, 6, 4242, weight_profile="steady")
+    f.weights = np.random.default_rng(4242).random(f.P) ** 40   # depleted: the step resamples
+    f.weights /= f.weights.sum()
+    nav, p = make_nav(nav_mod, f, maxq=40)
+    nav.SlamUpdate(None, f.z, u_resample=0.37)
+    src, resampled = nav.resample_sources()
+    assert resampled and len(np.unique(src)) < f.P
+    maps = {i: nav.MapModel(i) for i in list(range(0, f.P, 37)) + [f.P - 1]}
+    planes, counts, poses, weights = nav.download_state(40)
+    for i, (w, m, c) in maps.items():
+        assert counts[i] == len(w)
+        assert np.array_equal(planes[0, i, :counts[i]], w)
+        assert np.array_equal(planes[1:4, i, :counts[i]].T, m)
+        assert np.array_equal(planes[4:10, i, :counts[i]].T, c[:, IU[0], IU[1]])
+    nav.close()
