@@ -96,7 +96,7 @@ struct StepBufs {
 	double* wcopy;       // [P][cap + Mcap] weight of the surviving misdetection copy of predicted component c (0: none), k_prune_merge -> k_alpha_density
 	int*    cover;       // [P][cap] 1: this pruned component is such a copy
 	double* stamps;      // [P][16] phase stamps of the diagnostic build (NULL otherwise)
-	int     stamp_kernel; // which kernel writes them (env PHD_STAMP_KERNEL): 2 prune, 3 assoc, 4 density, 1 correct
+	int     stamp_kernel; // which kernel writes them (env PHD_STAMP_KERNEL): 2 prune, 3 assoc, 4 density, 1 correct, 5 the one-launch chain
 };
 
 // The bank playing `role`. The roles rotate on the device (a.sel lives in device memory), so the index is not known
@@ -168,17 +168,25 @@ template <int ZB>
 __global__ __launch_bounds__(256, 1) void k_particle_chain(const DevParams prm, const StepBufs a, int cutcap, int with_alpha)
 {
 	extern __shared__ __align__(16) double smem[];
+	PHD_STAMP_DECL;
+	PHD_STAMP(0);
 	sweep_body<ZB>(prm, a, smem);
 	__syncthreads();   // (workgroup scope: the global writes of the step before are visible to this workgroup's loads)
+	PHD_STAMP(1);
 	emit_finish_body(prm, a, smem);
 	__syncthreads();
+	PHD_STAMP(2);
 	prune_merge_body(prm, a, cutcap, smem);
 	if (with_alpha) {
 		__syncthreads();
+		PHD_STAMP(3);
 		alpha_assoc_body<ZB, false, false, 1>(prm, a, cutcap, smem);
 		__syncthreads();
+		PHD_STAMP(4);
 		alpha_density_body(prm, a, smem);
+		PHD_STAMP(5);
 	}
+	PHD_STAMP_FLUSH(5, 6);   // (diagnostic build, PHD_STAMP_KERNEL=5: the bodies' shares of the chain)
 }
 
 // Test surface (phd_stage_map, PHD_STAGE_CORRECTED): the emitted list carries no mean / covariance for the misdetection

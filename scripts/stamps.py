@@ -25,16 +25,17 @@ from monorfs_amd.synth import Frame
 prof = sys.argv[1] if len(sys.argv) > 1 else "steady"
 if len(sys.argv) > 2:
     os.environ["PHD_STAMP_KERNEL"] = sys.argv[2]   # 2 prune (default), 3 assoc
-f = Frame(2048, 512, 64, 1002, weight_profile=prof)
-p = prm3d_defaults(2048, 600, 64)
-nav = navigator.PHDNavigator(p, particlecount=2048)
+shape = tuple(int(x) for x in os.environ.get("PHD_STAMP_SHAPE", "2048,512,64").split(","))   # particles, components, measurements
+f = Frame(shape[0], shape[1], shape[2], 1002, weight_profile=prof)
+p = prm3d_defaults(shape[0], max(600, shape[1]), shape[2])
+nav = navigator.PHDNavigator(p, particlecount=shape[0])
 nav.upload_state(f.planes(), f.counts, f.poses, f.weights)
 nav.set_measurements(f.z)
 nav.set_frozen(True)
 for _ in range(3):
     nav.step_async(0.5)
 nav.sync()
-out = np.zeros((2048, 16))
+out = np.zeros((shape[0], 16))
 nav._lib.phd_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
 nav._lib.phd_debug_stamps(nav._h, out.ctypes.data_as(C.POINTER(C.c_double)))
 m = out.mean(0)   # stamp i = cycles since stamp 0 (stamps need not be numbered in time order)
