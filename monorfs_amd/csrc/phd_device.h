@@ -158,12 +158,11 @@ __device__ __forceinline__ double detection_probability_m(const DevParams& prm, 
 		mind = fmin(mind, (prm.lin_range - z[1]) / prm.ramp[1]);
 		return fmax(0.0, fmin(1.0, mind)) * prm.pd;
 	}
-	double mind = (z[0] - prm.left) / prm.ramp[0];
-	mind = fmin(mind, (prm.right - z[0]) / prm.ramp[0]);
-	mind = fmin(mind, (z[1] - prm.top) / prm.ramp[1]);
-	mind = fmin(mind, (prm.bottom - z[1]) / prm.ramp[1]);
-	mind = fmin(mind, (z[2] - prm.rmin) / prm.ramp[2]);
-	mind = fmin(mind, (prm.rmax - z[2]) / prm.ramp[2]);
+	// (the reference divides all six distances; a correctly rounded division by a positive number is monotone, so the
+	// smaller quotient of a pair is the quotient of the smaller distance, bit for bit: three divisions)
+	double mind = fmin(z[0] - prm.left, prm.right - z[0]) / prm.ramp[0];
+	mind = fmin(mind, fmin(z[1] - prm.top, prm.bottom - z[1]) / prm.ramp[1]);
+	mind = fmin(mind, fmin(z[2] - prm.rmin, prm.rmax - z[2]) / prm.ramp[2]);
 	return fmax(0.0, fmin(1.0, mind)) * prm.pd;
 }
 
