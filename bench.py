@@ -316,6 +316,33 @@ def main():
             modes["config_A"] = {"ms_per_step": ma, "value": Pa * Ca * Ma / (ma * 1e-3), "unit": "PHD updates/s", "steps": 50,
                                  "workload": "%d particles x %d components x %d measurements" % (Pa, Ca, Ma)}
 
+        # QuasiSetLogLikelihood of a batch of candidate poses against one landmark set and one measurement
+        # set (the smoother's shape: PHDNavigator.cs:526-548, LoopyPHDNavigator.cs:876-909) through the C-ABI, host arrays in
+        # and out (PCIe-inclusive): 50 landmarks seen from the base pose, their detections + clutter, poses jittered around it
+        try:
+            from monorfs_amd.synth import measure_to_map_identity, measure_perfect_identity
+            qrng = np.random.default_rng(77)
+            nlm, nz, nq = 50, min(M, 64), P
+            zc = np.stack([qrng.uniform(-300, 300, nlm), qrng.uniform(-220, 220, nlm), qrng.uniform(0.3, 1.8, nlm)], axis=1)
+            lms = measure_to_map_identity(zc)
+            qz = measure_perfect_identity(lms[qrng.choice(nlm, size=min(nz, nlm), replace=False)]) + qrng.normal(size=(min(nz, nlm), 3)) * np.sqrt([2.0, 2.0, 1e-3])
+            qposes = np.tile([0, 0, 0, 1.0, 0, 0, 0], (nq, 1)) + np.concatenate([qrng.normal(size=(nq, 3)) * 2e-3, np.zeros((nq, 1)), qrng.normal(size=(nq, 3)) * 5e-4], axis=1)
+            nav.QuasiSetLogLikelihood(qz, lms, qposes)
+            t1 = time.perf_counter()
+            for _ in range(5):
+                nav.QuasiSetLogLikelihood(qz, lms, qposes)
+            tv = (time.perf_counter() - t1) / 5
+            nav.QuasiSetLogLikelihoodGradient(qz, lms, qposes)
+            t1 = time.perf_counter()
+            for _ in range(5):
+                nav.QuasiSetLogLikelihoodGradient(qz, lms, qposes)
+            tg = (time.perf_counter() - t1) / 5
+            modes["quasi_set_loglik"] = {"poses": nq, "landmarks": nlm, "measurements": int(len(qz)), "value_ms": tv * 1e3, "value_poses_per_s": nq / tv,
+                                         "value_and_gradient_ms": tg * 1e3, "gradient_poses_per_s": nq / tg,
+                                         "note": "SURVEY row f4, one call per batch through the C-ABI with host arrays (transfers included)"}
+        except Exception as e:   # an extra leg must not take the headline line with it
+            modes["quasi_set_loglik"] = {"error": str(e)}
+
     if rank == 0:
         units = P * world * Cc * M * args.steps
         ms = elapsed / args.steps * 1e3
