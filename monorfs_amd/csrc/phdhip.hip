@@ -13,6 +13,8 @@
 #include <string>
 #include <vector>
 
+#define PHD_MAX_DEVICES 64   // device ordinals a process may hand to phd_create / phd_create_multi
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -567,7 +569,7 @@ phd_navigator* phd_create(const phd_params* params, int device)
 		g_create_error = "no HIP device: libphdhip has no CPU path";
 		return nullptr;
 	}
-	if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) {
+	if (device < 0 || device >= ndev || device >= PHD_MAX_DEVICES || hipSetDevice(device) != hipSuccess) {
 		g_create_error = "bad device ordinal";
 		return nullptr;
 	}
@@ -640,29 +642,32 @@ phd_navigator* phd_create(const phd_params* params, int device)
 		ok = ok && hipEventCreateWithFlags(&nav->ev_stage[i], hipEventDisableTiming) == hipSuccess;
 	}
 	{
-		// dynamic LDS limits, once: they depend on the handle's capacities only (the same kernels serve every handle of the
-		// process: the limit is only ever raised)
-		static int lim_prune = 0, lim_alpha[3] = {0, 0, 0}, lim_chain[3] = {0, 0, 0};
+		// dynamic LDS limits, set when a handle is created: they depend on the handle's capacities only. The attribute belongs
+		// to the function ON THE CURRENT DEVICE, and the same kernels serve every handle of the process there: per device
+		// the limit is only ever raised.
+		struct DevLimits { int prune = 0, alpha[3] = {0, 0, 0}, chain[3] = {0, 0, 0}; };
+		static DevLimits limits[PHD_MAX_DEVICES];
+		DevLimits& lim = limits[device];
 		const int lp = prune_lds(nav->cutcap).bytes;
-		if (lp > lim_prune) { ok = ok && hipFuncSetAttribute((const void*) k_prune_merge, hipFuncAttributeMaxDynamicSharedMemorySize, lp) == hipSuccess; lim_prune = lp; }
+		if (lp > lim.prune) { ok = ok && hipFuncSetAttribute((const void*) k_prune_merge, hipFuncAttributeMaxDynamicSharedMemorySize, lp) == hipSuccess; lim.prune = lp; }
 		const int la[3] = {alpha_lds(64, nav->cutcap).bytes, alpha_lds(128, nav->cutcap).bytes, alpha_lds(256, nav->cutcap).bytes};
-		if (la[0] > lim_alpha[0]) {
+		if (la[0] > lim.alpha[0]) {
 			ok = ok && hipFuncSetAttribute((const void*) k_alpha_assoc<1>, hipFuncAttributeMaxDynamicSharedMemorySize, la[0]) == hipSuccess;
 			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll<1>, hipFuncAttributeMaxDynamicSharedMemorySize, la[0]) == hipSuccess;
 			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll_grad<1>, hipFuncAttributeMaxDynamicSharedMemorySize, la[0]) == hipSuccess;
-			lim_alpha[0] = la[0];
+			lim.alpha[0] = la[0];
 		}
-		if (la[1] > lim_alpha[1]) {
+		if (la[1] > lim.alpha[1]) {
 			ok = ok && hipFuncSetAttribute((const void*) k_alpha_assoc<2>, hipFuncAttributeMaxDynamicSharedMemorySize, la[1]) == hipSuccess;
 			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll<2>, hipFuncAttributeMaxDynamicSharedMemorySize, la[1]) == hipSuccess;
 			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll_grad<2>, hipFuncAttributeMaxDynamicSharedMemorySize, la[1]) == hipSuccess;
-			lim_alpha[1] = la[1];
+			lim.alpha[1] = la[1];
 		}
-		if (la[2] > lim_alpha[2]) {
+		if (la[2] > lim.alpha[2]) {
 			ok = ok && hipFuncSetAttribute((const void*) k_alpha_assoc<4>, hipFuncAttributeMaxDynamicSharedMemorySize, la[2]) == hipSuccess;
 			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll<4>, hipFuncAttributeMaxDynamicSharedMemorySize, la[2]) == hipSuccess;
 			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll_grad<4>, hipFuncAttributeMaxDynamicSharedMemorySize, la[2]) == hipSuccess;
-			lim_alpha[2] = la[2];
+			lim.alpha[2] = la[2];
 		}
 		// the one-launch chain: its bodies share one pool, the largest of their layouts, which must fit a workgroup (160 KB)
 		// with the kernel's few static words; where it does not (a large MaxQuantity) the separate kernels run
@@ -672,9 +677,9 @@ phd_navigator* phd_create(const phd_params* params, int device)
 			hipFuncAttributes fc;
 			if (hipFuncGetAttributes(&fc, chainfn[z]) != hipSuccess) { ok = false; break; }
 			if ((size_t) fc.sharedSizeBytes + (size_t) lc[z] + 256 > 160 * 1024) continue;   // chain_ok[z] stays false
-			if (lc[z] > lim_chain[z]) {
+			if (lc[z] > lim.chain[z]) {
 				if (hipFuncSetAttribute(chainfn[z], hipFuncAttributeMaxDynamicSharedMemorySize, lc[z]) != hipSuccess) { (void) hipGetLastError(); continue; }
-				lim_chain[z] = lc[z];
+				lim.chain[z] = lc[z];
 			}
 			nav->chain_ok[z] = true;
 		}
