@@ -9,7 +9,7 @@ ROOTDIR=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOTDIR/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-events $*"
+ARGS="--steps 40 --warmup 2 --no-cpu-baseline --no-events $*"   # (40 steps: the cold first launches then weigh 2 % in the averages, not 10 %)
 echo "== kernel trace" > "$OUT/log.txt"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOTDIR/bench.py" $ARGS >> "$OUT/log.txt" 2>&1 || exit 1
 echo "== pmc sq" >> "$OUT/log.txt"
