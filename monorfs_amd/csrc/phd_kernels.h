@@ -164,13 +164,13 @@ __host__ __device__ inline int chain_lds_bytes(int cutcap)
 	return b;
 }
 
-template <int ZB>
+template <int ZB, bool HALF = false>
 __global__ __launch_bounds__(256, 1) void k_particle_chain(const DevParams prm, const StepBufs a, int cutcap, int with_alpha)
 {
 	extern __shared__ __align__(16) double smem[];
 	PHD_STAMP_DECL;
 	PHD_STAMP(0);
-	sweep_body<ZB>(prm, a, smem);
+	sweep_body<ZB, HALF>(prm, a, smem);
 	__syncthreads();   // (workgroup scope: the global writes of the step before are visible to this workgroup's loads)
 	PHD_STAMP(1);
 	emit_finish_body(prm, a, smem);

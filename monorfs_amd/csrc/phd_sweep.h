@@ -28,9 +28,13 @@ struct SweepLds {
 	static constexpr int doubles = ints + (MP + SW_UMAX + 4) / 2;
 };
 
-template <int ZB>
+// HALF (with ZB = 1, at most 32 measurements — the common frame of the reference's own scenes): lanes 32-63 hold the
+// measurements of lanes 0-31 again and take the component four further on, so a visit of the pair loop covers two
+// components and the loop is half as long; the two halves' partial sums of a measurement meet in the reductions.
+template <int ZB, bool HALF = false>
 __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs& a, double* pool)
 {
+	static_assert(!HALF || ZB == 1, "HALF is a layout of the one-block kernel");
 	using L = SweepLds<ZB>;
 	constexpr int MP = L::MP;
 	double* const zs = pool + L::zs;
@@ -48,6 +52,9 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 
 	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int M = a.M;
+	const int klane = HALF ? (lane & 31) : lane;          // this lane's measurement (within its block of 64)
+	const int hoff  = HALF ? 4 * (lane >> 5) : 0;         // ... and how far behind the wave's component its own is
+	const bool owner = !HALF || lane < 32;                // the lane that speaks for the measurement in the reductions
 	const MixView vin = bank_view(a, SEL_IN);
 	const Bank bin = bank_of(a, SEL_IN);
 	const int n = vin.count[p];
@@ -79,7 +86,7 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 	bool   zv[ZB];
 #pragma unroll
 	for (int b = 0; b < ZB; b++) {
-		zv[b] = b * 64 + lane < M;
+		zv[b] = b * 64 + klane < M;
 		wsum[b] = 0; dens[b] = 0;
 	}
 	// this lane's measurements, from LDS into registers: done anew behind every staging phase (which needs the registers
@@ -87,7 +94,7 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 	auto load_z = [&]() {
 #pragma unroll
 		for (int b = 0; b < ZB; b++) {
-			const int k = b * 64 + lane;
+			const int k = b * 64 + klane;
 			zx[b] = zs[k * 3]; zy[b] = zs[k * 3 + 1]; zr[b] = zs[k * 3 + 2];
 			wx[b] = zmap[k * 3]; wy[b] = zmap[k * 3 + 1]; wz[b] = zmap[k * 3 + 2];
 		}
@@ -110,21 +117,29 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 	unsigned long long zvm[ZB];
 #pragma unroll
 	for (int b = 0; b < ZB; b++) zvm[b] = ballot64(zv[b]);
-	auto weigh = [&](const double* tt, int b, double sq, int c) {
+	// (cval: this lane's component exists — always, except for the upper half of a HALF visit at the end of a tile)
+	auto weigh = [&](const double* tt, int b, double sq, int c, bool cval) {
 		const double x = gauss_logw(tt, zx[b] - tt[0], zy[b] - tt[1], zr[b] - tt[2]);
-		const unsigned long long nm = ballot64(sq <= g2c) & zvm[b];
+		const unsigned long long nm = ballot64(sq <= g2c) & (HALF ? ballot64(zv[b] && cval) : zvm[b]);
 		if (nm) {   // (wave-uniform)
-			const double v = exp_pair(x, etab, zv[b] && sq <= g2c);   // PD w * mc.Evaluate(z); 0 outside the gate
+			const double v = exp_pair(x, etab, zv[b] && sq <= g2c && (!HALF || cval));   // PD w * mc.Evaluate(z); 0 outside the gate
 			wsum[b] += v;
 			const unsigned long long bal = ballot64(v >= fma(cfac, wsum[b], ckap)) & nm;
 			if (bal) {
 				if ((bal >> lane) & 1ull) {
 					const int slot = ncand_w + __popcll(bal & lanemask_lt());
-					if (slot < segcap) cands[slot] = make_int2((c << 8) | (b * 64 + lane), __float_as_int((float) x));
+					if (slot < segcap) cands[slot] = make_int2((c << 8) | (b * 64 + klane), __float_as_int((float) x));
 				}
 				ncand_w += __popcll(bal);
 			}
 		}
+	};
+
+	// the four waves' partial sums of measurement k (HALF: of both lane halves)
+	auto sumk = [&](const double* arr, int k) {
+		const double lo = arr[k] + arr[MP + k] + arr[2 * MP + k] + arr[3 * MP + k];
+		if (!HALF) return lo;
+		return lo + (arr[k + 32] + arr[MP + k + 32] + arr[2 * MP + k + 32] + arr[3 * MP + k + 32]);
 	};
 
 	// ---- prior components: Explored density and weight sums together. Every term of the density is >= 0, so a measurement
@@ -206,7 +221,9 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 			}
 		}
 		auto visit = [&](int cc) {
-			const double* tt = tile + cc * SW_REC;
+			const int ccl = HALF ? min(cc + hoff, cend - 1) : cc;   // (HALF: this lane's own component of the visit)
+			const bool cval = !HALF || cc + hoff < cend;
+			const double* tt = tile + ccl * SW_REC;
 #pragma unroll
 			for (int b = 0; b < ZB; b++) {
 				double e0 = wx[b] - tt[10], e1 = wy[b] - tt[11], e2 = wz[b] - tt[12];
@@ -214,14 +231,19 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 				if (!compact) {
 					// w * N(x; m, P) of the component at MeasureToMap(z), inside the radius gate (Map.cs:214-217)
 					double vm = exp_neg(gauss_logw(tt + 10, e0, e1, e2), etab);
-					if (zv[b] && sq <= g2e) dens[b] += vm;
+					if (zv[b] && sq <= g2e && cval) dens[b] += vm;
 				}
-				weigh(tt, b, sq, c0 + cc);
+				weigh(tt, b, sq, c0 + ccl, cval);
 			}
 		};
 		int cc = wv;
-		for (; cc + 4 < cend; cc += 8) { visit(cc); visit(cc + 4); }
-		if (cc < cend) visit(cc);
+		if (HALF) {
+			for (; cc < cend; cc += 8) visit(cc);   // components cc and cc + 4 at once
+		}
+		else {
+			for (; cc + 4 < cend; cc += 8) { visit(cc); visit(cc + 4); }
+			if (cc < cend) visit(cc);
+		}
 		if (!compact) {
 #pragma unroll
 			for (int b = 0; b < ZB; b++) part2[wv * MP + b * 64 + lane] = dens[b];
@@ -232,9 +254,9 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 			unsigned long long open[ZB];
 #pragma unroll
 			for (int b = 0; b < ZB; b++) {
-				const int k = b * 64 + lane;
-				const double d = part2[k] + part2[MP + k] + part2[2 * MP + k] + part2[3 * MP + k];
-				open[b] = ballot64(zv[b] && !(d >= thr));
+				const int k = b * 64 + klane;
+				const double d = sumk(part2, k);
+				open[b] = ballot64(zv[b] && owner && !(d >= thr));
 				nopen += __popcll(open[b]);
 			}
 			if (nopen <= SW_UMAX) {
@@ -261,13 +283,13 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 	for (int b = 0; b < ZB; b++) part2[wv * MP + b * 64 + lane] = dens[b];
 	__syncthreads();
 	for (int k = tid; k < MP; k += 256) {
-		double d = part2[k] + part2[MP + k] + part2[2 * MP + k] + part2[3 * MP + k];
+		double d = (k < M) ? sumk(part2, k) : 0.0;
 		born[k] = (k < M) && !(d >= thr);   // !Explored (:808, :958)
 	}
 	__syncthreads();
 	if (tid < s_nu) {   // the measurements finished component-per-lane: their remaining terms are in s_du
 		const int k = s_ulist[tid];
-		const double d = part2[k] + part2[MP + k] + part2[2 * MP + k] + part2[3 * MP + k] + s_du[tid];
+		const double d = sumk(part2, k) + s_du[tid];
 		born[k] = !(d >= thr);
 	}
 	__syncthreads();
@@ -336,19 +358,21 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 	__syncthreads();
 	load_z();
 	// the births' share of the weight sums (they were born from this frame's measurements: :804, :886-890)
-	for (int bi = (wv - n) & 3; bi < nb; bi += 4) {   // component n + bi belongs to wave (n + bi) mod 4, as the prior ones do
-		const double* tt = tile + bi * 13;
+	for (int bi = (wv - n) & 3; bi < nb; bi += HALF ? 8 : 4) {   // component n + bi belongs to wave (n + bi) mod 4, as the prior ones do
+		const int bil = HALF ? min(bi + hoff, nb - 1) : bi;
+		const bool cval = !HALF || bi + hoff < nb;
+		const double* tt = tile + bil * 13;
 #pragma unroll
 		for (int b = 0; b < ZB; b++) {
 			double e0 = wx[b] - tt[10], e1 = wy[b] - tt[11], e2 = wz[b] - tt[12];
-			weigh(tt, b, e0 * e0 + e1 * e1 + e2 * e2, n + bi);
+			weigh(tt, b, e0 * e0 + e1 * e1 + e2 * e2, n + bil, cval);
 		}
 	}
 #pragma unroll
 	for (int b = 0; b < ZB; b++) part[wv * MP + b * 64 + lane] = wsum[b];
 	__syncthreads();
 	for (int k = tid; k < M; k += 256) {
-		a.denom[(size_t) p * a.Mcap + k] = prm.kappa + (part[k] + part[MP + k] + part[2 * MP + k] + part[3 * MP + k]);
+		a.denom[(size_t) p * a.Mcap + k] = prm.kappa + sumk(part, k);
 	}
 	if (lane == 0) a.cand_count[(size_t) p * 4 + wv] = ncand_w;   // above segcap: the segment overflowed
 	if (tid == 0) {
@@ -361,9 +385,9 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 #ifndef PHD_SWEEP_WAVES
 #define PHD_SWEEP_WAVES 4
 #endif
-template <int ZB>
+template <int ZB, bool HALF = false>
 __global__ __launch_bounds__(256, PHD_SWEEP_WAVES) void k_sweep(const DevParams prm, const StepBufs a)
 {
 	__shared__ __align__(16) double pool[SweepLds<ZB>::doubles];
-	sweep_body<ZB>(prm, a, pool);
+	sweep_body<ZB, HALF>(prm, a, pool);
 }

@@ -286,7 +286,9 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha)
 	if (nav->chain_ok[zi] && P <= nav->chain_max) {
 		// a small particle set (up to two workgroups per CU): the whole per-particle chain as one launch
 		timer_begin(nav, T_CH);
-		hipLaunchKernelGGL(k_particle_chain<ZB>, dim3(P), dim3(256), (size_t) chain_lds_bytes<ZB>(nav->cutcap), nav->stream, nav->dp, b0, nav->cutcap, with_alpha ? 1 : 0);
+		// (up to 32 measurements: the sweep with two components per visit, phd_sweep.h HALF)
+		if (ZB == 1 && nav->M <= 32) hipLaunchKernelGGL((k_particle_chain<1, true>), dim3(P), dim3(256), (size_t) chain_lds_bytes<1>(nav->cutcap), nav->stream, nav->dp, b0, nav->cutcap, with_alpha ? 1 : 0);
+		else hipLaunchKernelGGL(k_particle_chain<ZB>, dim3(P), dim3(256), (size_t) chain_lds_bytes<ZB>(nav->cutcap), nav->stream, nav->dp, b0, nav->cutcap, with_alpha ? 1 : 0);
 		timer_end(nav, T_CH);
 		HC(hipGetLastError());
 		return PHD_OK;
@@ -302,7 +304,8 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha)
 		if (n <= 0) continue;
 		hipStream_t st = s == 0 ? nav->stream : nav->aux[s - 1];
 		timer_begin(nav, T_SW, st);
-		hipLaunchKernelGGL(k_sweep<ZB>, dim3(n), dim3(256), 0, st, nav->dp, b);
+		if (ZB == 1 && nav->M <= 32) hipLaunchKernelGGL((k_sweep<1, true>), dim3(n), dim3(256), 0, st, nav->dp, b);
+		else hipLaunchKernelGGL(k_sweep<ZB>, dim3(n), dim3(256), 0, st, nav->dp, b);
 		timer_end(nav, T_SW, st);
 		timer_begin(nav, T_EF, st, true);
 		hipLaunchKernelGGL(k_emit_finish, dim3(n), dim3(256), 0, st, nav->dp, b);
@@ -645,7 +648,7 @@ phd_navigator* phd_create(const phd_params* params, int device)
 		// dynamic LDS limits, set when a handle is created: they depend on the handle's capacities only. The attribute belongs
 		// to the function ON THE CURRENT DEVICE, and the same kernels serve every handle of the process there: per device
 		// the limit is only ever raised.
-		struct DevLimits { int prune = 0, alpha[3] = {0, 0, 0}, chain[3] = {0, 0, 0}; };
+		struct DevLimits { int prune = 0, alpha[3] = {0, 0, 0}, chain[4] = {0, 0, 0, 0}; };
 		static DevLimits limits[PHD_MAX_DEVICES];
 		DevLimits& lim = limits[device];
 		const int lp = prune_lds(nav->cutcap).bytes;
@@ -672,17 +675,23 @@ phd_navigator* phd_create(const phd_params* params, int device)
 		// the one-launch chain: its bodies share one pool, the largest of their layouts, which must fit a workgroup (160 KB)
 		// with the kernel's few static words; where it does not (a large MaxQuantity) the separate kernels run
 		const int lc[3] = {chain_lds_bytes<1>(nav->cutcap), chain_lds_bytes<2>(nav->cutcap), chain_lds_bytes<4>(nav->cutcap)};
-		const void* chainfn[3] = {(const void*) k_particle_chain<1>, (const void*) k_particle_chain<2>, (const void*) k_particle_chain<4>};
-		for (int z = 0; z < 3 && ok; z++) {
+		const void* chainfn[4] = {(const void*) k_particle_chain<1>, (const void*) k_particle_chain<2>, (const void*) k_particle_chain<4>,
+		                          (const void*) k_particle_chain<1, true>};
+		bool fits[4] = {false, false, false, false};
+		for (int z = 0; z < 4 && ok; z++) {
+			const int zl = z == 3 ? 0 : z;   // (the HALF build of the one-block chain shares its layout)
 			hipFuncAttributes fc;
 			if (hipFuncGetAttributes(&fc, chainfn[z]) != hipSuccess) { ok = false; break; }
-			if ((size_t) fc.sharedSizeBytes + (size_t) lc[z] + 256 > 160 * 1024) continue;   // chain_ok[z] stays false
-			if (lc[z] > lim.chain[z]) {
-				if (hipFuncSetAttribute(chainfn[z], hipFuncAttributeMaxDynamicSharedMemorySize, lc[z]) != hipSuccess) { (void) hipGetLastError(); continue; }
-				lim.chain[z] = lc[z];
+			if ((size_t) fc.sharedSizeBytes + (size_t) lc[zl] + 256 > 160 * 1024) continue;
+			if (lc[zl] > lim.chain[z]) {
+				if (hipFuncSetAttribute(chainfn[z], hipFuncAttributeMaxDynamicSharedMemorySize, lc[zl]) != hipSuccess) { (void) hipGetLastError(); continue; }
+				lim.chain[z] = lc[zl];
 			}
-			nav->chain_ok[z] = true;
+			fits[z] = true;
 		}
+		nav->chain_ok[0] = fits[0] && fits[3];
+		nav->chain_ok[1] = fits[1];
+		nav->chain_ok[2] = fits[2];
 		hipFuncAttributes fa;
 		if (ok && hipFuncGetAttributes(&fa, (const void*) k_normalise_resample) == hipSuccess) {
 			nav->nr_static_lds = (int) fa.sharedSizeBytes;
