@@ -27,6 +27,11 @@ sys.path.insert(0, ROOT)
 
 FP64_SUSTAINED_TFLOPS = 53.0   # v_fma_f64 over the whole chip, measured (profiles/r01_mfma_f64_probe.txt); nominal 78.6
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+# SURVEY §8d's protocol is ">= 20 warm + >= 100 timed steps": the first ~20 steps behind the creation of a handle run about
+# 5 % slower than the steady state (the device comes out of idle: 0.72 ms per step timed behind 3 warm-up steps, 0.68 behind
+# 20, 0.67 behind 60). The state is therefore rolled this many untimed steps BEFORE the --warmup steps (reported as
+# "preroll_steps"); the timed region is still exactly --steps steps between two barriers.
+PREROLL_STEPS = 20
 
 
 def parse():
@@ -236,7 +241,7 @@ def main():
         nav.sync()
 
     nav.timing_reset(False)
-    for _ in range(args.warmup):
+    for _ in range(PREROLL_STEPS + args.warmup):
         step()
     barrier()
     nav.timing_reset(0 if args.no_events else max(1, min(args.events_every, 255)))
@@ -347,7 +352,7 @@ def main():
         units = P * world * Cc * M * args.steps
         ms = elapsed / args.steps * 1e3
         out = {"metric": "PHD updates/sec (particles x components x measurements)", "value": units / elapsed,
-               "unit": "PHD updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "unit": "PHD updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_steps": PREROLL_STEPS,
                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": "RB-PHD-SLAM SlamUpdate, BASELINE config %s: %d particles/GPU x %d components x %d measurements, "
@@ -451,7 +456,7 @@ def single_process(args):
                      np.concatenate([f.poses for f in frames]), np.full(P * n, 1.0 / (P * n)))
     nav.set_measurements(frames[0].z)
     nav.set_frozen(True)
-    for _ in range(args.warmup):
+    for _ in range(PREROLL_STEPS + args.warmup):
         nav.step_async(0.5)
     nav.sync()
     t0 = time.perf_counter()
@@ -460,7 +465,7 @@ def single_process(args):
     nav.sync()
     elapsed = time.perf_counter() - t0
     out = {"metric": "PHD updates/sec (particles x components x measurements)", "value": P * n * Cc * M * args.steps / elapsed,
-           "unit": "PHD updates/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+           "unit": "PHD updates/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "preroll_steps": PREROLL_STEPS, "ms_per_step": elapsed / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "RB-PHD-SLAM SlamUpdate, BASELINE config %s: %d particles/GPU x %d components x %d measurements, one "
                                   "multi-device handle (phd_create_multi, peer copies), devices %s" % (args.config, P, Cc, M, devices),
