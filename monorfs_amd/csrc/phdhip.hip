@@ -1434,6 +1434,8 @@ void* phd_device_global_weights(phd_navigator* nav, int world_particles)
 	return nav->d_gw;
 }
 
+static int plan_begin(phd_navigator* nav, int world_size);
+
 int phd_step_global_async(phd_navigator* nav, int rank, int world_size, double u_resample)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
@@ -1451,7 +1453,10 @@ int phd_step_global_async(phd_navigator* nav, int rank, int world_size, double u
 	if (rc) return rc;
 	hipLaunchKernelGGL(k_scatter_weights, dim3((nav->P + 255) / 256), dim3(256), 0, nav->stream, b, nav->d_gw, rank * nav->P);
 	HC(hipGetLastError());
-	return PHD_OK;
+	// what phd_migration_plan will read on the host follows the kernel down the stream at once (not when the host gets
+	// round to asking for it: the device idles while the host plans)
+	nav->plan_pending = 0;
+	return plan_begin(nav, world_size);
 }
 
 // Pure host logic (no handle, no device): from the global source vector of a resampling step, which of
