@@ -347,6 +347,26 @@ def main():
                                          "note": "SURVEY row f4, one call per batch through the C-ABI with host arrays (transfers included)"}
         except Exception as e:   # an extra leg must not take the headline line with it
             modes["quasi_set_loglik"] = {"error": str(e)}
+        # the particle motion step on the device (odometry reading + one noise vector per particle from the
+        # host's RNG, TrackVehicle.cs:89-102), host arrays in, asynchronous
+        try:
+            mrng = np.random.default_rng(78)
+            reading = mrng.normal(0, 1, 6) * [0.01, 0.01, 0.01, 0.003, 0.003, 0.003]
+            nmo = nav.particle_count   # (the handle holds the last extra leg's frame)
+            noise = mrng.normal(0, 1, (nmo, 6)) * [5e-3, 5e-3, 5e-3, 2e-4, 2e-4, 2e-4]
+            nav.set_frozen(False)
+            nav.UpdateOdometry(None, reading, noise)
+            nav.sync()
+            t1 = time.perf_counter()
+            for _ in range(20):
+                nav.UpdateOdometry(None, reading, noise)
+            nav.sync()
+            tm = (time.perf_counter() - t1) / 20
+            nav.set_frozen(True)
+            modes["motion_update"] = {"particles": nmo, "us_per_call": tm * 1e6, "particles_per_s": nmo / tm,
+                                      "note": "SURVEY row f1, phd_update_motion with host arrays (the upload of the noise vectors included)"}
+        except Exception as e:
+            modes["motion_update"] = {"error": str(e)}
 
     if rank == 0:
         units = P * world * Cc * M * args.steps
