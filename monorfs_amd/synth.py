@@ -40,12 +40,17 @@ class Frame:
         "steady" = detected components U(0.6, 1.2), the others U(0.002, 0.06): a map consistent with the
         frame, finite particle weights, depletion and resampling."""
         rng = np.random.default_rng(seed)
-        prng = np.random.default_rng([seed, shard]) if shard else rng   # per-particle draws of this shard (rank)
+        # per-particle draws of shard (rank) > 0 come from a stream of their own; the shared stream is drawn from all the
+        # same, so that the map, the weights and the measurements behind it are those of shard 0 on every rank
+        prng = np.random.default_rng([seed, shard]) if shard else None
         self.P, self.C, self.M = P, C, M
         # particle poses: base (identity) + one 30 Hz odometry-noise step, Q = diag(5e-3 x3, 2e-4 x3) (Config.cs:244-249)
         dt = 1.0 / 30
-        dloc = prng.normal(size=(P, 3)) * np.sqrt(5e-3) * dt
-        drot = prng.normal(size=(P, 3)) * np.sqrt(2e-4) * dt
+        dloc = rng.normal(size=(P, 3)) * np.sqrt(5e-3) * dt
+        drot = rng.normal(size=(P, 3)) * np.sqrt(2e-4) * dt
+        if prng is not None:
+            dloc = prng.normal(size=(P, 3)) * np.sqrt(5e-3) * dt
+            drot = prng.normal(size=(P, 3)) * np.sqrt(2e-4) * dt
         q = np.concatenate([np.ones((P, 1)), 0.5 * drot], axis=1)
         q /= np.linalg.norm(q, axis=1, keepdims=True)
         self.poses = np.concatenate([dloc, q], axis=1)
@@ -55,7 +60,10 @@ class Frame:
         A = rng.uniform(-0.05, 0.05, size=(C, 3, 3))
         cov = A @ np.transpose(A, (0, 2, 1)) + 1e-4 * np.eye(3)
         w = rng.uniform(0.05, 1.2, C)
-        self.mean = base[None] + prng.normal(size=(P, C, 3)) * mean_jitter
+        jitter = rng.normal(size=(P, C, 3))
+        if prng is not None:
+            jitter = prng.normal(size=(P, C, 3))
+        self.mean = base[None] + jitter * mean_jitter
         self.cov = np.broadcast_to(cov, (P, C, 3, 3))
         self.w = np.broadcast_to(w, (P, C))
         self.counts = np.full(P, C, np.int32)
