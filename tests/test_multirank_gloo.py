@@ -150,3 +150,19 @@ def test_plan_is_consistent_for_four_ranks():
         for i in range(Pl):
             got = rank * Pl + code[i] if code[i] >= 0 else recv[-(code[i] + 1)]
             assert got == gsrc[rank * Pl + i]
+
+
+def test_the_frames_of_all_ranks_share_map_and_measurements():
+    """bench.py gives every rank Frame(..., shard=rank): the same map (weights, covariances, base means), the same
+    measurements, particle poses and mean jitter of its own; rank 0's frame is the single-GPU frame."""
+    from monorfs_amd.synth import Frame
+    a = Frame(48, 20, 9, 1002, weight_profile="steady")
+    b = Frame(48, 20, 9, 1002, weight_profile="steady", shard=3)
+    c = Frame(48, 20, 9, 1002, weight_profile="steady", shard=5)
+    for f in (b, c):
+        assert np.array_equal(a.z, f.z) and np.array_equal(a.w, f.w) and np.array_equal(a.cov, f.cov)
+        assert np.allclose(a.mean, f.mean, atol=0.1) and not np.array_equal(a.mean, f.mean)
+        assert not np.array_equal(a.poses, f.poses)
+    assert not np.array_equal(b.poses, c.poses)
+    a0 = Frame(48, 20, 9, 1002, weight_profile="steady", shard=0)
+    assert np.array_equal(a.mean, a0.mean) and np.array_equal(a.poses, a0.poses)
