@@ -25,7 +25,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_SUSTAINED_TFLOPS = 53.0   # v_fma_f64 over the whole chip, measured (profiles/r01_mfma_f64_probe.txt); nominal 78.6
+FP64_SUSTAINED_TFLOPS = 53.0   # v_fma_f64 over the whole chip, measured (profiles/r01_mfma_f64_probe.txt)
+FP64_SPEC_TFLOPS = 78.6        # the datasheet FP64 vector rate (4 cycles per wave instruction, 1024 SIMDs, 2.4 GHz)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 # SURVEY §8d's protocol is ">= 20 warm + >= 100 timed steps": the first ~20 steps behind the creation of a handle run about
 # 5 % slower than the steady state (the device comes out of idle: 0.72 ms per step timed behind 3 warm-up steps, 0.68 behind
@@ -40,14 +41,16 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="B", help="BASELINE config name: A, B, S (per-GPU shard of C8 = B)")
-    ap.add_argument("--weights", default="steady", choices=["steady", "survey"],
-                    help="prior weight profile of the synthetic frame (monorfs_amd/synth.py)")
+    ap.add_argument("--weights", default="survey", choices=["steady", "survey"],
+                    help="prior weight profile of the synthetic frame (monorfs_amd/synth.py): survey = SURVEY 8d's literal U(0.05, 1.2), "
+                         "the headline; steady = a map consistent with the frame (finite particle weights, resampling every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="particles in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP events")
     ap.add_argument("--events-every", type=int, default=8, help="time the launches of every n-th step of the timed region (each event costs the device a few microseconds)")
     ap.add_argument("--force-dist", action="store_true", help="take the sharded (RCCL) step path even with one rank (rehearsal)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs of the N = 1 run (isolated kernel times, other modes)")
+    ap.add_argument("--extra-steps", type=int, default=100, help="timed steps of every extra leg (SURVEY 8d: >= 100)")
     ap.add_argument("--single-process", action="store_true",
                     help="N GPUs behind ONE handle in this process (phd_create_multi: peer copies instead of RCCL, the path a C# host drives); "
                          "2048 particles per device as in the sharded run")
@@ -59,8 +62,7 @@ def launch_ranks(args):
     """`bench.py --gpus N` started as ONE process: start the N ranks as children (torch.distributed.run, one per GPU) and
     pass rank 0's JSON line through. Nothing here touches a GPU (counting devices does not initialise HIP on this image);
     the current process is never re-executed."""
-    import torch
-    have = torch.cuda.device_count()
+    have = count_gpus_without_hip()
     if have < args.gpus:
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible to this process; refusing to report a %d-GPU number "
                          "from fewer devices" % (args.gpus, have, args.gpus))
@@ -76,6 +78,71 @@ def launch_ranks(args):
     if rc != 0:
         raise SystemExit("bench.py --gpus %d: the rank processes exited with status %d (no number reported)" % (args.gpus, rc))
     return 0
+
+
+def count_gpus_without_hip():
+    """GPUs this process would see, counted without loading or initialising the HIP runtime: the parent of the rank
+    processes must stay GPU-free (a process that has initialised the GPU must not start other programs on this pool).
+    KFD's topology in sysfs lists every node of the host; a GPU node has simd_count > 0 and counts when its DRM render node
+    can be opened from here. HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES narrow the list as the
+    runtime would."""
+    n = 0
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        for node in sorted(os.listdir(base)):
+            try:
+                props = dict(line.split()[:2] for line in open(os.path.join(base, node, "properties")) if len(line.split()) >= 2)
+            except OSError:
+                continue   # (a node of another container: not ours)
+            if int(props.get("simd_count", "0")) <= 0:
+                continue   # a CPU node
+            # sysfs shows every GPU of the host; the ones this container may use are those whose render node opens
+            # (opening the DRM node is not a HIP call and initialises nothing)
+            minor = int(props.get("drm_render_minor", "-1"))
+            try:
+                fd = os.open("/dev/dri/renderD%d" % minor, os.O_RDWR)
+                os.close(fd)
+                n += 1
+            except OSError:
+                pass
+    except OSError:
+        n = 0
+    if n == 0:
+        # no KFD topology to read (unusual): ask a short-lived child, which may initialise whatever it likes
+        try:
+            out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+            n = int(out.stdout.strip().splitlines()[-1])
+        except Exception:
+            n = 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def host_threads():
+    """threads the CPU baseline may use: the cores this process is allowed on, capped by the container's CPU quota"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    used = n if quota is None else max(1, min(n, int(quota + 0.5)))
+    return used, n, quota
 
 
 def cpu_model():
@@ -127,7 +194,7 @@ def cpu_baseline(frame, params, sample, threads):
     # the same step on 1 thread and on 8 (the reference's Parallel.For runs on NParallel = 8 threads, Config.cs:46), on
     # proportionally smaller particle samples (about a second each)
     by_threads = {}
-    for t in (1, 8):
+    for t in (1, 8, 16):
         if t >= threads:
             continue
         n = min(P, 48 * t)
@@ -193,6 +260,7 @@ def main():
     nav.upload_state(frame.planes(), frame.counts, frame.poses, frame.weights)
     nav.set_measurements(frame.z)
     nav.set_frozen(True)     # steady state: every step sees the same P x C x M input
+    nav.set_all_pairs(True)  # benchmark mode: all C x M pairs evaluated, the gate only masks — the unit count is exact
     lib, h = nav._lib, nav._h
 
     if use_dist:
@@ -278,13 +346,8 @@ def main():
         nav.timing_reset(False)
         nav.set_split(0)
 
-    def short_run(fr, steps=10):
-        """ms per step of a short frozen run on another frame of the same shape (an extra, recorded next to the headline)"""
-        nav.set_frozen(False)
-        nav.upload_state(fr.planes(), fr.counts, fr.poses, fr.weights)
-        nav.set_measurements(fr.z)
-        nav.set_frozen(True)
-        for _ in range(3):
+    def timed(steps, warm=20):
+        for _ in range(warm):
             step()
         barrier()
         t2 = time.perf_counter()
@@ -293,33 +356,51 @@ def main():
         barrier()
         return (time.perf_counter() - t2) / steps * 1e3
 
+    def short_run(fr, steps):
+        """ms per step of a frozen run on another frame that fits the handle (an extra, recorded next to the headline):
+        20 warm + `steps` timed steps"""
+        nav.set_frozen(False)
+        nav.upload_state(fr.planes(), fr.counts, fr.poses, fr.weights)
+        nav.set_measurements(fr.z)
+        nav.set_frozen(True)
+        return timed(steps)
+
     modes = {}
+    xs = max(1, args.extra_steps)
     if extra and args.config == "B":
-        other = "survey" if args.weights == "steady" else "steady"
-        fo = Frame(P, Cc, M, seed, weight_profile=other)
-        mo = short_run(fo)
-        modes["weights_" + other] = {"ms_per_step": mo, "value": P * Cc * M / (mo * 1e-3), "unit": "PHD updates/s", "steps": 10,
-                                     "note": "SURVEY 8d's literal prior weights U(0.05, 1.2): every WeightAlpha underflows, no resampling" if other == "survey"
-                                             else "detected components U(0.6, 1.2), the others U(0.002, 0.06)"}
-        # SURVEY 8d "realistic-gate": the kernels evaluate ALL C x M pairs (the gate only masks), which is what the metric
-        # counts; the reference evaluates only the pairs inside the radius gate of Map.Near (PHDNavigator.cs:882). Their
-        # share on this frame (squared-Euclidean gate, DensityDistanceThreshold), from the frame itself on the host:
+        # SURVEY 8d "realistic-gate": the reference evaluates only the pairs inside the radius gate of Map.Near
+        # (PHDNavigator.cs:882); the headline ran in benchmark mode (all C x M pairs, the gate only masks). The same frame,
+        # the same state, with the all-pairs mode off: k_sweep skips every group of 64 pairs that lies outside the gate as a
+        # whole. A RUN, not an estimate; next to it the share of gated pairs on this frame (host side, 64 particles).
         from monorfs_amd.synth import measure_to_map_identity
+        nav.set_all_pairs(False)
+        mg = timed(xs)
+        nav.set_all_pairs(True)
         samp = min(P, 64)
         x = measure_to_map_identity(frame.z)                                    # base pose = identity up to 1e-3: an estimate
         d2 = ((frame.mean[:samp, :, None, :] - x[None, None, :, :]) ** 2).sum(-1)
         share = float((d2 <= params.density_distance_threshold).mean())
-        modes["realistic_gate"] = {"gated_pair_share": share, "gated_pair_updates_per_s": share * units_per_s(P, Cc, M, elapsed, args.steps, world),
-                                   "note": "share of the (component, measurement) pairs inside the correct-step gate (reference-faithful "
-                                           "sparsity), estimated on %d particles; the rate is the headline value times that share" % samp}
+        modes["realistic_gate"] = {"ms_per_step": mg, "value": P * Cc * M / (mg * 1e-3), "unit": "PHD updates/s (all P x C x M pairs counted)", "steps": xs,
+                                   "gated_pair_share": share, "gated_pair_updates_per_s": share * P * Cc * M / (mg * 1e-3),
+                                   "note": "measured with phd_set_all_pairs(0): groups of 64 pairs outside the correct-step gate are skipped; on this "
+                                           "frame %.0f %% of the pairs are inside the gate and hardly a group is empty" % (100 * share)}
+        other = "survey" if args.weights == "steady" else "steady"
+        fo = Frame(P, Cc, M, seed, weight_profile=other)
+        mo = short_run(fo, xs)
+        modes["weights_" + other] = {"ms_per_step": mo, "value": P * Cc * M / (mo * 1e-3), "unit": "PHD updates/s", "steps": xs,
+                                     "note": "SURVEY 8d's literal prior weights U(0.05, 1.2): every WeightAlpha underflows, no resampling" if other == "survey"
+                                             else "the variant frame: detected components U(0.6, 1.2), the others U(0.002, 0.06) — a map consistent with "
+                                                  "the frame, finite particle weights, depletion and resampling in every step"}
     if extra:
         Pa, Ca, Ma, seeda = CONFIGS["A"]
         if P >= Pa and Cc >= Ca and M >= Ma:
             # BASELINE config A (256 x 128 x 32), the latency-bound regime, on the same handle
-            fa = Frame(Pa, Ca, Ma, seeda, weight_profile=args.weights)
-            ma = short_run(fa, steps=50)
-            modes["config_A"] = {"ms_per_step": ma, "value": Pa * Ca * Ma / (ma * 1e-3), "unit": "PHD updates/s", "steps": 50,
-                                 "workload": "%d particles x %d components x %d measurements" % (Pa, Ca, Ma)}
+            for prof in ("steady", "survey"):
+                fa = Frame(Pa, Ca, Ma, seeda, weight_profile=prof)
+                ma = short_run(fa, xs)
+                modes["config_A" if prof == "steady" else "config_A_survey"] = {
+                    "ms_per_step": ma, "value": Pa * Ca * Ma / (ma * 1e-3), "unit": "PHD updates/s", "steps": xs,
+                    "workload": "%d particles x %d components x %d measurements, prior weights '%s'" % (Pa, Ca, Ma, prof)}
 
         # SURVEY row f4: QuasiSetLogLikelihood of a batch of candidate poses against one landmark set and one measurement
         # set (the smoother's shape: PHDNavigator.cs:526-548, LoopyPHDNavigator.cs:876-909) through the C-ABI, host arrays in
@@ -367,6 +448,43 @@ def main():
                                       "note": "SURVEY row f1, phd_update_motion with host arrays (the upload of the noise vectors included)"}
         except Exception as e:
             modes["motion_update"] = {"error": str(e)}
+        # BASELINE's stress configuration S (4096 x 1024 x 128, MaxQuantity 1024: prune / merge compaction of up to 132 k
+        # corrected components per particle every step), in a handle of its own, benchmark mode, frozen state
+        if args.config == "B":
+            try:
+                Ps, Cs, Ms, seeds = CONFIGS["S"]
+                fs = Frame(Ps, Cs, Ms, seeds, weight_profile=args.weights)
+                ps = prm3d_defaults(max_particles=Ps, max_components=max(600, Cs), max_measurements=Ms)
+                ps.max_quantity = max(600, Cs)
+                navs = navigator.PHDNavigator(ps, particlecount=Ps, device=local_rank)
+                navs.upload_state(fs.planes(), fs.counts, fs.poses, fs.weights)
+                navs.set_measurements(fs.z)
+                navs.set_frozen(True)
+                navs.set_all_pairs(True)
+                navs.timing_reset(False)
+                for _ in range(10):
+                    navs.step_async(0.5)
+                navs.sync()
+                nS = max(20, xs // 4)
+                t1 = time.perf_counter()
+                for _ in range(nS):
+                    navs.step_async(0.5)
+                navs.sync()
+                msS = (time.perf_counter() - t1) / nS * 1e3
+                navs.timing_reset(1)
+                navs.set_split(1)
+                for _ in range(4):
+                    navs.step_async(0.5)
+                navs.sync()
+                kS = navs.last_timings()
+                modes["config_S"] = {"ms_per_step": msS, "value": Ps * Cs * Ms / (msS * 1e-3), "unit": "PHD updates/s", "steps": nS,
+                                     "workload": "%d particles x %d components x %d measurements, MaxQuantity %d, prior weights '%s'" % (Ps, Cs, Ms, ps.max_quantity, args.weights),
+                                     "kernel_ms_isolated": kS, "algorithmic_bytes_per_step": 160.0 * Ps * Cs,
+                                     "achieved_GBs_whole_step": 160.0 * Ps * Cs / (msS * 1e-3) / 1e9}
+                navs.close()
+                del fs
+            except Exception as e:
+                modes["config_S"] = {"error": str(e)}
 
     if rank == 0:
         units = P * world * Cc * M * args.steps
@@ -394,7 +512,7 @@ def main():
             alg_bytes = 160.0 * particles_per_launch * Cc   # 80 B/component read + 80 B written, per particle
             achieved = alg_bytes / (src[dom] * 1e-3) / 1e9
             traffic = None
-            for tname in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+            for tname in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
                 tfile = os.path.join(ROOT, "profiles", tname)
                 if os.path.exists(tfile):
                     try:
@@ -402,7 +520,7 @@ def main():
                     except Exception:
                         traffic = None
                     if traffic is not None:
-                        if not iso and per_step[dom] > 1 and tname.startswith("r02"):
+                        if not iso and per_step[dom] > 1 and not tname.startswith("r01"):
                             traffic = traffic / per_step[dom]   # r02 figures are per whole-range launch
                         break
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -423,7 +541,7 @@ def main():
             # The step is bound by vector-ALU issue, not by HBM: the wave-level VALU instructions of one
             # step (SQ_INSTS_VALU of the committed profile, per particle) against the rate at which the chip sustains
             # FP64 FMAs (scripts/probes/mfma_f64_rate.hip: 53 TFLOP/s = 4.14e11 wave instructions/s).
-            for vname in ("r02_valu_insts.json", "r01_valu_insts.json"):
+            for vname in ("r03_valu_insts.json", "r02_valu_insts.json", "r01_valu_insts.json"):
                 vfile = os.path.join(ROOT, "profiles", vname)
                 if not os.path.exists(vfile):
                     continue
@@ -432,8 +550,12 @@ def main():
                     insts = sum(v.get("per_particle", 0.0) * P + v.get("per_launch", 0.0) for v in valu.values())
                     rate = FP64_SUSTAINED_TFLOPS * 1e12 / 128.0
                     if insts > 0:
+                        spec = FP64_SPEC_TFLOPS * 1e12 / 128.0
                         out["valu_issue"] = {"wave_instructions_per_step": insts, "sustained_wave_instructions_per_s": rate,
                                              "bound_ms": insts / rate * 1e3, "frac": insts / rate * 1e3 / ms,
+                                             "spec_wave_instructions_per_s": spec, "bound_ms_at_spec": insts / spec * 1e3, "frac_at_spec": insts / spec * 1e3 / ms,
+                                             "flop_model": {"flop_per_update": 60, "tflops_delivered": 60.0 * P * Cc * M / (ms * 1e-3) / 1e12,
+                                                            "frac_of_fp64_vector_peak": 60.0 * P * Cc * M / (ms * 1e-3) / 1e12 / FP64_SPEC_TFLOPS},
                                              "source": "profiles/%s (rocprofv3 SQ_INSTS_VALU), profiles/r01_mfma_f64_probe.txt" % vname}
                         break
                 except Exception:
@@ -441,9 +563,11 @@ def main():
         if modes:
             out["other_modes"] = modes
         if world == 1 and not args.no_cpu_baseline:
-            threads = min(os.cpu_count() or 1, 16)
-            sample = args.cpu_sample or min(P, 256)
+            threads, allowed, quota = host_threads()   # every core this process may use
+            sample = args.cpu_sample or min(P, max(256, 4 * threads))
             out["cpu_baseline"] = cpu_baseline(frame, params, sample, threads)
+            out["cpu_baseline"]["cores_allowed"] = allowed
+            out["cpu_baseline"]["cpu_quota"] = quota
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     nav.close()
@@ -453,7 +577,12 @@ def main():
 
 
 def single_process(args):
-    """`--single-process`: the same weak-scaling workload through one multi-device handle (phd_create_multi)."""
+    """`--single-process`: the same weak-scaling workload through one multi-device handle (phd_create_multi) — the host a C#
+    caller drives: one worker thread per shard issues the steps, peer stores move weights and migrating particles, the
+    caller only posts. The line carries the host's cost per step (time inside phd_step_async, time a worker needs to issue
+    a step), the phases of a step on the first shard's stream, and which device pairs are connected peer to peer. When every
+    shard sits on the same device (a rehearsal on one GPU) the same particle set is also run through ONE single-device
+    handle, for the ratio."""
     import torch
     devices = [int(d) for d in args.devices.split(",")] if args.devices else list(range(args.gpus))
     if len(devices) != args.gpus:
@@ -471,28 +600,58 @@ def single_process(args):
     params.max_quantity = maxq
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    planes = np.concatenate([f.planes() for f in frames], axis=1)
+    counts = np.concatenate([f.counts for f in frames])
+    poses = np.concatenate([f.poses for f in frames])
+    weights = np.full(P * n, 1.0 / (P * n))
+
+    def run(nav):
+        nav.upload_state(planes, counts, poses, weights)
+        nav.set_measurements(frames[0].z)
+        nav.set_frozen(True)
+        nav.set_all_pairs(True)
+        nav.timing_reset(False)
+        for _ in range(PREROLL_STEPS + args.warmup):
+            nav.step_async(0.5)
+        nav.sync()
+        nav.timing_reset(max(1, min(args.events_every, 255)))
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            nav.step_async(0.5)
+        t_posted = time.perf_counter() - t0
+        nav.sync()
+        return time.perf_counter() - t0, t_posted
+
     nav = navigator.PHDNavigator(params, particlecount=P * n, devices=devices)
-    nav.upload_state(np.concatenate([f.planes() for f in frames], axis=1), np.concatenate([f.counts for f in frames]),
-                     np.concatenate([f.poses for f in frames]), np.full(P * n, 1.0 / (P * n)))
-    nav.set_measurements(frames[0].z)
-    nav.set_frozen(True)
-    for _ in range(PREROLL_STEPS + args.warmup):
-        nav.step_async(0.5)
-    nav.sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        nav.step_async(0.5)
-    nav.sync()
-    elapsed = time.perf_counter() - t0
+    elapsed, t_posted = run(nav)
+    rep = nav.multi_report()
+    kernels = nav.last_timings()
+    resampled = bool(nav.resample_sources()[1])
+    nav.close()
     out = {"metric": "PHD updates/sec (particles x components x measurements)", "value": P * n * Cc * M * args.steps / elapsed,
            "unit": "PHD updates/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "preroll_steps": PREROLL_STEPS, "ms_per_step": elapsed / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-           "config": {"workload": "RB-PHD-SLAM SlamUpdate, BASELINE config %s: %d particles/GPU x %d components x %d measurements, one "
-                                  "multi-device handle (phd_create_multi, peer copies), devices %s" % (args.config, P, Cc, M, devices),
+           "config": {"workload": "RB-PHD-SLAM SlamUpdate, BASELINE config %s: %d particles/shard x %d components x %d measurements, prior weights '%s', one "
+                                  "multi-device handle (phd_create_multi: a worker thread per shard, peer stores, plan on the device), devices %s"
+                                  % (args.config, P, Cc, M, args.weights, devices),
                       "particles_per_gpu": P, "components": Cc, "measurements": M, "max_quantity": maxq,
-                      "parallelism": "particles sharded x%d in one process" % n}}
+                      "parallelism": "particles sharded x%d in one process" % n},
+           "multi_host": {"post_us_per_step": rep["post_us"], "worker_issue_us_per_step": rep["issue_us"],
+                          "posting_all_steps_ms": t_posted * 1e3, "phase_ms_first_shard": rep["phase_ms"], "phase_samples": rep["sampled_steps"],
+                          "p2p": rep["p2p"], "resampled_every_step": resampled,
+                          "note": "post = the caller's thread inside phd_step_async (it only posts); worker issue = host time one shard's thread needs to issue "
+                                  "a step (launches, two events, 2 (n - 1) stream waits); phases = device time on the first shard's stream"},
+           "kernel_ms_first_shard": kernels}
+    if len(set(devices)) == 1:
+        p1 = prm3d_defaults(max_particles=P * n, max_components=maxq, max_measurements=M)
+        p1.max_quantity = maxq
+        one = navigator.PHDNavigator(p1, particlecount=P * n, device=devices[0])
+        e1, _ = run(one)
+        one.close()
+        out["single_handle_same_particles"] = {"ms_per_step": e1 / args.steps * 1e3, "particles": P * n,
+                                               "multi_over_single": elapsed / e1,
+                                               "note": "all shards share device %d: the same %d particles in ONE single-device handle, same steps" % (devices[0], P * n)}
     os.write(json_fd, (json.dumps(out) + "\n").encode())
-    nav.close()
     return 0
 
 

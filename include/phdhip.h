@@ -20,6 +20,11 @@
  * Threading: one caller thread per handle, no re-entrancy (Simulation.Update drives the
  * navigator from one thread, Simulation.cs:636-673). The library uses HIP streams internally.
  *
+ * Non-finite input: measurements, poses, weights, odometry, noise and map components that are NaN or infinite are rejected
+ * with PHD_ERR_BAD_ARGUMENT by every call that takes them (the state is untouched). The reference would carry a NaN through
+ * its weight sums (PHDNavigator.cs:886-890) and end with NaN particle weights; the device's pair loops count a NaN exponent
+ * as exp(-800) = 0. With finite input the two agree, so the boundary keeps the other case out.
+ *
  * Matrix conventions: row-major; a 3-D Gaussian component is (weight, mean[3], cov[9]);
  * a pose is (x, y, z, qw, qx, qy, qz) as in Pose3D (Pose3D.cs:142-162); a measurement is
  * (px, py, range) as in PixelRangeMeasurement.ToLinear (PixelRangeMeasurement.cs:96-99).
@@ -33,7 +38,8 @@
 extern "C" {
 #endif
 
-#define PHD_API_VERSION 2   /* 2: phd_create_multi, phd_set_association_workspace; phd_migration_local_async gone */
+#define PHD_API_VERSION 3   /* 2: phd_create_multi, phd_set_association_workspace; phd_migration_local_async gone
+                               3: phd_multi_report; phd_device_local_weights is an export buffer; the migration plan is made on the device */
 
 /* status codes */
 #define PHD_OK                    0
@@ -115,6 +121,13 @@ phd_navigator* phd_create(const phd_params* params, int device);
  * phd_quasi_set_loglik[_grad], phd_resample / phd_particle_depleted, the timing calls (first shard); the stage-level KAT entry
  * points and the per-rank sharding primitives below return PHD_ERR_BAD_ARGUMENT.                                       */
 phd_navigator* phd_create_multi(const phd_params* params, const int* devices, int ndevices);
+/* Diagnostics of a multi-device handle (bench.py --single-process). out8: [0..4] mean device time (ms) of the phases of the
+ * sampled steps on the first shard's stream — local step | waiting for the other shards' weights | global resampling + plan
+ * | pack (peer stores of the migrating particles) | waiting for the other shards' records + unpack; [5] mean time the caller
+ * spent inside phd_step_async (us); [6] mean time the slowest shard's worker spent issuing one step (us); [7] sampled steps
+ * (phd_timing_reset(nav, n) samples every n-th step). p2p (may be NULL): [nshards][nshards] bytes, 1 where shard s stores
+ * into shard t's memory directly (peer access or the same device; phd_create_multi fails when a pair cannot).        */
+int            phd_multi_report(phd_navigator* nav, double* out8, uint8_t* p2p, int* nshards);
 const char*    phd_create_error(void);
 /* ≙ Navigator.Dispose (Navigator.cs:395) / ISAM2Lib.deletenavigator.                             */
 void           phd_destroy(phd_navigator* nav);
@@ -171,6 +184,10 @@ int phd_set_association_workspace(phd_navigator* nav, int64_t bytes);
 /* Benchmark aid: when frozen, a step reads the current state but does not replace it, so every
  * step sees identical input sizes (SURVEY §8d "steady state").                                   */
 int phd_set_frozen(phd_navigator* nav, uint8_t frozen);
+/* Benchmark mode of SURVEY §8d: every (component, measurement) pair of the correct step is evaluated and the radius gate
+ * of Map.Near (PHDNavigator.cs:882) only masks, so that the unit count P x C x M is exact. Off (the default) a group of 64
+ * pairs that all lie outside the gate is skipped, as the reference never evaluates them; the results are bit-identical.  */
+int phd_set_all_pairs(phd_navigator* nav, uint8_t all_pairs);
 /* Scheduling knob (1..4; 0 = chosen from the particle count, the default; environment PHD_SPLIT at phd_create): the per-particle kernels of a
  * step are launched as `nsplit` particle sub-ranges on concurrent streams, forked from and joined into the
  * handle's stream. Results do not depend on it.                                                  */
@@ -219,11 +236,14 @@ int phd_particle_depleted(phd_navigator* nav, const double* weights, int npartic
  *                          the gathered vector (identical on every rank), local part of the copy;
  * Device pointers are exposed so the collective runs on device memory without staging.          */
 int   phd_step_local_async(phd_navigator* nav, uint8_t onlymapping);
-void* phd_device_local_weights(phd_navigator* nav);                 /* double[local particles]     */
+void* phd_device_local_weights(phd_navigator* nav);                 /* double[local particles]: an export buffer at a fixed
+                                                                       address, filled by phd_step_local_async on the handle's stream */
 void* phd_device_global_weights(phd_navigator* nav, int world_particles); /* double[world]         */
 int   phd_step_global_async(phd_navigator* nav, int rank, int world_size, double u_resample);
 /* Particle migration after a global resample: packs the particles other ranks need into a
- * contiguous device buffer (send), and unpacks what arrived (recv). Counts are in particles.    */
+ * contiguous device buffer (send), and unpacks what arrived (recv). Counts are in particles.
+ * The plan is made on the device by phd_step_global_async (at most 64 ranks); phd_migration_plan only waits for its 2 n
+ * split sizes, which the plan kernel writes to pinned host memory (no stream synchronisation, no vector crosses).    */
 int   phd_migration_plan(phd_navigator* nav, int rank, int world_size,
                          int32_t* send_counts, int32_t* recv_counts);
 /* The plan itself, as a pure host function (needs no handle and no GPU): `gsrc[world * Pl]` is the
@@ -233,6 +253,14 @@ int   phd_migration_plan(phd_navigator* nav, int rank, int world_size,
  * consecutive slots that take it (its copies share the record, as the copies of a local particle share its map).  */
 int   phd_plan_migration(const int32_t* gsrc, int particles_per_rank, int world_size, int rank,
                          int32_t* send_counts, int32_t* recv_counts, int32_t* send_list, int32_t* dst_code);
+/* Test surface: the plan as the DEVICE makes it inside a step (k_plan_migration; phd_plan_migration is its host statement and
+ * its reference in the tests), on a caller-supplied non-decreasing global source vector. Arrays as phd_plan_migration's, plus
+ * fslot[<= particles_per_rank] (the slot each arriving record is unpacked into) and send_dst[<= particles_per_rank + 64][2]
+ * (destination rank, record number in that rank's receive buffer). *status: 0 ok, 1 dropped, 2 not a resampling result
+ * (decreasing / out of range), 3 send list overflow.                                                                   */
+int   phd_test_migration_plan(phd_navigator* nav, const int32_t* gsrc, int particles_per_rank, int world_size, int rank, int resampled,
+                              int32_t* send_counts, int32_t* recv_counts, int32_t* send_list, int32_t* dst_code, int32_t* fslot,
+                              int32_t* send_dst, int32_t* nsend, int32_t* nrecv, int32_t* status);
 void* phd_migration_send_buffer(phd_navigator* nav, int64_t* bytes_per_particle);
 void* phd_migration_recv_buffer(phd_navigator* nav);
 int   phd_migration_pack_async(phd_navigator* nav);

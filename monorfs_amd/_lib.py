@@ -78,6 +78,7 @@ def load():
         "phd_step_async": (C.c_int, [P, C.c_uint8, C.c_double]),
         "phd_sync": (C.c_int, [P]),
         "phd_set_frozen": (C.c_int, [P, C.c_uint8]),
+        "phd_set_all_pairs": (C.c_int, [P, C.c_uint8]),
         "phd_set_association_workspace": (C.c_int, [P, C.c_int64]),
         "phd_update_motion": (C.c_int, [P, dp, dp, C.c_int, C.c_uint8]),
         "phd_quasi_set_loglik": (C.c_int, [P, dp, C.c_int, dp, C.c_int, dp, C.c_int, dp]),
@@ -102,6 +103,8 @@ def load():
         "phd_step_global_async": (C.c_int, [P, C.c_int, C.c_int, C.c_double]),
         "phd_migration_plan": (C.c_int, [P, C.c_int, C.c_int, ip, ip]),
         "phd_plan_migration": (C.c_int, [ip, C.c_int, C.c_int, C.c_int, ip, ip, ip, ip]),
+        "phd_test_migration_plan": (C.c_int, [P, ip, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, ip, ip, ip, ip, ip, ip, ip]),
+        "phd_multi_report": (C.c_int, [P, dp, u8p, ip]),
         "phd_migration_send_buffer": (C.c_void_p, [P, C.POINTER(C.c_int64)]),
         "phd_migration_recv_buffer": (C.c_void_p, [P]),
         "phd_migration_pack_async": (C.c_int, [P]),
@@ -120,10 +123,10 @@ def load():
 
 EXPORTS = ["phd_api_version", "phd_default_params", "phd_create", "phd_create_multi", "phd_create_error", "phd_destroy", "phd_last_error",
            "phd_reset", "phd_set_poses", "phd_set_weights", "phd_set_map", "phd_slam_update", "phd_set_measurements",
-           "phd_step_async", "phd_sync", "phd_set_frozen", "phd_set_association_workspace", "phd_update_motion", "phd_quasi_set_loglik", "phd_quasi_set_loglik_grad", "phd_test_pairing", "phd_set_split", "phd_weights", "phd_best_particle", "phd_poses",
+           "phd_step_async", "phd_sync", "phd_set_frozen", "phd_set_all_pairs", "phd_set_association_workspace", "phd_update_motion", "phd_quasi_set_loglik", "phd_quasi_set_loglik_grad", "phd_test_pairing", "phd_set_split", "phd_weights", "phd_best_particle", "phd_poses",
            "phd_particle_count", "phd_map", "phd_resample_sources", "phd_stage_run", "phd_stage_map", "phd_stage_alpha",
            "phd_stage_setloglik", "phd_resample", "phd_particle_depleted", "phd_step_local_async",
            "phd_device_local_weights", "phd_device_global_weights", "phd_step_global_async", "phd_migration_plan",
-           "phd_plan_migration", "phd_migration_send_buffer", "phd_migration_recv_buffer", "phd_migration_pack_async",
+           "phd_plan_migration", "phd_test_migration_plan", "phd_multi_report", "phd_migration_send_buffer", "phd_migration_recv_buffer", "phd_migration_pack_async",
            "phd_migration_unpack_async", "phd_stream", "phd_set_stream", "phd_timing_reset", "phd_last_timings", "phd_last_timing_counts", "phd_upload_state_soa",
            "phd_download_state_soa"]

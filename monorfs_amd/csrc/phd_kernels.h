@@ -96,6 +96,8 @@ struct StepBufs {
 	double* wcopy;       // [P][cap + Mcap] weight of the surviving misdetection copy of predicted component c (0: none), k_prune_merge -> k_alpha_density
 	int*    cover;       // [P][cap] 1: this pruned component is such a copy
 	double* stamps;      // [P][16] phase stamps of the diagnostic build (NULL otherwise)
+	int     all_pairs;   // 1: k_sweep evaluates every (component, measurement) pair, the radius gate only masks (SURVEY §8d's benchmark
+	                     // mode: the unit count P C M is exact); 0: a visit whose 64 pairs all lie outside the gate is skipped
 	int     stamp_kernel; // which kernel writes them (env PHD_STAMP_KERNEL): 2 prune, 3 assoc, 4 density, 1 correct, 5 the one-launch chain
 };
 
@@ -207,34 +209,6 @@ __global__ __launch_bounds__(256) void k_expand_emit(const DevParams prm, const 
 			for (int t = 0; t < 9; t++) r[t] = v[t];
 		}
 	}
-}
-
-// The sharded step's rotation when no rank resampled (the single-handle step does this inside k_normalise_resample,
-// rotate_roles in phd_resample.h, where the rules are written down): roles (IN, OUT, TMP, INMIX) = (O, I, T, O), slots
-// identity; frozen: nothing moves. One thread per particle.
-__global__ __launch_bounds__(256) void k_gather_rotate(const StepBufs a, const int* src, const int* info, int first,
-                                                       int* sel_next, int frozen, int* inslot)
-{
-	const int i = blockIdx.x * 256 + threadIdx.x;
-	const int resampled = info[1];
-	const int I = a.sel[SEL_IN], O = a.sel[SEL_OUT], T = a.sel[SEL_TMP], X = a.sel[SEL_INMIX];
-	if (i == 0) {
-		if (frozen)         { sel_next[SEL_IN] = I; sel_next[SEL_OUT] = O; sel_next[SEL_TMP] = T; sel_next[SEL_INMIX] = X; }
-		else if (resampled) { sel_next[SEL_IN] = T; sel_next[SEL_OUT] = I; sel_next[SEL_TMP] = O; sel_next[SEL_INMIX] = O; }
-		else                { sel_next[SEL_IN] = O; sel_next[SEL_OUT] = I; sel_next[SEL_TMP] = T; sel_next[SEL_INMIX] = O; }
-		sel_next[SEL_RES]    = resampled ? T : O;
-		sel_next[SEL_RESMIX] = O;
-	}
-	if (i >= a.P) return;
-	const int s = resampled ? src[first + i] - first : i;
-	if (resampled) {
-		const Bank bo = bank_of(a, SEL_OUT), bt = bank_of(a, SEL_TMP);
-		bt.count[i]   = bo.count[s];
-		bt.weights[i] = bo.weights[i];
-#pragma unroll
-		for (int t = 0; t < 7; t++) bt.poses[(size_t) i * 7 + t] = bo.poses[(size_t) s * 7 + t];
-	}
-	if (!frozen) inslot[i] = s;
 }
 
 // The mixtures of the current state gathered into its own bank: particle i <- (INMIX, inslot[i]) written to (IN, i),
@@ -349,62 +323,279 @@ __global__ __launch_bounds__(256) void k_replicate(const StepBufs a, double weig
 }
 
 // =================================================================================================
-// multi-GPU resampling: particles are sharded contiguously over ranks; after the global resample a
-// slot may need a particle that lives on another rank. A migrating particle travels as one
-// fixed-size record: [count, pose(7), planes(10 x cap)] doubles.
+// Sharded step: particles are sharded contiguously over ranks (one rank = one GPU: a process of its own
+// with RCCL, or a shard of a phd_create_multi handle); after the global resampling a slot may need a particle that lives
+// on another rank. A migrating particle travels as one fixed-size record: [count, pose(7), planes(10 x cap)] doubles.
+// Everything between the global resampling kernel and the next step is decided ON THE DEVICE (k_plan_migration): the host
+// never needs the source vector, only — where a collective wants split sizes (RCCL all-to-all) — 2 n counts.
 // =================================================================================================
+
+// The un-normalised weights of the local step, stored straight into the gathered weight vector of every destination
+// (dst[t] + first): the shards of a multi-device handle write their slice into every peer's vector through peer-mapped
+// pointers (the all-gather of SURVEY §5 / §8e as 16 KB of stores per peer, no copy engine, no host call per pair); the
+// per-rank host hands in one destination, the buffer its collective reads. gflag: the step's status word goes along
+// (slot `flagslot` behind the weights of every destination), so that a step dropped on one shard is dropped on all.
+__global__ __launch_bounds__(256) void k_push_weights(const StepBufs a, double* const* dst, int ndst, int first, int flagslot)
+{
+	const int i = blockIdx.x * 256 + threadIdx.x;
+	const double* w = bank_of(a, SEL_OUT).weights;
+	if (i < a.P) {
+		const double v = w[i];
+		for (int t = 0; t < ndst; t++) dst[t][first + i] = v;
+	}
+	if (i == 0 && flagslot >= 0) {
+		const double f = (double) *a.flags;
+		for (int t = 0; t < ndst; t++) dst[t][flagslot] = f;
+	}
+}
+
 __global__ __launch_bounds__(256) void k_scatter_weights(const StepBufs a, const double* gw, int first)
 {
 	int i = blockIdx.x * 256 + threadIdx.x;
 	if (i < a.P) bank_of(a, SEL_OUT).weights[i] = gw[first + i];
 }
 
-__global__ __launch_bounds__(256) void k_pack_particles(const StepBufs a, const int* sendlist, double* sendbuf)
+// The migration plan of one rank, device-resident. counts: [0, n) records sent to rank t, [n, 2n) records received from
+// rank s, then nsend, nrecv, status, resampled.
+#define MIG_OK        0
+#define MIG_DROPPED   1   // a kernel of the step raised a flag (on this or, multi-device handle, on any shard): nothing moves
+#define MIG_BAD       2   // the source vector is not a resampling result (not non-decreasing, or out of range)
+#define MIG_OVERFLOW  3   // more records than the send list holds
+struct MigPlan {
+	int* code;         // [Pl]  per local slot: >= 0 local source slot, < 0: -(k + 1) = record k of the receive buffer
+	int* fslot;        // [Pl]  OUT-bank slot record k is unpacked into (one no local particle keeps as its source)
+	int* sendlist;     // [sendcap] local slots to pack, grouped by destination rank (ascending), then by destination slot
+	long long* senddst;// [sendcap] destination rank << 32 | record number in that rank's receive buffer
+	int* counts;       // [2 n + 4]
+	int  sendcap;
+};
+
+// exclusive prefix sum of one int per thread over the 1024 threads of the workgroup (wsum: 17 ints of LDS); *total <- the sum
+__device__ __forceinline__ int block_excl_scan(int v, int* wsum, int tid, int* total)
 {
-	const int r = blockIdx.x, tid = threadIdx.x;
-	const int s = sendlist[r];
-	const MixView from = bank_view(a, SEL_OUT);
-	const Bank bo = bank_of(a, SEL_OUT);
-	const size_t rec = (size_t) 8 + (size_t) 10 * a.cap;
-	double* o = sendbuf + (size_t) r * rec;
-	const int n = from.count[s];
-	if (tid == 0) o[0] = (double) n;
-	if (tid < 7) o[1 + tid] = bo.poses[(size_t) s * 7 + tid];
-	const size_t fb = (size_t) s * a.cap;
-	for (int c = tid; c < n; c += 256) {
-		o[8 + c] = from.w[fb + c];
+	const int lane = tid & 63, wv = tid >> 6, nw = (int) (blockDim.x >> 6);
+	int incl = v;
 #pragma unroll
-		for (int t = 0; t < 3; t++) o[8 + (size_t) (1 + t) * a.cap + c] = from.m[t][fb + c];
-#pragma unroll
-		for (int t = 0; t < 6; t++) o[8 + (size_t) (4 + t) * a.cap + c] = from.P[t][fb + c];
+	for (int o = 1; o < 64; o <<= 1) {
+		const int y = __shfl_up(incl, o, 64);
+		if (lane >= o) incl += y;
+	}
+	__syncthreads();   // (wsum may still be read from the scan before)
+	if (lane == 63) wsum[wv] = incl;
+	__syncthreads();
+	int off = 0, tot = 0;
+	for (int q = 0; q < nw; q++) { const int x = wsum[q]; off += (q < wv) ? x : 0; tot += x; }
+	*total = tot;
+	return off + incl - v;
+}
+
+// phd_plan_migration (phdhip.hip, the host statement of the same plan, kept as the ABI's pure function and as this kernel's
+// reference in the tests) for the source vectors systematic resampling produces: those are non-decreasing (the recurrence of
+// PHDNavigator.cs:731-738 only ever advances k), so "the previous slot of rank t whose source lies on rank s" is simply the
+// slot before — every list is a prefix sum. One workgroup of 1024 threads; every rank runs it on the same global vector
+// and derives matching lists (the sender's order per destination is the receiver's order per source).
+//   gsrc [n Pl] global source of every slot; info[1] resampled; lflags: this rank's status word; gflags: the status words
+//   of all ranks as gathered with the weights (NULL: per-rank host); hostcounts: pinned host memory the counts are
+//   written to as well, followed by `seq` (the host polls that word instead of synchronising the stream); NULL: none
+__global__ __launch_bounds__(1024) void k_plan_migration(const int* __restrict__ gsrc, const int* __restrict__ info, const int* lflags,
+                                                         const double* gflags, int Pl, int n, int rank, MigPlan pl, int* hostcounts, int seq)
+{
+	extern __shared__ int sm[];
+	int* const cnt  = sm;                          // [n][n] records rank t takes from rank s
+	int* const base = cnt + n * n;                 // [n] first send-list position of destination t
+	int* const roff = base + n;                    // [n] record number, in destination t's receive buffer, of my first record for it
+	int* const wsum = roff + n;                    // [17]
+	int* const used = wsum + 20;                   // [(Pl + 31) / 32] bit c: OUT slot c stays the source of a local particle
+	__shared__ int s_bad;
+	const int tid = threadIdx.x, nt = (int) blockDim.x;
+	const int Pg = Pl * n, first = rank * Pl;
+	bool drop = *lflags != 0;
+	if (gflags) for (int t = 0; t < n; t++) drop = drop || gflags[t] != 0.0;
+	const int resampled = info[1];
+	int status = drop ? MIG_DROPPED : MIG_OK, nsend = 0, nrecv = 0;
+	if (resampled && !drop) {   // (uniform)
+		for (int i = tid; i < n * n; i += nt) cnt[i] = 0;
+		for (int i = tid; i < (Pl + 31) / 32; i += nt) used[i] = 0;
+		if (tid == 0) s_bad = 0;
+		__syncthreads();
+		// ---- all slots: who takes a record from whom; my own send list
+		const int CH = (Pg + nt - 1) / nt;
+		const int g0 = min(Pg, tid * CH), g1 = min(Pg, g0 + CH);
+		int mine = 0;
+		bool bad = false;
+		for (int g = g0; g < g1; g++) {
+			const int s = gsrc[g], prev = g > 0 ? gsrc[g - 1] : 0;
+			bad = bad || s < 0 || s >= Pg || prev > s;
+			const int t = g / Pl, sr = min(max(s, 0), Pg - 1) / Pl;
+			if (sr != t && (g == t * Pl || prev != s)) {   // a new run of slots of rank t fed by a particle of rank sr: one record
+				atomicAdd(&cnt[t * n + sr], 1);
+				mine += (sr == rank) ? 1 : 0;
+			}
+		}
+		if (bad) s_bad = 1;
+		int k = block_excl_scan(mine, wsum, tid, &nsend);
+		__syncthreads();   // cnt complete
+		if (tid < n) {
+			int b = 0, r = 0;
+			for (int t = 0; t < tid; t++) b += (t != rank) ? cnt[t * n + rank] : 0;     // destinations before `tid`
+			for (int s = 0; s < rank; s++) r += (s != tid) ? cnt[tid * n + s] : 0;      // sources before me at destination `tid`
+			base[tid] = b; roff[tid] = r;
+		}
+		__syncthreads();
+		if (s_bad) status = MIG_BAD;
+		else if (nsend > pl.sendcap) status = MIG_OVERFLOW;
+		if (status == MIG_OK) {
+			for (int g = g0; g < g1; g++) {
+				const int s = gsrc[g], t = g / Pl;
+				if (s / Pl == rank && t != rank && (g == t * Pl || gsrc[g - 1] != s)) {
+					pl.sendlist[k] = s - first;
+					pl.senddst[k] = ((long long) t << 32) | (long long) (roff[t] + (k - base[t]));
+					k++;
+				}
+			}
+			// ---- my slots: local source, or the record that feeds the run the slot belongs to (records numbered in slot order:
+			// with non-decreasing sources that is the order "by source rank, then by slot" the sender packs them in)
+			const int CL = (Pl + nt - 1) / nt;
+			const int i0 = min(Pl, tid * CL), i1 = min(Pl, i0 + CL);
+			int heads = 0;
+			for (int i = i0; i < i1; i++) {
+				const int s = gsrc[first + i];
+				heads += (s / Pl != rank && (i == 0 || gsrc[first + i - 1] != s)) ? 1 : 0;
+			}
+			int slot = block_excl_scan(heads, wsum, tid, &nrecv);
+			for (int i = i0; i < i1; i++) {
+				const int s = gsrc[first + i];
+				if (s / Pl == rank) {
+					pl.code[i] = s - first;
+					atomicOr(&used[(s - first) >> 5], 1 << ((s - first) & 31));
+				}
+				else {
+					slot += (i == 0 || gsrc[first + i - 1] != s) ? 1 : 0;
+					pl.code[i] = -slot;   // record slot - 1
+				}
+			}
+			__syncthreads();
+			// ---- an arriving particle is unpacked into a slot of the OUT bank that no local particle keeps as its source
+			int nfree = 0;
+			for (int c = i0; c < i1; c++) nfree += ((used[c >> 5] >> (c & 31)) & 1) ? 0 : 1;
+			int totfree;
+			int f = block_excl_scan(nfree, wsum, tid, &totfree);
+			for (int c = i0; c < i1; c++) {
+				if (!((used[c >> 5] >> (c & 31)) & 1)) {
+					if (f < nrecv) pl.fslot[f] = c;
+					f++;
+				}
+			}
+			// (at least nrecv slots are fed from elsewhere, so the Pl slots keep at most Pl - nrecv distinct local sources: at
+			// least nrecv slots of the OUT bank are free)
+		}
+		else { nsend = 0; nrecv = 0; }
+	}
+	__syncthreads();
+	const bool live = resampled && status == MIG_OK;
+	for (int t = tid; t < n; t += nt) {
+		pl.counts[t]     = (live && t != rank) ? cnt[t * n + rank] : 0;
+		pl.counts[n + t] = (live && t != rank) ? cnt[rank * n + t] : 0;
+	}
+	if (tid == 0) {
+		pl.counts[2 * n] = nsend; pl.counts[2 * n + 1] = nrecv; pl.counts[2 * n + 2] = status; pl.counts[2 * n + 3] = resampled;
+	}
+	if (hostcounts) {
+		// the same words into pinned host memory, then the sequence number the host waits for (system-scope stores; the
+		// fence orders the counts before it)
+		for (int t = tid; t < n; t += nt) {
+			__hip_atomic_store(hostcounts + t, (live && t != rank) ? cnt[t * n + rank] : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(hostcounts + n + t, (live && t != rank) ? cnt[rank * n + t] : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+		if (tid == 0) {
+			__hip_atomic_store(hostcounts + 2 * n, nsend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(hostcounts + 2 * n + 1, nrecv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(hostcounts + 2 * n + 2, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(hostcounts + 2 * n + 3, resampled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(hostcounts + 2 * n + 4, info[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(hostcounts + 2 * n + 5, *lflags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+		__threadfence_system();
+		__syncthreads();
+		if (tid == 0) __hip_atomic_store(hostcounts + 2 * n + 6, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 }
 
-// End of a sharded step that resampled. As in the single-handle step no local mixture is copied: particle i whose
-// source is a local particle reads that particle's slot of the OUT bank from now on; a particle that arrives from
-// another rank (record j of the receive buffer) is unpacked into a slot of the OUT bank that no local particle uses
-// as a source (fslot[j], chosen by the host plan: there are always enough) and read from there. Block b unpacks record
-// b (if there is one) and sets up particle b: small arrays into TMP, slot into inslot / slots.
-//   dstsrc[i] >= 0: local source slot; < 0: record -(dstsrc[i] + 1)
-__global__ __launch_bounds__(256) void k_unpack_gather(const StepBufs a, const int* dstsrc, const double* recvbuf, int nrecv,
-                                                       const int* fslot, double weight, int* sel_next, int frozen, int* inslot,
-                                                       int* slots)
+// Pack the particles other ranks take: record k of the send list = particle sendlist[k] of the OUT bank. sendbuf != NULL:
+// the records go, in list order, into this rank's send buffer (the host's all-to-all moves them); NULL: each record is
+// stored straight into its place in the destination's receive buffer (recvbase[t], a peer-mapped pointer: multi-device
+// handle). The count comes from the device plan: a fixed grid strides over the records.
+__global__ __launch_bounds__(256) void k_pack_particles(const StepBufs a, const MigPlan pl, int n, double* sendbuf, double* const* recvbase)
+{
+	const int tid = threadIdx.x;
+	const int nsend = pl.counts[2 * n];
+	if (pl.counts[2 * n + 2] != MIG_OK) return;
+	const MixView from = bank_view(a, SEL_OUT);
+	const Bank bo = bank_of(a, SEL_OUT);
+	const size_t rec = (size_t) 8 + (size_t) 10 * a.cap;
+	for (int r = blockIdx.x; r < nsend; r += gridDim.x) {
+		const int s = pl.sendlist[r];
+		double* o;
+		if (sendbuf) o = sendbuf + (size_t) r * rec;
+		else {
+			const long long d = pl.senddst[r];
+			o = recvbase[(int) (d >> 32)] + (size_t) (d & 0xffffffffll) * rec;
+		}
+		const int nc = from.count[s];
+		if (tid == 0) o[0] = (double) nc;
+		if (tid < 7) o[1 + tid] = bo.poses[(size_t) s * 7 + tid];
+		const size_t fb = (size_t) s * a.cap;
+		for (int c = tid; c < nc; c += 256) {
+			o[8 + c] = from.w[fb + c];
+#pragma unroll
+			for (int t = 0; t < 3; t++) o[8 + (size_t) (1 + t) * a.cap + c] = from.m[t][fb + c];
+#pragma unroll
+			for (int t = 0; t < 6; t++) o[8 + (size_t) (4 + t) * a.cap + c] = from.P[t][fb + c];
+		}
+	}
+}
+
+// End of a sharded step, one workgroup per local particle; what it does is read from the device plan, not decided by the
+// host (rotate_roles in phd_resample.h has the rules of the single-handle step, which are these):
+//   dropped step (a flag was raised): the roles stay as they were, nothing is touched
+//   not resampled: (IN, OUT, TMP, INMIX) = (O, I, T, O), slots identity
+//   resampled: as in the single-handle step no local mixture is copied — particle i whose source is a local particle reads
+//     that particle's slot of the OUT bank from now on; a particle that arrives from another rank (record j of the receive
+//     buffer) is unpacked into a slot of the OUT bank that no local particle uses as a source (fslot[j]) and read from
+//     there. Block b unpacks record b (if there is one) and sets up particle b: small arrays into TMP, slot into inslot.
+//     (IN, OUT, TMP, INMIX) = (T, I, O, O)
+//   frozen: roles and slots stay (benchmark steady state); RES / RESMIX / slots say where the result is
+__global__ __launch_bounds__(256) void k_finish_sharded(const StepBufs a, const MigPlan pl, int n, const double* recvbuf, double weight,
+                                                        int* sel_next, int frozen, int* inslot, int* slots)
 {
 	const int i = blockIdx.x, tid = threadIdx.x;
-	const int I = a.sel[SEL_IN], O = a.sel[SEL_OUT], T = a.sel[SEL_TMP];
+	const int nrecv = pl.counts[2 * n + 1], status = pl.counts[2 * n + 2], resampled = pl.counts[2 * n + 3];
+	const int I = a.sel[SEL_IN], O = a.sel[SEL_OUT], T = a.sel[SEL_TMP], X = a.sel[SEL_INMIX];
+	if (status != MIG_OK) {
+		if (i == 0 && tid < SEL_STRIDE) sel_next[tid] = a.sel[tid];
+		return;
+	}
 	if (i == 0 && tid == 0) {
-		if (frozen) { sel_next[SEL_IN] = I; sel_next[SEL_OUT] = O; sel_next[SEL_TMP] = T; sel_next[SEL_INMIX] = a.sel[SEL_INMIX]; }
-		else        { sel_next[SEL_IN] = T; sel_next[SEL_OUT] = I; sel_next[SEL_TMP] = O; sel_next[SEL_INMIX] = O; }
-		sel_next[SEL_RES] = T;
+		if (frozen)         { sel_next[SEL_IN] = I; sel_next[SEL_OUT] = O; sel_next[SEL_TMP] = T; sel_next[SEL_INMIX] = X; }
+		else if (resampled) { sel_next[SEL_IN] = T; sel_next[SEL_OUT] = I; sel_next[SEL_TMP] = O; sel_next[SEL_INMIX] = O; }
+		else                { sel_next[SEL_IN] = O; sel_next[SEL_OUT] = I; sel_next[SEL_TMP] = T; sel_next[SEL_INMIX] = O; }
+		sel_next[SEL_RES]    = resampled ? T : O;
 		sel_next[SEL_RESMIX] = O;
+	}
+	if (!resampled) {
+		if (tid == 0) {
+			slots[i] = i;
+			if (!frozen) inslot[i] = i;
+		}
+		return;
 	}
 	const size_t rec = (size_t) 8 + (size_t) 10 * a.cap;
 	if (i < nrecv) {
 		const MixView dst = bank_view(a, SEL_OUT);
 		const double* r = recvbuf + (size_t) i * rec;
-		const int n = (int) r[0];
-		const size_t db = (size_t) fslot[i] * a.cap;
-		for (int c = tid; c < n; c += 256) {
+		const int nc = (int) r[0];
+		const size_t db = (size_t) pl.fslot[i] * a.cap;
+		for (int c = tid; c < nc; c += 256) {
 			dst.w[db + c] = r[8 + c];
 #pragma unroll
 			for (int t = 0; t < 3; t++) dst.m[t][db + c] = r[8 + (size_t) (1 + t) * a.cap + c];
@@ -412,9 +603,8 @@ __global__ __launch_bounds__(256) void k_unpack_gather(const StepBufs a, const i
 			for (int t = 0; t < 6; t++) dst.P[t][db + c] = r[8 + (size_t) (4 + t) * a.cap + c];
 		}
 	}
-	if (i >= a.P) return;
 	const Bank bo = bank_of(a, SEL_OUT), bt = bank_of(a, SEL_TMP);
-	const int code = dstsrc[i];
+	const int code = pl.code[i];
 	int slot;
 	if (code >= 0) {
 		slot = code;
@@ -424,7 +614,7 @@ __global__ __launch_bounds__(256) void k_unpack_gather(const StepBufs a, const i
 	else {
 		const int j = -(code + 1);
 		const double* r = recvbuf + (size_t) j * rec;
-		slot = fslot[j];
+		slot = pl.fslot[j];
 		if (tid == 0) bt.count[i] = (int) r[0];
 		if (tid < 7) bt.poses[(size_t) i * 7 + tid] = r[1 + tid];
 	}

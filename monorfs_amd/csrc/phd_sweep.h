@@ -5,14 +5,17 @@
 //   CorrectConditional (:882-890)           weightsum[z] = sum_c PD_c w_c N(z; h(m_c), S_c) over |e|^2 <= DDT gate
 // so k_sweep evaluates both Gaussians per visit and shares e, |e|^2, the staging and the loop. Per prior component it
 // stages two gauss_logw records, both built on the spot from (w, m, P): the map-space one (m, -P^-1/2 folded,
-// log(w mult_P)) by waves 0-1 and the measurement-space one (h(m), -(S^-1 + S^-T)/4 folded, log(PD w mult_S); :857-870)
-// by waves 2-3, which also emit the component's misdetection copy w (1 - PD) (:837-840) when it reaches MinWeight.
+// log(w mult_P)) by the first wave(s) and the measurement-space one (h(m), -(S^-1 + S^-T)/4 folded, log(PD w mult_S); :857-870)
+// by the others, which also emit the component's misdetection copy w (1 - PD) (:837-840) when it reaches MinWeight.
 // The births it finds are measured, emitted and added to the weight sums in its tail. Nothing per component goes
 // through HBM between the prior mixture and the emitted list.
 #pragma once
 #include "phd_device.h"
 
-#define SW_TILE   128   // prior components staged per LDS tile
+#ifndef SW_TILE1
+#define SW_TILE1  192   // prior components staged per LDS tile in the one-block kernel (up to 64 measurements): 128 or 192. With 192
+#endif                  // three waves share the dear part of the staging; the kernel's LDS then just fits four workgroups per CU.
+                        // The two- and four-block kernels (more partial-sum arrays) keep 128.
 #define SW_REC    20    // doubles per staged component: zh[3] G[6] lw | m[3] Gm[6] lwm  (two gauss_logw records)
 #define SW_UMAX   16    // measurements still unexplored when the density part leaves the pair loop (see the sweep)
 
@@ -22,7 +25,11 @@
 template <int ZB>
 struct SweepLds {
 	static constexpr int MP = ZB * 64;
-	static constexpr int TD = (SW_TILE * SW_REC > MP * 13) ? SW_TILE * SW_REC : MP * 13;
+	static constexpr int T = (ZB == 1) ? SW_TILE1 : 128;   // components per tile
+	static constexpr int NMAP = 256 - T;                   // threads that build the map-space records (the first waves), ...
+	static constexpr int MAPEACH = T / NMAP;               // ... this many components each
+	static_assert(T % 64 == 0 && T < 256 && T % NMAP == 0, "tile: whole waves, and the map-space threads share it evenly");
+	static constexpr int TD = (T * SW_REC > MP * 13) ? T * SW_REC : MP * 13;
 	static constexpr int zs = 0, zmap = zs + 3 * MP, part = zmap + 3 * MP, part2 = part + 4 * MP, tile = part2 + 4 * MP,
 	                     etab = tile + TD, du = etab + EXPTAB_N, ints = du + SW_UMAX;   // ints: born[MP], ulist[SW_UMAX], nb, nmis, nu
 	static constexpr int doubles = ints + (MP + SW_UMAX + 4) / 2;
@@ -41,7 +48,7 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 	double* const zmap = pool + L::zmap;
 	double* const part = pool + L::part;
 	double* const part2 = pool + L::part2;
-	double* const tile = pool + L::tile;                  // [SW_TILE][20] prior components | [births][13] in the tail
+	double* const tile = pool + L::tile;                  // [L::T][20] prior components | [births][13] in the tail
 	double* const etab = pool + L::etab;
 	double* const s_du = pool + L::du;
 	int* const born = (int*) (pool + L::ints);
@@ -118,10 +125,14 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 #pragma unroll
 	for (int b = 0; b < ZB; b++) zvm[b] = ballot64(zv[b]);
 	// (cval: this lane's component exists — always, except for the upper half of a HALF visit at the end of a tile)
+	// (a visit none of whose 64 pairs lies inside the radius gate contributes exact zeros: it is skipped — the reference only
+	// ever evaluates gated pairs, PHDNavigator.cs:882 — unless the handle is in all-pairs mode, SURVEY §8d's benchmark mode,
+	// where every pair is evaluated and the gate only masks; the results are the same bits either way)
+	const bool allpairs = a.all_pairs != 0;
 	auto weigh = [&](const double* tt, int b, double sq, int c, bool cval) {
-		const double x = gauss_logw(tt, zx[b] - tt[0], zy[b] - tt[1], zr[b] - tt[2]);
 		const unsigned long long nm = ballot64(sq <= g2c) & (HALF ? ballot64(zv[b] && cval) : zvm[b]);
-		if (nm) {   // (wave-uniform)
+		if (nm || allpairs) {   // (wave-uniform)
+			const double x = gauss_logw(tt, zx[b] - tt[0], zy[b] - tt[1], zr[b] - tt[2]);
 			const double v = exp_pair(x, etab, zv[b] && sq <= g2c && (!HALF || cval));   // PD w * mc.Evaluate(z); 0 outside the gate
 			wsum[b] += v;
 			const unsigned long long bal = ballot64(v >= fma(cfac, wsum[b], ckap)) & nm;
@@ -149,24 +160,39 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 	// the open measurements are summed the other way round: component per lane, one open measurement at a time, a
 	// wave reduction per tile. The terms are the same; only their order of addition differs.
 	bool compact = false;   // block-uniform
+	constexpr int SW_TILE = L::T, SW_NMAP = L::NMAP, SW_MAPEACH = L::MAPEACH;
 	for (int c0 = 0; c0 < n; c0 += SW_TILE) {
-		{   // two threads per component: waves 0-1 build its map-space record, waves 2-3 its measurement-space record
-			const int cl = tid & (SW_TILE - 1), c = c0 + cl;
-			bool mis = false;
-			double wm = 0, m[3] = {0, 0, 0}, P[6] = {1, 0, 0, 1, 0, 1};
-			if (c < n) {
-				double* tt = tile + cl * SW_REC;
+		{   // the measurement-space record of a component (h(m), S^-1, PD: ~650 dependent FP64 instructions, :857-870) is built by
+			// one thread of the last SW_TILE / 64 waves; its map-space record (P^-1: ~110) by the first waves, SW_MAPEACH
+			// components per thread — with 192-component tiles three waves share the dear part and one takes the cheap one
+			if (tid < SW_NMAP) {
 #pragma unroll
-				for (int t = 0; t < 6; t++) P[t] = vin.P[t][sb + c];
+				for (int q = 0; q < SW_MAPEACH; q++) {
+					const int cl = tid + q * SW_NMAP, c = c0 + cl;
+					if (c < n) {
+						double P[6], m[3], Pi[6], det;
 #pragma unroll
-				for (int t = 0; t < 3; t++) m[t] = vin.m[t][sb + c];
-				const double w = vin.w[sb + c];
-				if (tid < SW_TILE) {
-					double Pi[6], det;
-					inv_sym3(P, Pi, det);
-					gauss_record(w, m, Pi, PHD_INV_2PI / sqrt(fabs(det)), tt + 10);
+						for (int t = 0; t < 6; t++) P[t] = vin.P[t][sb + c];
+#pragma unroll
+						for (int t = 0; t < 3; t++) m[t] = vin.m[t][sb + c];
+						const double w = vin.w[sb + c];
+						inv_sym3(P, Pi, det);
+						gauss_record(w, m, Pi, PHD_INV_2PI / sqrt(fabs(det)), tile + cl * SW_REC + 10);
+					}
 				}
-				else {
+			}
+			else {   // (wave-uniform) also the misdetection copies that survive MinWeight
+				const int cl = tid - SW_NMAP, c = c0 + cl;
+				bool mis = false;
+				double wm = 0;
+				if (c < n) {
+					double* tt = tile + cl * SW_REC;
+					double P[6], m[3];
+#pragma unroll
+					for (int t = 0; t < 6; t++) P[t] = vin.P[t][sb + c];
+#pragma unroll
+					for (int t = 0; t < 3; t++) m[t] = vin.m[t][sb + c];
+					const double w = vin.w[sb + c];
 					CompMeas q;
 					comp_measure(prm, pose, rq, m, P, q);
 					tt[0] = q.zh[0]; tt[1] = q.zh[1]; tt[2] = q.zh[2];
@@ -180,8 +206,6 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 					wm  = (1 - q.pd) * w;        // component.Reweight((1 - PD) w), :838-839
 					mis = !(wm < prm.minw);
 				}
-			}
-			if (tid >= SW_TILE) {   // (wave-uniform) the misdetection copies that survive MinWeight
 				unsigned long long bal = ballot64(mis);
 				if (bal) {
 					int base = 0, first = __ffsll((long long) bal) - 1;
@@ -228,7 +252,7 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 			for (int b = 0; b < ZB; b++) {
 				double e0 = wx[b] - tt[10], e1 = wy[b] - tt[11], e2 = wz[b] - tt[12];
 				double sq = e0 * e0 + e1 * e1 + e2 * e2;
-				if (!compact) {
+				if (!compact && (allpairs || ballot64(sq <= g2e))) {
 					// w * N(x; m, P) of the component at MeasureToMap(z), inside the radius gate (Map.cs:214-217)
 					double vm = exp_neg(gauss_logw(tt + 10, e0, e1, e2), etab);
 					if (zv[b] && sq <= g2e && cval) dens[b] += vm;

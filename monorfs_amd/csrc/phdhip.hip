@@ -7,6 +7,12 @@
 #include "phd_kernels.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -46,13 +52,12 @@ struct phd_navigator {
 	int Pcap = 0, cap = 0, Mcap = 0, ecap = 0, Jcap = 0, cutcap = 0;
 	int P = 0, M = 0;
 	bool frozen = false;
+	bool all_pairs = false;            // phd_set_all_pairs: the benchmark mode of SURVEY §8d
 
 	Bank   bank[3];
 	int*   d_sel = nullptr;      // [2][SEL_STRIDE]: roles for the current / next step (+ where the last result is)
-	int*   d_mslot = nullptr;    // [Pcap] sharded step: slot of every particle's mixture in the OUT bank; d_fslot [Pcap]: free slots for arrivals
-	int*   d_fslot = nullptr;
+	int*   d_mslot = nullptr;    // [Pcap] sharded step: slot of every particle's mixture in the OUT bank
 	const int* d_res_slots = nullptr;   // slots of the last step's result in RESMIX (frozen mode getters)
-	std::vector<int> h_fslot;
 	int*   d_inslot = nullptr;   // [Pcap] slot of every particle's mixture in the INMIX bank (identity unless the last step resampled)
 	int    parity = 0;
 	int    h_sel[SEL_STRIDE] = {0, 1, 2, 0, 0, 0, 0, 0};
@@ -75,7 +80,7 @@ struct phd_navigator {
 	double* d_motion = nullptr;   // odometry[6] + noise[P][6] of phd_update_motion
 	double* d_quasi = nullptr;    // phd_quasi_set_loglik: poses[Pcap][7], landmarks[Jcap][3], z[256][3], out[Pcap]
 	std::vector<double> h_quasi;
-	double* d_gw = nullptr; int gwcap = 0;           // gathered weights of all ranks
+	double* d_gw = nullptr; int gwcap = 0;           // gathered weights of all ranks (+ their status words behind them: flagslot)
 	double* d_stage = nullptr;                       // device staging of phd_set_poses / phd_set_weights (stored into the IN bank by k_store_small)
 	// pinned host staging of the per-frame inputs (poses, weights, odometry + noise, measurements): the caller's buffers are
 	// copied here and are free when the call returns; the copy to the device is asynchronous. Two buffers, each guarded by
@@ -83,15 +88,19 @@ struct phd_navigator {
 	double* h_stage[2] = {nullptr, nullptr}; hipEvent_t ev_stage[2] = {nullptr, nullptr}; bool stage_used[2] = {false, false};
 	int stage_i = 0; size_t stagecap = 0;
 	int nr_static_lds = 0;                           // static LDS of k_normalise_resample
-	// migration (multi-GPU resampling)
-	double* d_send = nullptr; double* d_recv = nullptr; int* d_plan = nullptr; int migcap = 0;
-	std::vector<int> h_plan_send, h_plan_recv;       // particle lists
-	int* d_sendlist = nullptr; int sendlistcap = 0; int* d_code = nullptr;
+	// sharded step (one rank of a multi-GPU particle set: a process of its own, or a shard of a phd_create_multi handle)
+	double*  d_lw = nullptr;                         // [Pcap] local weights, exported for the host's all-gather (per-rank host)
+	double** d_dst_tab = nullptr; int ndst = 1;      // device table: where k_push_weights stores the local weights (own d_lw | every shard's d_gw)
+	int      push_first = 0, push_flagslot = -1;     // ... at which offset, and where the status word goes (-1: nowhere)
+	double** d_recv_tab = nullptr;                   // device table: the receive buffer of every shard (multi-device handle; NULL: per-rank host)
+	const double* d_gflags = nullptr;                // the gathered status words (multi-device handle)
+	double* d_send = nullptr; double* d_recv = nullptr; int* d_plan = nullptr; int sendrecs = 0, recvrecs = 0;
+	MigPlan plan = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};   // device-resident migration plan (k_plan_migration)
+	int* h_counts = nullptr; int plan_seq = 0;       // pinned + mapped: the plan's counts as the kernel writes them, and the word the host polls
+	bool plan_waiting = false;                       // a plan kernel with host counts is in flight
+	int world = 1, rank = 0;                         // of the last global step
 	int nsend = 0, nrecv = 0, last_world_particles = 1;
-	bool local_gather_done = false;                  // k_gather_local ran for the step being migrated
-	int* h_pin = nullptr; int h_pin_cap = 0;         // pinned: [2] resampling info + the global source vector
-	int  plan_pending = 0;                           // world size of a plan whose device-to-host copies are already enqueued (plan_begin)
-
+	bool sharded_used = false;
 	// host mirrors handed out by the getters
 	std::vector<double> h_weights, h_poses, h_mw, h_mm, h_mc, h_alpha, h_setll, h_tmp;
 	std::vector<int32_t> h_src;
@@ -210,11 +219,27 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.bigws = nav->d_bigws; b.bigws_bytes = nav->bigws_bytes; b.bigws_used = nav->d_bigws_used;
 	b.cand_count = nav->d_cand_count; b.denom = nav->d_denom;
 	b.cand = nav->d_cand; b.candcap = nav->candcap;
-	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account; b.srec = nav->d_srec; b.wcopy = nav->d_wcopy; b.cover = nav->d_cover; b.stamps = nav->d_stamps; b.stamp_kernel = getenv("PHD_STAMP_KERNEL") ? atoi(getenv("PHD_STAMP_KERNEL")) : 2;
+	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account; b.srec = nav->d_srec; b.wcopy = nav->d_wcopy; b.cover = nav->d_cover; b.stamps = nav->d_stamps; b.all_pairs = nav->all_pairs ? 1 : 0; b.stamp_kernel = getenv("PHD_STAMP_KERNEL") ? atoi(getenv("PHD_STAMP_KERNEL")) : 2;
 	return b;
 }
 
 int zb_of(int M) { return M <= 64 ? 1 : (M <= 128 ? 2 : 4); }
+
+// Non-finite numbers do not cross the ABI (include/phdhip.h, "Non-finite input"): the reference lets a NaN term poison a
+// whole weight sum (PHDNavigator.cs:886-890) where the device's pair loops count a NaN exponent as 0 (exp_pair); with
+// finite input the two never meet.
+bool all_finite(const double* v, size_t n)
+{
+	if (!v) return true;
+	unsigned long long bad = 0;
+	for (size_t i = 0; i < n; i++) {
+		unsigned long long b;
+		std::memcpy(&b, v + i, 8);
+		bad |= (unsigned long long) ((b & 0x7ff0000000000000ull) == 0x7ff0000000000000ull);
+	}
+	return bad == 0;
+}
+#define FINITE_OR_FAIL(nav, ptr, n, who) do { if (!all_finite((ptr), (size_t) (n))) return (nav)->fail(PHD_ERR_BAD_ARGUMENT, who ": non-finite input (NaN or infinity) is not accepted"); } while (0)
 
 // A pinned staging buffer nobody reads any more (waits for the copy that last read it: normally long done).
 double* stage_acquire(phd_navigator* nav)
@@ -267,7 +292,10 @@ const char* T_PM = "k_prune_merge";
 const char* T_WA = "k_alpha_assoc";
 const char* T_WD = "k_alpha_density";
 const char* T_NR = "k_normalise_resample";
-const char* T_GR = "k_gather_rotate";
+const char* T_GR = "k_finish_sharded";
+const char* T_PL = "k_plan_migration";
+const char* T_PK = "k_pack_particles";
+const char* T_PW = "k_push_weights";
 const char* T_CH = "k_particle_chain";
 
 // The per-particle kernels of a step. With nsplit > 1 the particle range is cut into sub-ranges whose kernel
@@ -516,6 +544,7 @@ int multi_map(phd_navigator* nav, int particle, int* ncomp, const double** w, co
 const int32_t* multi_resample_sources(phd_navigator* nav, int* length, uint8_t* resampled);
 void multi_destroy(phd_navigator* nav);
 phd_navigator* multi_shard0(phd_navigator* nav);
+static void multi_timing_reset(phd_navigator* nav, uint8_t enabled);
 #define MULTI_UNSUPPORTED(nav, what) if ((nav) && (nav)->multi) return (nav)->fail(PHD_ERR_BAD_ARGUMENT, what ": not available on a multi-device handle (use a single-device handle)")
 
 // =================================================================================================
@@ -650,6 +679,8 @@ phd_navigator* phd_create(const phd_params* params, int device)
 		// the limit is only ever raised.
 		struct DevLimits { int prune = 0, alpha[3] = {0, 0, 0}, chain[4] = {0, 0, 0, 0}; };
 		static DevLimits limits[PHD_MAX_DEVICES];
+		static std::mutex limits_mu;   // (handles may be created from several host threads, one per GPU)
+		std::lock_guard<std::mutex> limits_guard(limits_mu);
 		DevLimits& lim = limits[device];
 		const int lp = prune_lds(nav->cutcap).bytes;
 		if (lp > lim.prune) { ok = ok && hipFuncSetAttribute((const void*) k_prune_merge, hipFuncAttributeMaxDynamicSharedMemorySize, lp) == hipSuccess; lim.prune = lp; }
@@ -728,12 +759,13 @@ void phd_destroy(phd_navigator* nav)
 	for (int i = 0; i < 3; i++) {
 		hipFree(nav->bank[i].mix); hipFree(nav->bank[i].count); hipFree(nav->bank[i].poses); hipFree(nav->bank[i].weights);
 	}
-	hipFree(nav->d_sel); hipFree(nav->d_inslot); hipFree(nav->d_mslot); hipFree(nav->d_fslot); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
+	hipFree(nav->d_sel); hipFree(nav->d_inslot); hipFree(nav->d_mslot); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
-	hipFree(nav->d_murty); hipFree(nav->d_bigws); hipFree(nav->d_bigws_used); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_wcopy); hipFree(nav->d_cover); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_sendlist); hipFree(nav->d_code); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
+	hipFree(nav->d_murty); hipFree(nav->d_bigws); hipFree(nav->d_bigws_used); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_wcopy); hipFree(nav->d_cover); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
+	hipFree(nav->d_lw); hipFree(nav->d_dst_tab); hipFree(nav->d_recv_tab); hipFree(nav->plan.code); hipFree(nav->plan.fslot); hipFree(nav->plan.sendlist); hipFree(nav->plan.senddst); hipFree(nav->plan.counts);
+	if (nav->h_counts) hipHostFree(nav->h_counts);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
-	if (nav->h_pin) hipHostFree(nav->h_pin);
 	for (int i = 0; i < 2; i++) {
 		if (nav->h_stage[i]) hipHostFree(nav->h_stage[i]);
 		if (nav->ev_stage[i]) hipEventDestroy(nav->ev_stage[i]);
@@ -786,6 +818,11 @@ int phd_reset(phd_navigator* nav, int nparticles, const double* pose7, const dou
               const double* cov9, int ncomp)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (ncomp > 0 && (!w || !mean3 || !cov9)) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_reset: map arrays are NULL");
+	FINITE_OR_FAIL(nav, pose7, 7, "phd_reset");
+	FINITE_OR_FAIL(nav, w, std::max(ncomp, 0), "phd_reset");
+	FINITE_OR_FAIL(nav, mean3, (size_t) std::max(ncomp, 0) * 3, "phd_reset");
+	FINITE_OR_FAIL(nav, cov9, (size_t) std::max(ncomp, 0) * 9, "phd_reset");
 	if (nav->multi) return multi_reset(nav, nparticles, pose7, w, mean3, cov9, ncomp);
 	return reset_impl(nav, nparticles, pose7, w, mean3, cov9, ncomp, 1.0 / std::max(nparticles, 1));
 }
@@ -793,6 +830,8 @@ int phd_reset(phd_navigator* nav, int nparticles, const double* pose7, const dou
 int phd_set_poses(phd_navigator* nav, const double* poses7, int nparticles)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nparticles != nav->P || !poses7) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_poses: particle count mismatch");
+	FINITE_OR_FAIL(nav, poses7, (size_t) nparticles * 7, "phd_set_poses");
 	if (nav->multi) return multi_set_small(nav, poses7, nullptr, nparticles);
 	if (nparticles != nav->P || !poses7) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_poses: particle count mismatch");
 	hipSetDevice(nav->device);
@@ -814,6 +853,9 @@ int phd_set_poses(phd_navigator* nav, const double* poses7, int nparticles)
 int phd_update_motion(phd_navigator* nav, const double* odometry6, const double* noise6, int nparticles, uint8_t perfect_still)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (!odometry6 || nparticles != nav->P) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_update_motion: particle count mismatch");
+	FINITE_OR_FAIL(nav, odometry6, 6, "phd_update_motion");
+	FINITE_OR_FAIL(nav, noise6, (size_t) nparticles * 6, "phd_update_motion");
 	if (nav->multi) return multi_update_motion(nav, odometry6, noise6, nparticles, perfect_still);
 	if (nav->prm.model != PHD_MODEL_PRM3D) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_update_motion: Pose3D odometry, the PRM3D model only");
 	if (!odometry6 || nparticles != nav->P) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_update_motion: particle count mismatch");
@@ -843,6 +885,9 @@ static int quasi_batch(phd_navigator* nav, const double* poses7, int nposes, con
 	    nmeasurements > nav->prm.max_measurements || !poses7 || !out || (nlandmarks && !landmarks3) || (nmeasurements && !z3)) {
 		return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_quasi_set_loglik: sizes out of range (poses <= max_particles, landmarks <= min(1024, max_quantity), measurements <= max_measurements)");
 	}
+	FINITE_OR_FAIL(nav, poses7, (size_t) nposes * 7, "phd_quasi_set_loglik");
+	FINITE_OR_FAIL(nav, landmarks3, (size_t) nlandmarks * 3, "phd_quasi_set_loglik");
+	FINITE_OR_FAIL(nav, z3, (size_t) nmeasurements * 3, "phd_quasi_set_loglik");
 	hipSetDevice(nav->device);
 	const size_t op = 0, ol = op + (size_t) nav->Pcap * 7, oz = ol + (size_t) nav->Jcap * 3, oo = oz + 256 * 3, og = oo + nav->Pcap,
 	             total = og + (size_t) nav->Pcap * 6;
@@ -865,6 +910,9 @@ static int quasi_batch(phd_navigator* nav, const double* poses7, int nposes, con
 	default: rc = launch_quasi<4>(nav, b, nposes, gradient); break;
 	}
 	if (rc) return rc;
+	// (the slab blocks this batch took are free again: the next step's association kernel must find the whole slab, and
+	// only a step's own k_normalise_resample resets the counter otherwise)
+	HC(hipMemsetAsync(nav->d_bigws_used, 0, 8, nav->stream));
 	HC(hipMemcpyAsync(out, nav->d_quasi + oo, (size_t) nposes * 8, hipMemcpyDeviceToHost, nav->stream));
 	if (gradient) HC(hipMemcpyAsync(gradients6, nav->d_quasi + og, (size_t) nposes * 6 * 8, hipMemcpyDeviceToHost, nav->stream));
 	HC(hipStreamSynchronize(nav->stream));
@@ -928,6 +976,8 @@ int phd_test_pairing(phd_navigator* nav, const double* matrix, int n, int mode, 
 int phd_set_weights(phd_navigator* nav, const double* weights, int nparticles)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nparticles != nav->P || !weights) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_weights: particle count mismatch");
+	FINITE_OR_FAIL(nav, weights, nparticles, "phd_set_weights");
 	if (nav->multi) return multi_set_small(nav, nullptr, weights, nparticles);
 	if (nparticles != nav->P || !weights) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_weights: particle count mismatch");
 	hipSetDevice(nav->device);
@@ -945,6 +995,10 @@ int phd_set_weights(phd_navigator* nav, const double* weights, int nparticles)
 int phd_set_map(phd_navigator* nav, int particle, const double* w, const double* mean3, const double* cov9, int ncomp)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (ncomp < 0 || (ncomp > 0 && (!w || !mean3 || !cov9))) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_map: bad map arrays");
+	FINITE_OR_FAIL(nav, w, ncomp, "phd_set_map");
+	FINITE_OR_FAIL(nav, mean3, (size_t) ncomp * 3, "phd_set_map");
+	FINITE_OR_FAIL(nav, cov9, (size_t) ncomp * 9, "phd_set_map");
 	if (nav->multi) return multi_set_map(nav, particle, w, mean3, cov9, ncomp);
 	if (particle < 0 || particle >= nav->P) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_map: particle out of range");
 	hipSetDevice(nav->device);
@@ -986,6 +1040,13 @@ int phd_upload_state_soa(phd_navigator* nav, int nparticles, int stride, const d
                          const double* poses7, const double* weights)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nparticles < 1 || nparticles > nav->Pcap || stride < 0 || !counts || !poses7 || !weights || (stride > 0 && !planes)) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_upload_state_soa: sizes out of range");
+	FINITE_OR_FAIL(nav, poses7, (size_t) nparticles * 7, "phd_upload_state_soa");
+	FINITE_OR_FAIL(nav, weights, nparticles, "phd_upload_state_soa");
+	for (int i = 0; i < nparticles; i++) {   // (the components a particle holds; what lies behind its count is not read)
+		if (counts[i] < 0 || counts[i] > stride) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_upload_state_soa: a component count exceeds the stride");
+		for (int f = 0; f < 10; f++) FINITE_OR_FAIL(nav, planes + ((size_t) f * nparticles + i) * stride, counts[i], "phd_upload_state_soa");
+	}
 	if (nav->multi) return multi_upload(nav, nparticles, stride, planes, counts, poses7, weights);
 	return upload_impl(nav, nparticles, stride, planes, (size_t) nparticles * stride, counts, poses7, weights);
 }
@@ -1021,6 +1082,8 @@ int phd_download_state_soa(phd_navigator* nav, int stride, double* planes, int32
 int phd_set_measurements(phd_navigator* nav, const double* z3, int nmeasurements)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nmeasurements < 0 || nmeasurements > nav->prm.max_measurements || (nmeasurements > 0 && !z3)) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_measurements: count out of range");
+	FINITE_OR_FAIL(nav, z3, (size_t) nmeasurements * 3, "phd_set_measurements");
 	if (nav->multi) return multi_set_measurements(nav, z3, nmeasurements);
 	if (nmeasurements < 0 || nmeasurements > nav->prm.max_measurements || (nmeasurements > 0 && !z3)) {
 		return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_measurements: count out of range");
@@ -1066,6 +1129,14 @@ int phd_set_frozen(phd_navigator* nav, uint8_t frozen)
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	if (nav->multi) return multi_forward_int(nav, 2, frozen);
 	nav->frozen = frozen != 0;
+	return PHD_OK;
+}
+
+int phd_set_all_pairs(phd_navigator* nav, uint8_t all_pairs)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) return multi_forward_int(nav, 3, all_pairs);
+	nav->all_pairs = all_pairs != 0;
 	return PHD_OK;
 }
 
@@ -1194,6 +1265,7 @@ int phd_stage_run(phd_navigator* nav, const double* z3, int nmeasurements, uint8
 	if (rc) return rc;
 	hipLaunchKernelGGL(k_expand_emit, dim3(nav->P), dim3(256), 0, nav->stream, nav->dp, b);   // PHD_STAGE_CORRECTED reads whole records
 	HC(hipGetLastError());
+	HC(hipMemsetAsync(nav->d_bigws_used, 0, 8, nav->stream));   // (as behind a quasi batch: no k_normalise_resample follows a stage run)
 	rc = sync_state(nav);
 	if (rc) return rc;
 	nav->stage_valid = true;
@@ -1276,14 +1348,17 @@ const double* phd_stage_setloglik(phd_navigator* nav, int* length)
 	return nav->h_setll.data();
 }
 
+// the gathered weight vector of all ranks (+ room for their status words behind it) and the global source vector
 static int ensure_gw(phd_navigator* nav, int n)
 {
 	if (n <= nav->gwcap) return PHD_OK;
+	if (nav->d_recv_tab) return nav->fail(PHD_ERR_GENERIC, "the gathered-weight vector of a shard cannot grow (other shards hold its address)");
+	HC(hipStreamSynchronize(nav->stream));
 	hipFree(nav->d_gw);
 	nav->d_gw = nullptr;
 	hipFree(nav->d_plan);
 	nav->d_plan = nullptr;
-	HC(hipMalloc((void**) &nav->d_gw, (size_t) n * 8));
+	HC(hipMalloc((void**) &nav->d_gw, ((size_t) n + PHD_MAX_DEVICES) * 8));
 	HC(hipMalloc((void**) &nav->d_plan, (size_t) n * 4));
 	nav->gwcap = n;
 	return PHD_OK;
@@ -1296,19 +1371,21 @@ int phd_resample(phd_navigator* nav, const double* weights, int nparticles, doub
 	if (nav->multi) nav = multi_shard0(nav);
 	if (nparticles < 1 || !weights || !sources) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_resample: bad arguments");
 	hipSetDevice(nav->device);
-	int rc = ensure_gw(nav, nparticles);
-	if (rc) return rc;
 	HC(hipStreamSynchronize(nav->stream));
-	HC(hipMemcpy(nav->d_gw, weights, (size_t) nparticles * 8, hipMemcpyHostToDevice));
-	StepBufs b = make_bufs(nav);
+	// (buffers of its own: the gathered-weight vector of a sharded handle is known to other shards by address)
+	double* d_w = nullptr;
 	int* d_src2 = nullptr;
-	HC(hipMalloc((void**) &d_src2, (size_t) nparticles * 4 + 8));
-	rc = launch_normalise(nav, b, nav->d_gw, nparticles, u_resample, 1, 1, d_src2 + 2, d_src2);
-	hipError_t e = hipStreamSynchronize(nav->stream);
+	HC(hipMalloc((void**) &d_w, (size_t) nparticles * 8));
+	if (hipMalloc((void**) &d_src2, (size_t) nparticles * 4 + 8) != hipSuccess) { hipFree(d_w); return nav->fail(PHD_ERR_DEVICE, "phd_resample: out of device memory"); }
+	hipError_t e = hipMemcpy(d_w, weights, (size_t) nparticles * 8, hipMemcpyHostToDevice);
+	StepBufs b = make_bufs(nav);
+	int rc = (e == hipSuccess) ? launch_normalise(nav, b, d_w, nparticles, u_resample, 1, 1, d_src2 + 2, d_src2) : PHD_OK;
+	if (e == hipSuccess) e = hipStreamSynchronize(nav->stream);
 	int info[2] = {0, 0};
 	if (e == hipSuccess) e = hipMemcpy(sources, d_src2 + 2, (size_t) nparticles * 4, hipMemcpyDeviceToHost);
 	if (e == hipSuccess) e = hipMemcpy(info, d_src2, 8, hipMemcpyDeviceToHost);
-	hipFree(d_src2);
+	hipFree(d_src2); hipFree(d_w);
+	if (rc) return rc;
 	if (e != hipSuccess) return nav->fail(PHD_ERR_DEVICE, hipGetErrorString(e));
 	if (best_particle) *best_particle = info[0];
 	return PHD_OK;
@@ -1320,18 +1397,19 @@ int phd_particle_depleted(phd_navigator* nav, const double* weights, int npartic
 	if (nav->multi) nav = multi_shard0(nav);
 	if (nparticles < 1 || !weights || !depleted) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_particle_depleted: bad arguments");
 	hipSetDevice(nav->device);
-	int rc = ensure_gw(nav, nparticles);
-	if (rc) return rc;
 	HC(hipStreamSynchronize(nav->stream));
-	HC(hipMemcpy(nav->d_gw, weights, (size_t) nparticles * 8, hipMemcpyHostToDevice));
-	StepBufs b = make_bufs(nav);
+	double* d_w = nullptr;
 	int* d_tmp = nullptr;
-	HC(hipMalloc((void**) &d_tmp, (size_t) nparticles * 4 + 8));
-	rc = launch_normalise(nav, b, nav->d_gw, nparticles, 0.5, 0, 1, d_tmp + 2, d_tmp);
-	hipError_t e = hipStreamSynchronize(nav->stream);
+	HC(hipMalloc((void**) &d_w, (size_t) nparticles * 8));
+	if (hipMalloc((void**) &d_tmp, (size_t) nparticles * 4 + 8) != hipSuccess) { hipFree(d_w); return nav->fail(PHD_ERR_DEVICE, "phd_particle_depleted: out of device memory"); }
+	hipError_t e = hipMemcpy(d_w, weights, (size_t) nparticles * 8, hipMemcpyHostToDevice);
+	StepBufs b = make_bufs(nav);
+	int rc = (e == hipSuccess) ? launch_normalise(nav, b, d_w, nparticles, 0.5, 0, 1, d_tmp + 2, d_tmp) : PHD_OK;
+	if (e == hipSuccess) e = hipStreamSynchronize(nav->stream);
 	int info[2] = {0, 0};
 	if (e == hipSuccess) e = hipMemcpy(info, d_tmp, 8, hipMemcpyDeviceToHost);
-	hipFree(d_tmp);
+	hipFree(d_tmp); hipFree(d_w);
+	if (rc) return rc;
 	if (e != hipSuccess) return nav->fail(PHD_ERR_DEVICE, hipGetErrorString(e));
 	*depleted = info[1] ? 1 : 0;
 	return PHD_OK;
@@ -1351,7 +1429,10 @@ void* phd_stream(phd_navigator* nav) { return (nav && !nav->multi) ? (void*) nav
 int phd_timing_reset(phd_navigator* nav, uint8_t enabled)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
-	if (nav->multi) nav = multi_shard0(nav);   // the kernels of the first shard are the ones timed
+	if (nav->multi) {   // the kernels of the first shard are the ones timed; the phases of its steps too (phd_multi_report)
+		multi_timing_reset(nav, enabled);
+		nav = multi_shard0(nav);
+	}
 	hipSetDevice(nav->device);
 	hipStreamSynchronize(nav->stream);
 	nav->ntimers = 0;
@@ -1399,64 +1480,126 @@ int phd_last_timing_counts(phd_navigator* nav, const int** counts)
 
 // ---- multi-GPU ----------------------------------------------------------------------------------
 // Particles are sharded contiguously: rank r owns global slots [r * P, (r + 1) * P). One step is
-//   phd_step_local_async                      predict / correct / prune / reweight of the shard
+//   phd_step_local_async                      predict / correct / prune / reweight of the shard; the weights are exported
 //   <all-gather of phd_device_local_weights into phd_device_global_weights, RCCL, by the host>
-//   phd_step_global_async                     normalise + BestParticle + depletion test + systematic
-//                                             resampling over ALL particles, identical on every rank
-//   phd_migration_plan                        (host) who sends which particle to whom
+//   phd_step_global_async                     normalise + BestParticle + depletion test + systematic resampling over ALL
+//                                             particles, identical on every rank; then the migration plan, ON THE DEVICE
+//   phd_migration_plan                        the host learns the 2 n split sizes of the exchange (nothing else crosses)
 //   phd_migration_pack_async, <all-to-all of the send/recv buffers>, phd_migration_unpack_async
+// A phd_create_multi handle plays the same kernels from one worker thread per shard, with peer stores in place of the
+// collectives and no host wait anywhere (phd_multi.inc).
+
+// Buffers of the sharded step, made once (their addresses go into other shards' tables): export buffer, plan arrays, pinned
+// counts, send / receive buffers. With non-decreasing sources a rank receives at most one record per slot and sends at
+// most Pcap + world - 1 (a source particle goes to every rank its run of slots meets; runs of successive sources share at
+// most one rank).
+static int ensure_sharded(phd_navigator* nav, bool need_send = true)
+{
+	if (nav->plan.code) return PHD_OK;
+	hipSetDevice(nav->device);
+	const size_t rec = (size_t) 8 + (size_t) 10 * nav->cap;
+	nav->plan.sendcap = nav->Pcap + PHD_MAX_DEVICES;
+	nav->recvrecs = nav->Pcap;
+	nav->sendrecs = nav->plan.sendcap;
+	HC(hipMalloc((void**) &nav->d_lw, (size_t) (nav->Pcap + 1) * 8));
+	HC(hipMalloc((void**) &nav->d_dst_tab, PHD_MAX_DEVICES * sizeof(double*)));
+	HC(hipMemcpy(nav->d_dst_tab, &nav->d_lw, sizeof(double*), hipMemcpyHostToDevice));
+	HC(hipMalloc((void**) &nav->plan.code, (size_t) nav->Pcap * 4));
+	HC(hipMalloc((void**) &nav->plan.fslot, (size_t) nav->Pcap * 4));
+	HC(hipMalloc((void**) &nav->plan.sendlist, (size_t) nav->plan.sendcap * 4));
+	HC(hipMalloc((void**) &nav->plan.senddst, (size_t) nav->plan.sendcap * 8));
+	HC(hipMalloc((void**) &nav->plan.counts, (2 * PHD_MAX_DEVICES + 8) * 4));
+	HC(hipMemset(nav->plan.counts, 0, (2 * PHD_MAX_DEVICES + 8) * 4));
+	HC(hipHostMalloc((void**) &nav->h_counts, (2 * PHD_MAX_DEVICES + 8) * 4, hipHostMallocMapped));
+	std::memset(nav->h_counts, 0, (2 * PHD_MAX_DEVICES + 8) * 4);
+	HC(hipMalloc((void**) &nav->d_mslot, (size_t) nav->Pcap * 4));
+	if (need_send) HC(hipMalloc((void**) &nav->d_send, (size_t) nav->sendrecs * rec * 8));   // (a shard of a multi-device handle packs straight into its peers' receive buffers)
+	HC(hipMalloc((void**) &nav->d_recv, (size_t) nav->recvrecs * rec * 8));
+	return PHD_OK;
+}
+
+// the local part of a sharded step: the per-particle kernels, then the un-normalised weights stored where the exchange
+// reads them (the host's all-gather buffer, or every shard's gathered vector)
+static int step_local(phd_navigator* nav, uint8_t onlymapping)
+{
+	if (nav->P < 1) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step_local: no particles");
+	hipSetDevice(nav->device);
+	int rc = ensure_sharded(nav);
+	if (rc) return rc;
+	nav->sharded_used = true;
+	nav->timing_now = (nav->timing_step++ % nav->timing_period) == 0;
+	StepBufs b = make_bufs(nav);
+	rc = launch_map(nav, b, !onlymapping);
+	if (rc) return rc;
+	timer_begin(nav, T_PW);
+	hipLaunchKernelGGL(k_push_weights, dim3((nav->P + 255) / 256), dim3(256), 0, nav->stream, b, (double* const*) nav->d_dst_tab, nav->ndst,
+	                   nav->push_first, nav->push_flagslot);
+	timer_end(nav, T_PW);
+	HC(hipGetLastError());
+	return PHD_OK;
+}
+
 int phd_step_local_async(phd_navigator* nav, uint8_t onlymapping)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	MULTI_UNSUPPORTED(nav, "phd_step_local_async");
-	if (nav->P < 1) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step_local: no particles");
-	hipSetDevice(nav->device);
-	nav->timing_now = (nav->timing_step++ % nav->timing_period) == 0;
-	StepBufs b = make_bufs(nav);
-	return launch_map(nav, b, !onlymapping);
+	return step_local(nav, onlymapping);
 }
 
 void* phd_device_local_weights(phd_navigator* nav)
 {
-	if (!nav) return nullptr;
-	hipSetDevice(nav->device);
-	// un-normalised weights written by the local step live in the OUT bank of the current roles; the host
-	// mirror of the roles is kept current by phd_migration_unpack_async, so this needs no round trip there
-	if (!nav->sel_host_valid && sync_state(nav)) return nullptr;
-	return nav->bank[nav->h_sel[SEL_OUT]].weights;
+	if (!nav || nav->multi) return nullptr;
+	if (ensure_sharded(nav)) return nullptr;
+	return nav->d_lw;   // filled by phd_step_local_async, on the handle's stream
 }
 
 void* phd_device_global_weights(phd_navigator* nav, int world_particles)
 {
-	if (!nav || world_particles < 1) return nullptr;
+	if (!nav || nav->multi || world_particles < 1) return nullptr;
 	hipSetDevice(nav->device);
 	if (ensure_gw(nav, world_particles)) return nullptr;
 	return nav->d_gw;
 }
 
-static int plan_begin(phd_navigator* nav, int world_size);
+// the global part: the resampling kernel on the gathered vector, this rank's weights back into its bank, the plan.
+// onlymapping: OnlyMapping keeps the weights and never resamples (PHDNavigator.cs:330-336) — the same kernel with the
+// weights taken as they are and resampling off. hostcounts: the plan also writes its counts to pinned host memory.
+static int step_global(phd_navigator* nav, int rank, int world_size, double u, uint8_t onlymapping, bool hostcounts)
+{
+	hipSetDevice(nav->device);
+	const int Pg = nav->P * world_size;
+	nav->last_world_particles = Pg;
+	nav->world = world_size; nav->rank = rank;
+	int rc = ensure_sharded(nav);
+	if (!rc) rc = ensure_gw(nav, Pg);
+	if (rc) return rc;
+	StepBufs b = make_bufs(nav);
+	timer_begin(nav, T_NR);
+	rc = launch_normalise(nav, b, nav->d_gw, Pg, u, onlymapping ? -1 : 0, onlymapping ? 1 : 0, nav->d_plan, nav->d_info);
+	timer_end(nav, T_NR);
+	if (rc) return rc;
+	hipLaunchKernelGGL(k_scatter_weights, dim3((nav->P + 255) / 256), dim3(256), 0, nav->stream, b, nav->d_gw, rank * nav->P);
+	const size_t lds = ((size_t) world_size * world_size + 2 * world_size + 24 + (nav->P + 31) / 32) * 4;
+	int* hc = nullptr;
+	if (hostcounts) {
+		HC(hipHostGetDevicePointer((void**) &hc, nav->h_counts, 0));
+		nav->plan_seq++;
+		nav->plan_waiting = true;
+	}
+	timer_begin(nav, T_PL);
+	hipLaunchKernelGGL(k_plan_migration, dim3(1), dim3(1024), lds, nav->stream, (const int*) nav->d_plan, (const int*) nav->d_info, (const int*) nav->d_flags,
+	                   nav->d_gflags, nav->P, world_size, rank, nav->plan, hc, nav->plan_seq);
+	timer_end(nav, T_PL);
+	HC(hipGetLastError());
+	return PHD_OK;
+}
 
 int phd_step_global_async(phd_navigator* nav, int rank, int world_size, double u_resample)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	MULTI_UNSUPPORTED(nav, "phd_step_global_async");
-	if (world_size < 1 || rank < 0 || rank >= world_size) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step_global: bad rank/world");
-	hipSetDevice(nav->device);
-	const int Pg = nav->P * world_size;
-	nav->last_world_particles = Pg;
-	int rc = ensure_gw(nav, Pg);
-	if (rc) return rc;
-	StepBufs b = make_bufs(nav);
-	timer_begin(nav, T_NR);
-	rc = launch_normalise(nav, b, nav->d_gw, Pg, u_resample, 0, 0, nav->d_plan, nav->d_info);
-	timer_end(nav, T_NR);
-	if (rc) return rc;
-	hipLaunchKernelGGL(k_scatter_weights, dim3((nav->P + 255) / 256), dim3(256), 0, nav->stream, b, nav->d_gw, rank * nav->P);
-	HC(hipGetLastError());
-	// what phd_migration_plan will read on the host follows the kernel down the stream at once (not when the host gets
-	// round to asking for it: the device idles while the host plans)
-	nav->plan_pending = 0;
-	return plan_begin(nav, world_size);
+	if (world_size < 1 || world_size > PHD_MAX_DEVICES || rank < 0 || rank >= world_size) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step_global: bad rank/world (at most 64 ranks)");
+	return step_global(nav, rank, world_size, u_resample, 0, true);
 }
 
 // Pure host logic (no handle, no device): from the global source vector of a resampling step, which of
@@ -1513,117 +1656,139 @@ int phd_plan_migration(const int32_t* gsrc, int Pl, int world_size, int rank, in
 	return slot;
 }
 
-// First half of phd_migration_plan: enqueue the copies of the resampling flag, the global source vector and the status
-// flags into pinned memory. A host that drives several devices (phd_create_multi) starts them on every device before it
-// waits for the first.
-static int plan_begin(phd_navigator* nav, int world_size)
+// Test surface of the device plan: k_plan_migration on a caller-supplied global source vector (the host statement above is
+// its reference in the tests). Arrays as phd_plan_migration's, plus fslot[<= Pl] (the OUT-bank slots of the arriving
+// records) and send_dst[<= Pl + 64][2] (destination rank, record number in its receive buffer). *status <- MIG_*;
+// returns PHD_OK when the kernel ran.
+int phd_test_migration_plan(phd_navigator* nav, const int32_t* gsrc, int particles_per_rank, int world_size, int rank, int resampled,
+                            int32_t* send_counts, int32_t* recv_counts, int32_t* send_list, int32_t* dst_code, int32_t* fslot,
+                            int32_t* send_dst, int32_t* nsend, int32_t* nrecv, int32_t* status)
 {
-	hipSetDevice(nav->device);
-	const int Pg = nav->P * world_size;
-	if (nav->h_pin_cap < Pg + 3) {
-		if (nav->h_pin) hipHostFree(nav->h_pin);
-		nav->h_pin = nullptr;
-		HC(hipHostMalloc((void**) &nav->h_pin, (size_t) (Pg + 3) * 4, hipHostMallocDefault));
-		nav->h_pin_cap = Pg + 3;
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	if (nav->multi) nav = multi_shard0(nav);
+	const int Pl = particles_per_rank, n = world_size;
+	if (!gsrc || Pl < 1 || Pl > nav->Pcap || n < 1 || n > PHD_MAX_DEVICES || rank < 0 || rank >= n || !send_counts || !recv_counts || !send_list || !dst_code ||
+	    !fslot || !send_dst || !nsend || !nrecv || !status) {
+		return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_test_migration_plan: sizes out of range (particles_per_rank <= max_particles, world_size <= 64)");
 	}
-	// one round trip: the resampling flag, the global source vector and the status flags land in pinned memory together
-	HC(hipMemcpyAsync(nav->h_pin, nav->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, nav->stream));
-	HC(hipMemcpyAsync(nav->h_pin + 2, nav->d_plan, (size_t) Pg * 4, hipMemcpyDeviceToHost, nav->stream));
-	HC(hipMemcpyAsync(nav->h_pin + 2 + Pg, nav->d_flags, sizeof(int), hipMemcpyDeviceToHost, nav->stream));
-	nav->plan_pending = world_size;
+	hipSetDevice(nav->device);
+	int rc = ensure_sharded(nav);
+	if (rc) return rc;
+	HC(hipStreamSynchronize(nav->stream));
+	int* d_g = nullptr;
+	HC(hipMalloc((void**) &d_g, ((size_t) Pl * n + 4) * 4));
+	int* d_i = d_g + (size_t) Pl * n;   // info[2], a clear status word
+	const int info[3] = {0, resampled ? 1 : 0, 0};
+	hipError_t e = hipMemcpy(d_g, gsrc, (size_t) Pl * n * 4, hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(d_i, info, 12, hipMemcpyHostToDevice);
+	const size_t lds = ((size_t) n * n + 2 * n + 24 + (Pl + 31) / 32) * 4;
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(k_plan_migration, dim3(1), dim3(1024), lds, nav->stream, (const int*) d_g, (const int*) d_i, (const int*) (d_i + 2), (const double*) nullptr,
+		                   Pl, n, rank, nav->plan, (int*) nullptr, 0);
+		e = hipStreamSynchronize(nav->stream);
+	}
+	std::vector<int> c(2 * n + 4);
+	if (e == hipSuccess) e = hipMemcpy(c.data(), nav->plan.counts, c.size() * 4, hipMemcpyDeviceToHost);
+	hipFree(d_g);
+	if (e != hipSuccess) return nav->fail(PHD_ERR_DEVICE, std::string("phd_test_migration_plan: ") + hipGetErrorString(e));
+	for (int r = 0; r < n; r++) { send_counts[r] = c[r]; recv_counts[r] = c[n + r]; }
+	*nsend = c[2 * n]; *nrecv = c[2 * n + 1]; *status = c[2 * n + 2];
+	if (*status == MIG_OK && resampled) {
+		std::vector<long long> sd((size_t) std::max(*nsend, 1));
+		HC(hipMemcpy(dst_code, nav->plan.code, (size_t) Pl * 4, hipMemcpyDeviceToHost));
+		if (*nrecv > 0) HC(hipMemcpy(fslot, nav->plan.fslot, (size_t) *nrecv * 4, hipMemcpyDeviceToHost));
+		if (*nsend > 0) {
+			HC(hipMemcpy(send_list, nav->plan.sendlist, (size_t) *nsend * 4, hipMemcpyDeviceToHost));
+			HC(hipMemcpy(sd.data(), nav->plan.senddst, (size_t) *nsend * 8, hipMemcpyDeviceToHost));
+			for (int k = 0; k < *nsend; k++) { send_dst[2 * k] = (int32_t) (sd[k] >> 32); send_dst[2 * k + 1] = (int32_t) (sd[k] & 0xffffffffll); }
+		}
+	}
 	return PHD_OK;
 }
 
+// The split sizes of the exchange. The plan itself was made on the device behind the resampling kernel
+// (k_plan_migration); its counts arrive in pinned host memory, and the host waits for the word written behind them — no
+// stream synchronisation, no copy command, and nothing of the size of the particle set crosses.
 int phd_migration_plan(phd_navigator* nav, int rank, int world_size, int32_t* send_counts, int32_t* recv_counts)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	MULTI_UNSUPPORTED(nav, "phd_migration_plan");
 	if (world_size < 1 || rank < 0 || rank >= world_size || !send_counts || !recv_counts) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_plan: bad arguments");
+	if (!nav->plan_waiting || world_size != nav->world || rank != nav->rank) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_plan: call phd_step_global_async(rank, world_size) first");
 	hipSetDevice(nav->device);
-	int rc = PHD_OK;
-	if (!nav->sel_host_valid) rc = sync_state(nav);
-	if (rc) return rc;
-	const int Pl = nav->P, Pg = Pl * world_size, first = rank * Pl;
-	if (nav->plan_pending != world_size) rc = plan_begin(nav, world_size);
-	nav->plan_pending = 0;
-	if (rc) return rc;
-	HC(hipStreamSynchronize(nav->stream));
-	if (nav->h_pin[2 + Pg]) {
+	const int n = world_size;
+	volatile int* hc = nav->h_counts;
+	const auto t0 = std::chrono::steady_clock::now();
+	for (long spins = 0; hc[2 * n + 6] != nav->plan_seq; spins++) {
+		__builtin_ia32_pause();
+		if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+			// (a device that never gets there: report what the stream says rather than spin for ever)
+			HC(hipStreamSynchronize(nav->stream));
+			if (hc[2 * n + 6] != nav->plan_seq) return nav->fail(PHD_ERR_DEVICE, "phd_migration_plan: the plan kernel did not report");
+		}
+	}
+	__atomic_thread_fence(__ATOMIC_ACQUIRE);
+	nav->plan_waiting = false;
+	const int status = hc[2 * n + 2];
+	for (int r = 0; r < n; r++) { send_counts[r] = hc[r]; recv_counts[r] = hc[n + r]; }
+	nav->nsend = hc[2 * n]; nav->nrecv = hc[2 * n + 1];
+	if (status == MIG_DROPPED) {
 		// a kernel of the local step raised a flag: the step is dropped before anything rotates (the caller must not go on to
-		// pack / unpack; the state is the one before phd_step_local_async)
-		nav->h_flags = nav->h_pin[2 + Pg];
+		// pack / unpack — if it does, those kernels find the same status and leave the state alone; the state is the one
+		// before phd_step_local_async)
+		nav->h_flags = hc[2 * n + 5];
 		hipMemsetAsync(nav->d_flags, 0, 4, nav->stream);
 		return check_flags(nav);
 	}
-	nav->h_info[0] = nav->h_pin[0]; nav->h_info[1] = nav->h_pin[1];
-	for (int r = 0; r < world_size; r++) send_counts[r] = recv_counts[r] = 0;
-	nav->nsend = nav->nrecv = 0;
-	nav->h_plan_send.clear();
-	nav->h_plan_recv.assign(Pl, 0);
-	std::vector<int> gsrc(nav->h_pin + 2, nav->h_pin + 2 + Pg);
-	nav->h_src.assign(gsrc.begin() + first, gsrc.begin() + first + Pl);   // global source of each local slot
-	if (!nav->h_info[1]) {
-		for (int i = 0; i < Pl; i++) nav->h_plan_recv[i] = i;
-		return PHD_OK;
-	}
-	std::vector<int> code(Pl), sendlist(Pl * (size_t) std::max(world_size - 1, 1));
-	int slot = phd_plan_migration(gsrc.data(), Pl, world_size, rank, send_counts, recv_counts, sendlist.data(), code.data());
-	int ns = 0;
-	for (int r = 0; r < world_size; r++) ns += send_counts[r];
-	nav->h_plan_send.assign(sendlist.begin(), sendlist.begin() + ns);
-	nav->h_plan_recv = code;
-	nav->nsend = (int) nav->h_plan_send.size();
-	nav->nrecv = slot;
-	// an arriving particle is unpacked into a slot of the OUT bank that no local particle keeps as its source
-	{
-		std::vector<char> used(Pl, 0);
-		for (int i = 0; i < Pl; i++) if (code[i] >= 0) used[code[i]] = 1;
-		nav->h_fslot.assign(std::max(slot, 1), 0);
-		int f = 0;
-		for (int j = 0; j < slot; j++) {
-			while (f < Pl && used[f]) f++;
-			if (f >= Pl) return nav->fail(PHD_ERR_GENERIC, "phd_migration_plan: no free slot for an arriving particle");
-			nav->h_fslot[j] = f++;
-		}
-	}
-	size_t rec = (size_t) 8 + (size_t) 10 * nav->cap;
-	int need = std::max(nav->nsend, nav->nrecv);
-	if (need > nav->migcap) {
-		hipFree(nav->d_send); hipFree(nav->d_recv);
-		nav->d_send = nav->d_recv = nullptr;
-		HC(hipMalloc((void**) &nav->d_send, (size_t) need * rec * 8));
-		HC(hipMalloc((void**) &nav->d_recv, (size_t) need * rec * 8));
-		nav->migcap = need;
-	}
+	if (status == MIG_BAD) return nav->fail(PHD_ERR_GENERIC, "phd_migration_plan: the gathered source vector is not a resampling result (were the weights of all ranks gathered?)");
+	if (status == MIG_OVERFLOW) return nav->fail(PHD_ERR_CAPACITY, "phd_migration_plan: more migrating particles than the send list holds");
+	nav->h_info[0] = hc[2 * n + 4]; nav->h_info[1] = hc[2 * n + 3];
 	return PHD_OK;
 }
 
 void* phd_migration_send_buffer(phd_navigator* nav, int64_t* bytes_per_particle)
 {
-	if (!nav) return nullptr;
+	if (!nav || nav->multi) return nullptr;
 	if (bytes_per_particle) *bytes_per_particle = (int64_t) ((size_t) 8 + (size_t) 10 * nav->cap) * 8;
 	return nav->d_send;
 }
 
-void* phd_migration_recv_buffer(phd_navigator* nav) { return nav ? nav->d_recv : nullptr; }
+void* phd_migration_recv_buffer(phd_navigator* nav) { return (nav && !nav->multi) ? nav->d_recv : nullptr; }
+
+// grid of k_pack_particles / its like: the records are counted on the device, a fixed grid strides over them
+static int pack_grid(const phd_navigator* nav) { return std::min(nav->plan.sendcap, 1024); }
 
 int phd_migration_pack_async(phd_navigator* nav)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	MULTI_UNSUPPORTED(nav, "phd_migration_pack_async");
 	hipSetDevice(nav->device);
-	if (nav->nsend == 0) return PHD_OK;
-	if (nav->nsend > nav->sendlistcap) {
-		HC(hipStreamSynchronize(nav->stream));
-		hipFree(nav->d_sendlist);
-		nav->d_sendlist = nullptr;
-		HC(hipMalloc((void**) &nav->d_sendlist, (size_t) nav->nsend * 4));
-		nav->sendlistcap = nav->nsend;
-	}
-	HC(hipMemcpyAsync(nav->d_sendlist, nav->h_plan_send.data(), (size_t) nav->nsend * 4, hipMemcpyHostToDevice, nav->stream));
+	if (!nav->plan.code) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_pack_async: no plan (phd_step_global_async, phd_migration_plan first)");
+	if (nav->nsend == 0) return PHD_OK;   // (the per-rank host knows the counts)
 	StepBufs b = make_bufs(nav);
-	hipLaunchKernelGGL(k_pack_particles, dim3(nav->nsend), dim3(256), 0, nav->stream, b, nav->d_sendlist, nav->d_send);
+	timer_begin(nav, T_PK);
+	hipLaunchKernelGGL(k_pack_particles, dim3(std::min(nav->nsend, pack_grid(nav))), dim3(256), 0, nav->stream, b, nav->plan, nav->world, nav->d_send,
+	                   (double* const*) nullptr);
+	timer_end(nav, T_PK);
 	HC(hipGetLastError());
+	return PHD_OK;
+}
+
+// the end of a sharded step: arrivals unpacked, small arrays gathered, roles rotated — all read from the device plan
+static int step_finish(phd_navigator* nav)
+{
+	hipSetDevice(nav->device);
+	StepBufs b = make_bufs(nav);
+	int* sel_next = nav->d_sel + (nav->parity ^ 1) * SEL_STRIDE;
+	nav->d_res_slots = nav->d_mslot;
+	timer_begin(nav, T_GR);
+	hipLaunchKernelGGL(k_finish_sharded, dim3(nav->P), dim3(256), 0, nav->stream, b, nav->plan, nav->world, (const double*) nav->d_recv,
+	                   1.0 / (double) nav->last_world_particles, sel_next, nav->frozen ? 1 : 0, nav->d_inslot, nav->d_mslot);
+	timer_end(nav, T_GR);
+	HC(hipGetLastError());
+	nav->parity ^= 1;
+	nav->stage_valid = false;
+	nav->sel_host_valid = false;   // the rotation depends on the plan's status and the resampling flag, known on the device
 	return PHD_OK;
 }
 
@@ -1631,43 +1796,8 @@ int phd_migration_unpack_async(phd_navigator* nav)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	MULTI_UNSUPPORTED(nav, "phd_migration_unpack_async");
-	hipSetDevice(nav->device);
-	StepBufs b = make_bufs(nav);
-	int* sel_next = nav->d_sel + (nav->parity ^ 1) * SEL_STRIDE;
-	if (!nav->h_info[1]) {
-		// no resampling: only rotate the bank roles
-		timer_begin(nav, T_GR);
-		hipLaunchKernelGGL(k_gather_rotate, dim3((nav->P + 255) / 256), dim3(256), 0, nav->stream, b, nav->d_src, nav->d_info, 0, sel_next,
-		                   nav->frozen ? 1 : 0, nav->d_inslot);
-		timer_end(nav, T_GR);
-		HC(hipGetLastError());
-	}
-	else {
-		if (!nav->d_code) HC(hipMalloc((void**) &nav->d_code, (size_t) nav->Pcap * 4));
-		if (!nav->d_fslot) HC(hipMalloc((void**) &nav->d_fslot, (size_t) nav->Pcap * 4));
-		if (!nav->d_mslot) HC(hipMalloc((void**) &nav->d_mslot, (size_t) nav->Pcap * 4));
-		HC(hipMemcpyAsync(nav->d_code, nav->h_plan_recv.data(), (size_t) nav->P * 4, hipMemcpyHostToDevice, nav->stream));
-		if (nav->nrecv > 0) HC(hipMemcpyAsync(nav->d_fslot, nav->h_fslot.data(), (size_t) nav->nrecv * 4, hipMemcpyHostToDevice, nav->stream));
-		nav->d_res_slots = nav->d_mslot;
-		timer_begin(nav, T_GR);
-		hipLaunchKernelGGL(k_unpack_gather, dim3(std::max(nav->P, nav->nrecv)), dim3(256), 0, nav->stream, b, nav->d_code, nav->d_recv, nav->nrecv,
-		                   nav->d_fslot, 1.0 / (double) nav->last_world_particles, sel_next, nav->frozen ? 1 : 0, nav->d_inslot, nav->d_mslot);
-		timer_end(nav, T_GR);
-		HC(hipGetLastError());
-	}
-	nav->local_gather_done = false;
-	nav->parity ^= 1;
-	nav->stage_valid = false;
-	if (nav->sel_host_valid && !nav->frozen) {   // same rotation as the kernels wrote to the device
-		int I = nav->h_sel[SEL_IN], O = nav->h_sel[SEL_OUT], T = nav->h_sel[SEL_TMP];
-		if (nav->h_info[1]) { nav->h_sel[SEL_IN] = T; nav->h_sel[SEL_OUT] = I; nav->h_sel[SEL_TMP] = O; nav->h_sel[SEL_RES] = T; nav->h_sel[SEL_INMIX] = O; nav->h_sel[SEL_RESMIX] = O; }
-		else                { nav->h_sel[SEL_IN] = O; nav->h_sel[SEL_OUT] = I; nav->h_sel[SEL_TMP] = T; nav->h_sel[SEL_RES] = O; nav->h_sel[SEL_INMIX] = O; nav->h_sel[SEL_RESMIX] = O; }
-	}
-	else if (nav->sel_host_valid) {
-		nav->h_sel[SEL_RES] = nav->h_info[1] ? nav->h_sel[SEL_TMP] : nav->h_sel[SEL_OUT];
-		nav->h_sel[SEL_RESMIX] = nav->h_sel[SEL_OUT];
-	}
-	return PHD_OK;
+	if (!nav->plan.code) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_unpack_async: no plan (phd_step_global_async first)");
+	return step_finish(nav);
 }
 
 // Lend the handle a stream of the host (e.g. the framework's current stream) so that the library's kernels and

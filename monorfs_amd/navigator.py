@@ -327,6 +327,10 @@ class PHDNavigator:
     def set_frozen(self, frozen):
         self._check(self._lib.phd_set_frozen(self._h, int(bool(frozen))))
 
+    def set_all_pairs(self, on):
+        """SURVEY 8d's benchmark mode: every (component, measurement) pair evaluated, the gate only masks (phd_set_all_pairs)"""
+        self._check(self._lib.phd_set_all_pairs(self._h, int(bool(on))))
+
     def set_split(self, nsplit):
         """Launch a step's per-particle kernels as `nsplit` sub-ranges on concurrent streams (phd_set_split)."""
         self._check(self._lib.phd_set_split(self._h, int(nsplit)))
@@ -340,6 +344,32 @@ class PHDNavigator:
         ms = dp()
         n = self._lib.phd_last_timings(self._h, C.byref(names), C.byref(ms))
         return {names[i].decode(): ms[i] for i in range(n)}
+
+    def multi_report(self):
+        """diagnostics of a multi-device handle (phd_multi_report): per-phase device time of the sampled steps on the first
+        shard's stream, the host's cost of posting / issuing a step, and which shard pairs exchange by direct peer access"""
+        out = np.zeros(8)
+        p2p = np.zeros(64 * 64, np.uint8)
+        n = C.c_int32(0)
+        self._check(self._lib.phd_multi_report(self._h, _ptr(out), p2p.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(n)))
+        k = n.value
+        names = ("local", "gather_wait", "global_and_plan", "pack", "exchange_wait_and_unpack")
+        return {"phase_ms": {nm: float(out[i]) for i, nm in enumerate(names)}, "post_us": float(out[5]), "issue_us": float(out[6]),
+                "sampled_steps": int(out[7]), "shards": k, "p2p": p2p[:k * k].reshape(k, k).astype(bool).tolist()}
+
+    def test_migration_plan(self, gsrc, particles_per_rank, world, rank, resampled=True):
+        """the migration plan as the device makes it inside a sharded step (phd_test_migration_plan): dict of the lists"""
+        g = np.ascontiguousarray(gsrc, np.int32)
+        Pl, n = int(particles_per_rank), int(world)
+        sc, rc = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        sl, code, fs = np.zeros(Pl + 64, np.int32), np.zeros(Pl, np.int32), np.zeros(Pl, np.int32)
+        sd = np.zeros((Pl + 64, 2), np.int32)
+        ns, nr, st = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        q = lambda a: a.ctypes.data_as(ip)
+        self._check(self._lib.phd_test_migration_plan(self._h, q(g), Pl, n, int(rank), int(bool(resampled)), q(sc), q(rc), q(sl), q(code), q(fs), q(sd),
+                                                      C.byref(ns), C.byref(nr), C.byref(st)))
+        return {"send_counts": sc, "recv_counts": rc, "send_list": sl[:ns.value].copy(), "dst_code": code, "fslot": fs[:nr.value].copy(),
+                "send_dst": sd[:ns.value].copy(), "nsend": ns.value, "nrecv": nr.value, "status": st.value}
 
     def last_timing_counts(self):
         """launches behind each mean of the last last_timings() call (a split step launches each kernel per sub-range)"""

@@ -14,6 +14,8 @@ CONFIGS = {   # BASELINE.json configs: particles, components, measurements, seed
     "S": (4096, 1024, 128, 1004),
     # tuning shapes (where the one-launch chain stops paying: phdhip.hip chain_max), not BASELINE configs
     "A512": (512, 128, 32, 1001), "A1024": (1024, 128, 32, 1001), "B512": (512, 512, 64, 1002), "B1024": (1024, 512, 64, 1002),
+    # rehearsal shapes of the multi-shard hosts: what 8 shards of A / B512 hold, as ONE handle
+    "A2048": (2048, 128, 32, 1001), "B4096": (4096, 512, 64, 1002),
 }
 
 
