@@ -271,6 +271,11 @@ def main():
         scounts = np.zeros(world, np.int32)
         rcounts = np.zeros(world, np.int32)
         ip = C.POINTER(C.c_int32)
+        lw_ptr = lib.phd_device_local_weights(h)          # fixed addresses: the export buffer and the migration buffers
+        bpp = C.c_int64(0)
+        mig_send = lib.phd_migration_send_buffer(h, C.byref(bpp))
+        mig_recv = lib.phd_migration_recv_buffer(h)
+        mig_rec = bpp.value // 8
 
     cache = {}
 
@@ -288,18 +293,16 @@ def main():
             nav.step_async(u)
             return
         nav._check(lib.phd_step_local_async(h, 0))
-        dist.all_gather_into_tensor(gw, dev_tensor(lib.phd_device_local_weights(h), P))
+        dist.all_gather_into_tensor(gw, dev_tensor(lw_ptr, P))
         nav._check(lib.phd_step_global_async(h, rank, world, u))
+        # the plan was made on the device; the host only waits for its 2 n split sizes (pinned memory, no stream sync)
         nav._check(lib.phd_migration_plan(h, rank, world, scounts.ctypes.data_as(ip), rcounts.ctypes.data_as(ip)))
-        nav._check(lib.phd_migration_pack_async(h))
-        bpp = C.c_int64(0)
-        sptr = lib.phd_migration_send_buffer(h, C.byref(bpp))
-        rptr = lib.phd_migration_recv_buffer(h)
-        rec = bpp.value // 8
-        ns, nr = int(scounts.sum()), int(rcounts.sum())
-        send = dev_tensor(sptr, ns * rec) if ns else empty
-        recv = dev_tensor(rptr, nr * rec) if nr else empty
-        dist.all_to_all_single(recv, send, (rcounts * rec).tolist(), (scounts * rec).tolist())
+        if lib.phd_last_resampled(h) != 0:   # (every rank knows the same flag: no resampling, no exchange)
+            nav._check(lib.phd_migration_pack_async(h))
+            ns, nr = int(scounts.sum()), int(rcounts.sum())
+            send = dev_tensor(mig_send, ns * mig_rec) if ns else empty
+            recv = dev_tensor(mig_recv, nr * mig_rec) if nr else empty
+            dist.all_to_all_single(recv, send, (rcounts * mig_rec).tolist(), (scounts * mig_rec).tolist())
         nav._check(lib.phd_migration_unpack_async(h))
 
     def barrier():

@@ -261,6 +261,9 @@ int   phd_plan_migration(const int32_t* gsrc, int particles_per_rank, int world_
 int   phd_test_migration_plan(phd_navigator* nav, const int32_t* gsrc, int particles_per_rank, int world_size, int rank, int resampled,
                               int32_t* send_counts, int32_t* recv_counts, int32_t* send_list, int32_t* dst_code, int32_t* fslot,
                               int32_t* send_dst, int32_t* nsend, int32_t* nrecv, int32_t* status);
+/* 1 / 0: the last global step did / did not resample, as phd_migration_plan learnt it (the same on every rank: when it did
+ * not, all ranks may skip pack and the all-to-all together; phd_migration_unpack_async still ends the step); -1: not known. */
+int   phd_last_resampled(phd_navigator* nav);
 void* phd_migration_send_buffer(phd_navigator* nav, int64_t* bytes_per_particle);
 void* phd_migration_recv_buffer(phd_navigator* nav);
 int   phd_migration_pack_async(phd_navigator* nav);

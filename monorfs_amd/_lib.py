@@ -105,6 +105,7 @@ def load():
         "phd_plan_migration": (C.c_int, [ip, C.c_int, C.c_int, C.c_int, ip, ip, ip, ip]),
         "phd_test_migration_plan": (C.c_int, [P, ip, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, ip, ip, ip, ip, ip, ip, ip]),
         "phd_multi_report": (C.c_int, [P, dp, u8p, ip]),
+        "phd_last_resampled": (C.c_int, [P]),
         "phd_migration_send_buffer": (C.c_void_p, [P, C.POINTER(C.c_int64)]),
         "phd_migration_recv_buffer": (C.c_void_p, [P]),
         "phd_migration_pack_async": (C.c_int, [P]),
@@ -127,6 +128,6 @@ EXPORTS = ["phd_api_version", "phd_default_params", "phd_create", "phd_create_mu
            "phd_particle_count", "phd_map", "phd_resample_sources", "phd_stage_run", "phd_stage_map", "phd_stage_alpha",
            "phd_stage_setloglik", "phd_resample", "phd_particle_depleted", "phd_step_local_async",
            "phd_device_local_weights", "phd_device_global_weights", "phd_step_global_async", "phd_migration_plan",
-           "phd_plan_migration", "phd_test_migration_plan", "phd_multi_report", "phd_migration_send_buffer", "phd_migration_recv_buffer", "phd_migration_pack_async",
+           "phd_plan_migration", "phd_test_migration_plan", "phd_multi_report", "phd_last_resampled", "phd_migration_send_buffer", "phd_migration_recv_buffer", "phd_migration_pack_async",
            "phd_migration_unpack_async", "phd_stream", "phd_set_stream", "phd_timing_reset", "phd_last_timings", "phd_last_timing_counts", "phd_upload_state_soa",
            "phd_download_state_soa"]

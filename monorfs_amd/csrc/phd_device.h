@@ -443,6 +443,16 @@ __device__ __forceinline__ double uniform_d(double v)
 	return __hiloint2double(hi, lo);
 }
 
+// s / d for 0 <= s < 2^24 and 1 <= d without the integer-division sequence (rd = 1.0f / d): a float quotient is off by at
+// most one
+__device__ __forceinline__ int small_div(int s, int d, float rd)
+{
+	int q = (int) ((float) s * rd);
+	q -= (q * d > s) ? 1 : 0;
+	q += ((q + 1) * d <= s) ? 1 : 0;
+	return q;
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll

@@ -349,12 +349,6 @@ __global__ __launch_bounds__(256) void k_push_weights(const StepBufs a, double* 
 	}
 }
 
-__global__ __launch_bounds__(256) void k_scatter_weights(const StepBufs a, const double* gw, int first)
-{
-	int i = blockIdx.x * 256 + threadIdx.x;
-	if (i < a.P) bank_of(a, SEL_OUT).weights[i] = gw[first + i];
-}
-
 // The migration plan of one rank, device-resident. counts: [0, n) records sent to rank t, [n, 2n) records received from
 // rank s, then nsend, nrecv, status, resampled.
 #define MIG_OK        0
@@ -370,7 +364,7 @@ struct MigPlan {
 	int  sendcap;
 };
 
-// exclusive prefix sum of one int per thread over the 1024 threads of the workgroup (wsum: 17 ints of LDS); *total <- the sum
+// exclusive prefix sum of one int per thread over the threads of the workgroup (wsum: 17 ints of LDS); *total <- the sum
 __device__ __forceinline__ int block_excl_scan(int v, int* wsum, int tid, int* total)
 {
 	const int lane = tid & 63, wv = tid >> 6, nw = (int) (blockDim.x >> 6);
@@ -392,49 +386,105 @@ __device__ __forceinline__ int block_excl_scan(int v, int* wsum, int tid, int* t
 // phd_plan_migration (phdhip.hip, the host statement of the same plan, kept as the ABI's pure function and as this kernel's
 // reference in the tests) for the source vectors systematic resampling produces: those are non-decreasing (the recurrence of
 // PHDNavigator.cs:731-738 only ever advances k), so "the previous slot of rank t whose source lies on rank s" is simply the
-// slot before — every list is a prefix sum. One workgroup of 1024 threads; every rank runs it on the same global vector
-// and derives matching lists (the sender's order per destination is the receiver's order per source).
+// slot before — every list is a prefix sum over flags of neighbouring slots. One workgroup of 1024 threads; every rank
+// runs it on the same global vector and derives matching lists (the sender's order per destination is the receiver's order
+// per source). The vector is read in rounds of 1024 consecutive slots (coalesced; the slot before comes from the
+// neighbouring lane); positions in the lists are (flags before in the round's waves) + (flags before in the wave), the
+// first from one scan over the per-round, per-wave counts.
 //   gsrc [n Pl] global source of every slot; info[1] resampled; lflags: this rank's status word; gflags: the status words
 //   of all ranks as gathered with the weights (NULL: per-rank host); hostcounts: pinned host memory the counts are
 //   written to as well, followed by `seq` (the host polls that word instead of synchronising the stream); NULL: none
+// LDS (ints): cnt[n][n] base[n] roff[n] wsum[20] | wc[rounds][16] send counts per round and wave | used[(Pl + 31) / 32]
+//   | sg[n Pl] the source vector itself, when `staged` (it is read five times over: from LDS the rounds do not each wait
+//   for a trip to memory)
+#define PLAN_LDS_MAX (150 * 1024)
+__host__ __device__ inline size_t plan_lds_fixed(int Pl, int n)
+{
+	const size_t rounds = ((size_t) Pl * n + 1023) / 1024;
+	return ((size_t) n * n + 2 * n + 24 + rounds * 16 + 16 + (Pl + 31) / 32 + 4) * 4;
+}
+__host__ __device__ inline bool plan_staged(int Pl, int n) { return plan_lds_fixed(Pl, n) + (size_t) Pl * n * 4 <= PLAN_LDS_MAX; }
+__host__ __device__ inline size_t plan_lds_bytes(int Pl, int n) { return plan_lds_fixed(Pl, n) + (plan_staged(Pl, n) ? (size_t) Pl * n * 4 : 0); }
+
+//   gw (may be NULL): this rank's slice of the gathered (normalised, or 1 / P) weights goes back into its OUT bank here
 __global__ __launch_bounds__(1024) void k_plan_migration(const int* __restrict__ gsrc, const int* __restrict__ info, const int* lflags,
-                                                         const double* gflags, int Pl, int n, int rank, MigPlan pl, int* hostcounts, int seq)
+                                                         const double* gflags, int Pl, int n, int rank, MigPlan pl, int* hostcounts, int seq,
+                                                         const StepBufs a, const double* gw)
 {
 	extern __shared__ int sm[];
+	const int tid = threadIdx.x, nt = (int) blockDim.x, lane = tid & 63, wv = tid >> 6;
+	const int Pg = Pl * n, first = rank * Pl;
+	if (gw) {
+		double* wout = bank_of(a, SEL_OUT).weights;
+		for (int i = tid; i < Pl; i += nt) wout[i] = gw[first + i];
+	}
+	const int rounds = (Pg + nt - 1) / nt, lrounds = (Pl + nt - 1) / nt;
 	int* const cnt  = sm;                          // [n][n] records rank t takes from rank s
 	int* const base = cnt + n * n;                 // [n] first send-list position of destination t
 	int* const roff = base + n;                    // [n] record number, in destination t's receive buffer, of my first record for it
-	int* const wsum = roff + n;                    // [17]
-	int* const used = wsum + 20;                   // [(Pl + 31) / 32] bit c: OUT slot c stays the source of a local particle
+	int* const wsum = roff + n;                    // [20]
+	int* const wc   = wsum + 20;                   // [rounds][16] flags per round and wave, then their exclusive prefix
+	int* const used = wc + rounds * 16 + 16;       // [(Pl + 31) / 32] bit c: OUT slot c stays the source of a local particle
+	int* const sg   = used + (Pl + 31) / 32 + 4;   // [Pg] the source vector (staged)
+	const bool staged = plan_staged(Pl, n);
 	__shared__ int s_bad;
-	const int tid = threadIdx.x, nt = (int) blockDim.x;
-	const int Pg = Pl * n, first = rank * Pl;
+	const float rPl = 1.0f / (float) Pl;
 	bool drop = *lflags != 0;
 	if (gflags) for (int t = 0; t < n; t++) drop = drop || gflags[t] != 0.0;
 	const int resampled = info[1];
 	int status = drop ? MIG_DROPPED : MIG_OK, nsend = 0, nrecv = 0;
+	const bool bigidx = Pg >= (1 << 24);   // (the float quotient of small_div needs 24-bit operands; beyond that: the division)
+	auto rank_of = [&](int s) { return bigidx ? s / Pl : small_div(s, Pl, rPl); };
+	// the flags of slot g: does a new run start here, who owns the slot, who the source
+	auto look = [&](int g, int& s, int& t, int& sr, bool& head, bool& bad) {
+		int prev;
+		if (staged) { s = sg[g]; prev = g > 0 ? sg[g - 1] : 0; }
+		else {
+			s = gsrc[g];
+			prev = __shfl_up(s, 1, 64);
+			if (lane == 0) prev = g > 0 ? gsrc[g - 1] : 0;
+		}
+		bad = s < 0 || s >= Pg || (g > 0 && prev > s);
+		t = rank_of(g);
+		sr = rank_of(min(max(s, 0), Pg - 1));
+		head = sr != t && (g == t * Pl || prev != s);   // a new run of slots of rank t fed by a particle of rank sr: one record
+	};
 	if (resampled && !drop) {   // (uniform)
 		for (int i = tid; i < n * n; i += nt) cnt[i] = 0;
 		for (int i = tid; i < (Pl + 31) / 32; i += nt) used[i] = 0;
 		if (tid == 0) s_bad = 0;
-		__syncthreads();
-		// ---- all slots: who takes a record from whom; my own send list
-		const int CH = (Pg + nt - 1) / nt;
-		const int g0 = min(Pg, tid * CH), g1 = min(Pg, g0 + CH);
-		int mine = 0;
-		bool bad = false;
-		for (int g = g0; g < g1; g++) {
-			const int s = gsrc[g], prev = g > 0 ? gsrc[g - 1] : 0;
-			bad = bad || s < 0 || s >= Pg || prev > s;
-			const int t = g / Pl, sr = min(max(s, 0), Pg - 1) / Pl;
-			if (sr != t && (g == t * Pl || prev != s)) {   // a new run of slots of rank t fed by a particle of rank sr: one record
-				atomicAdd(&cnt[t * n + sr], 1);
-				mine += (sr == rank) ? 1 : 0;
+		if (staged) {   // eight loads in flight per thread, then their stores
+			for (int b0 = tid; b0 < Pg; b0 += 8 * nt) {
+				int v[8];
+#pragma unroll
+				for (int q = 0; q < 8; q++) v[q] = (b0 + q * nt < Pg) ? gsrc[b0 + q * nt] : 0;
+#pragma unroll
+				for (int q = 0; q < 8; q++) if (b0 + q * nt < Pg) sg[b0 + q * nt] = v[q];
 			}
 		}
-		if (bad) s_bad = 1;
-		int k = block_excl_scan(mine, wsum, tid, &nsend);
-		__syncthreads();   // cnt complete
+		__syncthreads();
+		// ---- all slots: who takes a record from whom; how many records of mine every round and wave holds
+		bool anybad = false;
+		for (int r = 0; r < rounds; r++) {
+			const int g = r * nt + tid;
+			int s = 0, t = 0, sr = 0;
+			bool head = false, bad = false;
+			if (g < Pg) look(g, s, t, sr, head, bad);
+			anybad = anybad || bad;
+			if (head && !bad) atomicAdd(&cnt[t * n + sr], 1);
+			const unsigned long long mine = ballot64(head && !bad && sr == rank);
+			if (lane == 0) wc[r * 16 + wv] = __popcll(mine);
+		}
+		if (anybad) s_bad = 1;
+		__syncthreads();
+		{   // exclusive prefix over the (round, wave) counts, in slot order: rounds x 16 entries, chunked over the threads
+			const int tot = rounds * 16, CHW = (tot + nt - 1) / nt;
+			const int e0 = min(tot, tid * CHW), e1 = min(tot, e0 + CHW);
+			int mysum = 0;
+			for (int e = e0; e < e1; e++) mysum += wc[e];
+			int run = block_excl_scan(mysum, wsum, tid, &nsend);
+			for (int e = e0; e < e1; e++) { const int x = wc[e]; wc[e] = run; run += x; }
+		}
 		if (tid < n) {
 			int b = 0, r = 0;
 			for (int t = 0; t < tid; t++) b += (t != rank) ? cnt[t * n + rank] : 0;     // destinations before `tid`
@@ -445,49 +495,87 @@ __global__ __launch_bounds__(1024) void k_plan_migration(const int* __restrict__
 		if (s_bad) status = MIG_BAD;
 		else if (nsend > pl.sendcap) status = MIG_OVERFLOW;
 		if (status == MIG_OK) {
-			for (int g = g0; g < g1; g++) {
-				const int s = gsrc[g], t = g / Pl;
-				if (s / Pl == rank && t != rank && (g == t * Pl || gsrc[g - 1] != s)) {
+			// ---- my send list: the heads among other ranks' slots whose source is mine, in slot order (= by destination, then slot)
+			for (int r = 0; r < rounds; r++) {
+				const int g = r * nt + tid;
+				int s = 0, t = 0, sr = 0;
+				bool head = false, bad = false;
+				if (g < Pg) look(g, s, t, sr, head, bad);
+				const bool mine = head && sr == rank;
+				const unsigned long long bal = ballot64(mine);
+				if (mine) {
+					const int k = wc[r * 16 + wv] + __popcll(bal & lanemask_lt());
 					pl.sendlist[k] = s - first;
 					pl.senddst[k] = ((long long) t << 32) | (long long) (roff[t] + (k - base[t]));
-					k++;
 				}
 			}
 			// ---- my slots: local source, or the record that feeds the run the slot belongs to (records numbered in slot order:
 			// with non-decreasing sources that is the order "by source rank, then by slot" the sender packs them in)
-			const int CL = (Pl + nt - 1) / nt;
-			const int i0 = min(Pl, tid * CL), i1 = min(Pl, i0 + CL);
-			int heads = 0;
-			for (int i = i0; i < i1; i++) {
-				const int s = gsrc[first + i];
-				heads += (s / Pl != rank && (i == 0 || gsrc[first + i - 1] != s)) ? 1 : 0;
-			}
-			int slot = block_excl_scan(heads, wsum, tid, &nrecv);
-			for (int i = i0; i < i1; i++) {
-				const int s = gsrc[first + i];
-				if (s / Pl == rank) {
-					pl.code[i] = s - first;
-					atomicOr(&used[(s - first) >> 5], 1 << ((s - first) & 31));
+			__syncthreads();   // (wc is reused)
+			for (int r = 0; r < lrounds; r++) {
+				const int i = r * nt + tid;
+				bool head = false;
+				if (i < Pl) {
+					int s, t, sr; bool bad;
+					look(first + i, s, t, sr, head, bad);
 				}
-				else {
-					slot += (i == 0 || gsrc[first + i - 1] != s) ? 1 : 0;
-					pl.code[i] = -slot;   // record slot - 1
+				const unsigned long long bal = ballot64(head);
+				if (lane == 0) wc[r * 16 + wv] = __popcll(bal);
+			}
+			__syncthreads();
+			{
+				const int tot = lrounds * 16, CHW = (tot + nt - 1) / nt;
+				const int e0 = min(tot, tid * CHW), e1 = min(tot, e0 + CHW);
+				int mysum = 0;
+				for (int e = e0; e < e1; e++) mysum += wc[e];
+				int run = block_excl_scan(mysum, wsum, tid, &nrecv);
+				for (int e = e0; e < e1; e++) { const int x = wc[e]; wc[e] = run; run += x; }
+			}
+			__syncthreads();
+			for (int r = 0; r < lrounds; r++) {
+				const int i = r * nt + tid;
+				int s = 0, t = 0, sr = 0;
+				bool head = false, bad = false;
+				if (i < Pl) look(first + i, s, t, sr, head, bad);
+				const unsigned long long bal = ballot64(head);
+				if (i < Pl) {
+					if (sr == rank) {
+						pl.code[i] = s - first;
+						atomicOr(&used[(s - first) >> 5], 1 << ((s - first) & 31));
+					}
+					else {
+						// heads up to and including this slot: the number of the record that feeds it (a slot inside a run
+						// carries the count of its run's head: no head lies in between)
+						const int slot = wc[r * 16 + wv] + __popcll(bal & (lanemask_lt() | (1ull << lane)));
+						pl.code[i] = -slot;   // record slot - 1
+					}
 				}
 			}
 			__syncthreads();
 			// ---- an arriving particle is unpacked into a slot of the OUT bank that no local particle keeps as its source
-			int nfree = 0;
-			for (int c = i0; c < i1; c++) nfree += ((used[c >> 5] >> (c & 31)) & 1) ? 0 : 1;
-			int totfree;
-			int f = block_excl_scan(nfree, wsum, tid, &totfree);
-			for (int c = i0; c < i1; c++) {
-				if (!((used[c >> 5] >> (c & 31)) & 1)) {
-					if (f < nrecv) pl.fslot[f] = c;
-					f++;
-				}
-			}
 			// (at least nrecv slots are fed from elsewhere, so the Pl slots keep at most Pl - nrecv distinct local sources: at
 			// least nrecv slots of the OUT bank are free)
+			{
+				const int words = (Pl + 31) / 32, CHW = (words + nt - 1) / nt;
+				const int e0 = min(words, tid * CHW), e1 = min(words, e0 + CHW);
+				int nfree = 0;
+				for (int e = e0; e < e1; e++) {
+					unsigned int fr = ~(unsigned int) used[e];
+					if (e == words - 1 && (Pl & 31)) fr &= (1u << (Pl & 31)) - 1u;
+					nfree += __popc(fr);
+				}
+				int totfree;
+				int f = block_excl_scan(nfree, wsum, tid, &totfree);
+				for (int e = e0; e < e1 && f < nrecv; e++) {
+					unsigned int fr = ~(unsigned int) used[e];
+					if (e == words - 1 && (Pl & 31)) fr &= (1u << (Pl & 31)) - 1u;
+					while (fr && f < nrecv) {
+						const int bit = __ffs((int) fr) - 1;
+						fr &= fr - 1;
+						pl.fslot[f++] = e * 32 + bit;
+					}
+				}
+			}
 		}
 		else { nsend = 0; nrecv = 0; }
 	}
@@ -593,7 +681,7 @@ __global__ __launch_bounds__(256) void k_finish_sharded(const StepBufs a, const 
 	if (i < nrecv) {
 		const MixView dst = bank_view(a, SEL_OUT);
 		const double* r = recvbuf + (size_t) i * rec;
-		const int nc = (int) r[0];
+		const int nc = min(max((int) r[0], 0), a.cap);   // (a record is what a peer packed; never trust a count with a store loop)
 		const size_t db = (size_t) pl.fslot[i] * a.cap;
 		for (int c = tid; c < nc; c += 256) {
 			dst.w[db + c] = r[8 + c];
@@ -615,7 +703,7 @@ __global__ __launch_bounds__(256) void k_finish_sharded(const StepBufs a, const 
 		const int j = -(code + 1);
 		const double* r = recvbuf + (size_t) j * rec;
 		slot = pl.fslot[j];
-		if (tid == 0) bt.count[i] = (int) r[0];
+		if (tid == 0) bt.count[i] = min(max((int) r[0], 0), a.cap);
 		if (tid < 7) bt.poses[(size_t) i * 7 + tid] = r[1 + tid];
 	}
 	if (tid == 0) {

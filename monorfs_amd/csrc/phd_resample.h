@@ -86,6 +86,33 @@ __device__ __forceinline__ double block_sum_1024(double v, double* scratch16, in
 	return t;
 }
 
+// T_i = fl(u / P) + i * fl(1 / P), exactly, as a double-double: what `random` is at slot i before anything is subtracted
+__device__ __forceinline__ dd slot_target(int i, double R0, double invP)
+{
+#pragma clang fp contract(off)
+	const double ph = (double) i * invP, pl = fma((double) i, invP, -ph);
+	return dd_add_d(dd{ph, pl}, R0);
+}
+
+// How many slots i in [0, P) have T_i <= x: an estimate from the quotient, settled by exact comparisons with the slots
+// around it. *settled <- false if six steps did not settle it (never seen; the caller then lets the recurrence decide).
+__device__ __forceinline__ int slots_upto(dd x, double R0, double invP, int P, bool* settled)
+{
+#pragma clang fp contract(off)
+	const double est = (x.hi - R0) * (double) P;
+	int n = (est >= (double) P) ? P : ((est < 0) ? 0 : (int) est + 1);
+	int it = 0;
+	for (; it < 6; it++) {
+		const bool up = n < P && dd_ge(x, slot_target(n, R0, invP));
+		const bool dn = !up && n > 0 && !dd_ge(x, slot_target(n - 1, R0, invP));
+		if (up) n++;
+		else if (dn) n--;
+		else break;
+	}
+	if (it == 6) *settled = false;
+	return n;
+}
+
 // End of a single-handle step (sel_next != NULL), folded into the same launch: the resampled particles
 // (PHDNavigator.cs:740-741) and the bank roles of the next step, decided here from the resampling flag so the host never
 // waits inside a step. No mixture is copied:
@@ -143,6 +170,8 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 	__shared__ int    s_res, s_ok, s_best;
 	// (launched with 1024 threads, or 256 for short weight vectors: the shape of the sums depends on the vector length only)
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = (int) blockDim.x, nw = nt >> 6;
+	PHD_STAMP_DECL;
+	PHD_STAMP(0);
 	if (tid == 0 && a.bigws_used && *a.bigws_used) *a.bigws_used = 0;   // the association slab is free again (every k_alpha_assoc of the step is over)
 	// A kernel of this step raised a flag (emit capacity, landmark scratch): what it wrote into the OUT bank is not a
 	// valid state. The step is dropped as a whole — the roles stay, nothing of the current state was touched — and the host
@@ -152,33 +181,50 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 		return;
 	}
 	double* gwp = gw ? gw : bank_of(a, SEL_OUT).weights;
-	double* w = use_lds ? lw : gwp;
+	const int CH = (P + nt - 1) / nt;              // contiguous chunk of every thread
+	const int c0 = min(P, tid * CH), c1 = min(P, c0 + CH), cn = c1 - c0;
+	// The vector is staged in LDS chunk-transposed: element j of chunk t at lw[j * LS + t], LS = nt + 1. Every loop below has
+	// the lanes of a wave on the same element of neighbouring chunks — consecutive LDS words — where the plain layout put
+	// them CH doubles apart (at 16 384 weights: 16 lanes on one bank, every access 16 times its cost); the odd row stride
+	// spreads the accesses that run along a chunk (staging the vector, storing the sources) over the banks as well.
+	const int LS = nt + 1;
+	auto W = [&](int chunk, int j) -> double { return use_lds ? lw[j * LS + chunk] : gwp[chunk * CH + j]; };
+	const float rCH = 1.0f / (float) CH;
+	const int chshift = (CH & (CH - 1)) == 0 ? __ffs(CH) - 1 : -1;   // (a power of two — every BASELINE size — needs no division)
+	// where element i of the vector sits in LDS (i < 2^24: small_div's range; a vector that long is not staged anyway)
+	auto lpos = [&](int i) {
+		const int c = chshift >= 0 ? (i >> chshift) : small_div(i, CH, rCH);
+		return (i - c * CH) * LS + c;
+	};
 	if (use_lds) {
-		for (int i = tid; i < P; i += nt) lw[i] = gwp[i];
+		for (int i = tid; i < P; i += nt) lw[lpos(i)] = gwp[i];   // (global reads in whole lines; the scattered side is the LDS one)
 	}
 	__syncthreads();
-	const int CH = (P + nt - 1) / nt;              // contiguous chunk of every thread
-	const int c0 = min(P, tid * CH), c1 = min(P, c0 + CH);
+	PHD_STAMP(1);
 
-	// ---- normalise (:343-345)
+	// ---- normalise (:343-345); BestParticle (first strict maximum, :347-354), sum of squares (:772-774) and the chunk sums
+	// for S in the same pass over the thread's chunk
+	double nsum = 1;
 	if (!skip_normalise) {
 		double part = 0;
-		for (int k = c0; k < c1; k++) part += w[k];
+		for (int j = 0; j < cn; j++) part += W(tid, j);
 		double sum = block_sum_1024(part, s16, tid);
-		sum = (sum == 0) ? 1 : sum;
-		for (int k = c0; k < c1; k++) w[k] = w[k] / sum;
+		nsum = (sum == 0) ? 1 : sum;
 	}
-	__syncthreads();
-
-	// ---- BestParticle (first strict maximum, :347-354), sum of squares (:772-774), and the chunk sums for S
+	PHD_STAMP(2);
 	double part2 = 0, wmax = -INFINITY;
 	int    imax = 0;
 	bool   bad = false;
 	dd     chunk = {0, 0};
-	for (int k = c0; k < c1; k++) {
-		double wk = w[k];
+	for (int j = 0; j < cn; j++) {
+		double wk = W(tid, j);
+		if (!skip_normalise) {
+			wk = wk / nsum;
+			if (use_lds) lw[j * LS + tid] = wk;
+			else gwp[c0 + j] = wk;
+		}
 		part2 += wk * wk;
-		if (wk > wmax) { wmax = wk; imax = k; }
+		if (wk > wmax) { wmax = wk; imax = c0 + j; }
 		bad |= !(wk >= 0);
 		chunk = dd_add_d(chunk, wk);
 	}
@@ -201,15 +247,16 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 		if (s16b[q] > gmax) { gmax = s16b[q]; gbest = s_i16[q]; }
 	}
 	if (!(gmax > 0)) gbest = 0;   // maxweight starts at 0 and the comparison is strict (:347-353)
+	PHD_STAMP(3);
 	bool depleted = (1.0 / cum < min_eff * P);   // :776
 	if (force_resample > 0) depleted = true;
 	if (force_resample < 0) depleted = false;
 
 	if (!depleted) {   // uniform: every thread computed the same `cum`
 		if (tid == 0) { info[0] = gbest; info[1] = 0; }
-		for (int k = c0; k < c1; k++) {
-			src[k] = k;
-			if (use_lds && !skip_normalise) gwp[k] = lw[k];
+		for (int i = tid; i < P; i += nt) {
+			src[i] = i;
+			if (use_lds && !skip_normalise) gwp[i] = lw[lpos(i)];
 		}
 		if (sel_next) rotate_roles(a, src, 0, sel_next, frozen, inslot, tid);   // no thread reads another's writes here
 		return;
@@ -226,8 +273,17 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 	__syncthreads();
 	if (lane == 63) { s16[wv] = incl.hi; s16b[wv] = incl.lo; }
 	__syncthreads();
-	dd woff = {0, 0};
-	for (int q = 0; q < wv; q++) woff = dd_add(woff, dd{s16[q], s16b[q]});
+	dd woff;
+	{   // exclusive scan of the wave totals: lane q holds wave q's, every wave does the same four steps; its own offset is lane wv's
+		dd tot = (lane < nw) ? dd{s16[lane], s16b[lane]} : dd{0, 0};
+		dd inc = tot;
+#pragma unroll
+		for (int o = 1; o < 16; o <<= 1) {
+			dd y = {shfl_up_d(inc.hi, o), shfl_up_d(inc.lo, o)};
+			if (lane >= o) inc = dd_add(y, inc);
+		}
+		woff = (wv == 0) ? dd{0, 0} : dd{__shfl(inc.hi, wv - 1, 64), __shfl(inc.lo, wv - 1, 64)};   // (wave-uniform index)
+	}
 	dd excl = dd_add(woff, incl);
 	excl = dd_add(excl, dd{-chunk.hi, -chunk.lo});   // prefix at the start of this thread's chunk
 	if (c0 == 0) excl = dd{0, 0};
@@ -236,56 +292,117 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 	if (tid == 0) { s_ok = 1; s_best = 0x7fffffff; }
 	bad = __syncthreads_or(bad);
 
+	PHD_STAMP(4);
 	const double R0 = u / P, invP = 1.0 / P;
 	const double B = 8.0 * P * 1.1102230246251565e-16 * (fmax(gmax, 0.0) + fabs(R0) + invP);
 	const int nchunks = (P + CH - 1) / CH;
 	bool   ok = !bad;
 	double mybestw = -INFINITY;
 	int    mybesti = 0x7fffffff;
-	for (int i = tid; i < P; i += nt) {
-		// T_i = R0 + i * invP, exactly, as a double-double
-		double ph = (double) i * invP, pl = fma((double) i, invP, -ph);
-		dd T = dd_add_d(dd{ph, pl}, R0);
+	int lo0 = 0;   // (staged path) the first slot of this thread's first particle
+	if (use_lds) {
+		// ---- per PARTICLE, not per slot: particle k takes the slots i with S_k < T_i <= S_(k+1), i.e. [N(S_k), N(S_(k+1))) with
+		// N(x) = #{i : T_i <= x}. Every thread takes the particles of its chunk; each costs the same few exact comparisons
+		// whatever the weights are — no lane waits for another lane's search (a walk over the slots made every wave pay for
+		// its slowest lane at every slot: most of this kernel at 16 384 weights). A particle's cell in LDS (its weight is
+		// dead once its owner has read it) takes N(S_(k+1)); the runs are then laid over the slots by a max-scan.
+		//   boundaries between chunks come from the scanned chunk prefixes on both sides, so the ranges tile [0, P);
+		//   the recurrence's comparisons are exact (B) iff, for every particle with slots, T at its first slot clears S_k and
+		//   S_(k+1) clears T at its last one — the two prefix sums around every crossing, as before.
+		int2* cells = (int2*) lw;   // cell (chunk c, element j) at [j * LS + c]: {N(S_(k+1)) | source of slot k, head written for slot k}
+		dd S = {s_pchi[tid], s_pclo[tid]};
+		bool settled = true;
+		int lo = (c0 == 0) ? 0 : slots_upto(S, R0, invP, P, &settled);   // (slot 0 belongs to the first particle even when u == 0: the clamp of :739)
+		lo0 = lo;
+		for (int j = 0; j < cn; j++) {
+			const int k = c0 + j;
+			const double wk = lw[j * LS + tid];
+			const dd Sn = dd_add_d(S, wk);
+			const dd Sb = (j == cn - 1 && tid + 1 < nchunks) ? dd{s_pchi[tid + 1], s_pclo[tid + 1]} : Sn;   // S_(k+1) as the next chunk knows it
+			int hi = slots_upto(Sb, R0, invP, P, &settled);
+			const int hinat = hi;
+			if (k == P - 1) hi = P;        // the recurrence runs into P: whatever is left goes to the last particle
+			if (hi < lo) { ok = false; hi = lo; }
+			if (hi > lo) {
+				// the last comparison that came out positive, at the particle's first slot (none for particle 0: `random` is
+				// u / P itself there, compared without any rounding)
+				if (k > 0) ok = ok && dd_diff(slot_target(lo, R0, invP), S) > B;
+				// the comparison that stopped the loop, at its last slot (none for the slots the last particle gets by k == P)
+				if (hinat > lo) ok = ok && dd_diff(Sb, slot_target(hinat - 1, R0, invP)) > B;
+				if (wk > mybestw) { mybestw = wk; mybesti = lo; }   // k ascending per thread, slots ascending with k: first maximum kept
+			}
+			cells[j * LS + tid] = make_int2(hi, 0);
+			S = Sn; lo = hi;
+		}
+		ok = ok && settled;
+	}
+	else {
+	// (the vector does not fit LDS: the slots are walked in global memory)
+	// Every thread takes the slots [c0, c1) and walks the prefix sums forward with them: T_i grows with i and so does the
+	// crossing, which for most slots of a depleted set is the one of the slot before (a heavy particle takes a run of
+	// slots) — one comparison. A slot that moves on scans the rest of its chunk; only when the target lies beyond the next
+	// chunk's start is that chunk found by bisection over the chunk prefixes.
+	//   s = S_k (the first k weights, k = ck * CH + jn: jn weights of chunk ck added), sprev = S_(k-1), wlast = w[k - 1]
+	dd s = {0, 0}, sprev = {0, 0};
+	int k = 0, ck = 0, jn = 0;
+	bool have = false;                // a chunk has been entered
+	double wlast = 0;
+	for (int i = c0; i < c1; i++) {
+		const dd T = slot_target(i, R0, invP);
 		int kstar;
-		double mlow = INFINITY, mhigh = INFINITY;
+		double ws, mlow = INFINITY, mhigh = INFINITY;
 		if (!(T.hi > 0 || (T.hi == 0 && T.lo > 0))) {
 			kstar = 0;   // random <= 0 before any subtraction (u == 0)
 			mhigh = -dd_diff(T, dd{0, 0});
 			if (mhigh == 0) mhigh = INFINITY;   // the comparison 0 > 0 is exact
+			ws = W(0, 0);                       // (the reference would index -1: clamped to the first particle)
 		}
 		else {
-			// last chunk whose start prefix is still below T
-			int lo = 0, hi = nchunks - 1;
-			while (lo < hi) {
-				int mid = (lo + hi + 1) >> 1;
-				if (dd_lt(dd{s_pchi[mid], s_pclo[mid]}, T)) lo = mid;
-				else hi = mid - 1;
+			if ((!have || dd_lt(s, T)) && k < P) {   // no crossing yet, or the one of the slot before does not reach T: move on
+				// (k == P: every weight is added and the sum stays below T — the recurrence ran into P)
+				int lo = -1;
+				if (!have) lo = 0;
+				else if (jn == min(CH, P - ck * CH)) lo = ck + 1;                                          // this chunk is used up
+				else if (ck + 1 < nchunks && dd_lt(dd{s_pchi[ck + 1], s_pclo[ck + 1]}, T)) lo = ck + 1;   // the target lies beyond it
+				if (lo >= 0) {
+					// the last chunk, from lo on, whose start prefix is still below T. (lo's own is: the prefix of chunk 0 is 0;
+					// that of ck + 1 is the sum walked so far up to the rounding of two orders of addition — should they fall on
+					// different sides of T, the literal recurrence decides)
+					if (lo > 0 && !dd_lt(dd{s_pchi[lo], s_pclo[lo]}, T)) ok = false;
+					int hi = nchunks - 1;
+					while (lo < hi) {
+						int mid = (lo + hi + 1) >> 1;
+						if (dd_lt(dd{s_pchi[mid], s_pclo[mid]}, T)) lo = mid;
+						else hi = mid - 1;
+					}
+					ck = lo; jn = 0; k = lo * CH;
+					s = dd{s_pchi[lo], s_pclo[lo]};
+					have = true;
+				}
+				const int jend = min(CH, P - ck * CH);
+				while (jn < jend) {
+					sprev = s;
+					wlast = W(ck, jn);
+					s = dd_add_d(s, wlast);
+					jn++; k++;
+					if (dd_ge(s, T)) break;
+				}
+				if (dd_lt(s, T) && k < P) ok = false;   // the chunk ends below T although the next one starts at or above it: cannot happen (defensive)
 			}
-			dd s = {s_pchi[lo], s_pclo[lo]};
-			int k = lo * CH, kend = min(P, k + CH);
-			kstar = P;
-			dd sprev = s;
-			while (k < kend) {
-				sprev = s;
-				s = dd_add_d(s, w[k]);
-				k++;
-				if (dd_ge(s, T)) { kstar = k; break; }
-			}
-			if (kstar == P && k < P) {   // crossing exactly at the start of the next chunk cannot happen (its prefix >= T): defensive
-				ok = false;
-			}
+			const bool reached = dd_ge(s, T);
+			kstar = reached ? k : P;
 			mlow = dd_diff(T, sprev);                       // last comparison that came out positive
-			if (kstar < P) mhigh = dd_diff(s, T);           // the comparison that stopped the loop (none if k ran into P)
-			else mlow = dd_diff(T, sprev);
+			if (reached) mhigh = dd_diff(s, T);             // the comparison that stopped the loop (none if k ran into P)
+			ws = wlast;                                     // w[kstar - 1] (k ran into P: the last particle)
 		}
 		ok = ok && (mlow > B) && (mhigh > B);
-		int sidx = (kstar - 1 < 0) ? 0 : kstar - 1;
-		src[i] = sidx;
-		double ws = w[sidx];
+		src[i] = (kstar - 1 < 0) ? 0 : kstar - 1;
 		if (ws > mybestw) { mybestw = ws; mybesti = i; }    // i ascending per thread: first maximum kept
 	}
+	}   // (walk in global memory)
 	if (!ok) s_ok = 0;
 	__syncthreads();
+	PHD_STAMP(5);
 	if (s_ok) {
 		// BestParticle = first slot whose source has the largest weight (:745-748)
 		double m = mybestw;
@@ -298,6 +415,37 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 		if (gm > 0 && mybestw == gm) atomicMin(&s_best, mybesti);
 		__syncthreads();
 		if (tid == 0) { info[0] = (gm > 0) ? s_best : 0; info[1] = 1; }
+		if (use_lds) {
+			// the runs laid over the slots: a particle with slots writes its number (+ 1) into the cell of its first slot, a
+			// running maximum over the slots fills the runs (sources never decrease); then the sources leave in whole lines
+			int2* cells = (int2*) lw;
+			int lo = lo0;
+			for (int j = 0; j < cn; j++) {
+				const int hi = cells[j * LS + tid].x;
+				if (hi > lo) ((int*) lw)[2 * lpos(lo) + 1] = c0 + j + 1;
+				lo = hi;
+			}
+			__syncthreads();
+			int run = 0;
+			for (int j = 0; j < cn; j++) run = max(run, cells[j * LS + tid].y);
+			int incl = run;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				const int y = __shfl_up(incl, o, 64);
+				if (lane >= o) incl = max(incl, y);
+			}
+			if (lane == 63) s_i16[wv] = incl;
+			__syncthreads();
+			int before = __shfl_up(incl, 1, 64);
+			if (lane == 0) before = 0;
+			for (int q = 0; q < wv; q++) before = max(before, s_i16[q]);
+			for (int j = 0; j < cn; j++) {
+				before = max(before, cells[j * LS + tid].y);
+				cells[j * LS + tid].x = before - 1;   // (slot 0 always carries a head: the first particle with slots starts there)
+			}
+			__syncthreads();
+			for (int i = tid; i < P; i += nt) src[i] = cells[lpos(i)].x;
+		}
 	}
 	else if (wv == 0) {
 		// fallback: the recurrence itself, wave-uniform (weights through v_readlane, scalar control flow)
@@ -305,12 +453,15 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 			int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
 			return __hiloint2double(hi, lo);
 		};
+		// (the staged weights have given way to the cells: read from memory — still un-normalised there when this launch
+		// normalises, so divided again, by the same sum: the same bits)
+		auto wk = [&](int q) { return (use_lds && !skip_normalise) ? gwp[q] / nsum : gwp[q]; };
 		double random = u / P, maxweight = 0;
 		int k = 0, best = 0, cb = 0;
-		double cur = (lane < P) ? w[lane] : 0.0, prev = 0.0;
+		double cur = (lane < P) ? wk(lane) : 0.0, prev = 0.0;
 		for (int i = 0; i < P; i++) {
 			while (k < P && __builtin_amdgcn_readfirstlane((int) (random > 0))) {
-				if (k >= cb + 64) { prev = cur; cb += 64; cur = (cb + lane < P) ? w[cb + lane] : 0.0; }
+				if (k >= cb + 64) { prev = cur; cb += 64; cur = (cb + lane < P) ? wk(cb + lane) : 0.0; }
 				random -= rl(cur, k - cb);
 				k++;
 			}
@@ -323,7 +474,12 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 		if (lane == 0) { info[0] = best; info[1] = 1; }
 	}
 	__syncthreads();
-	for (int k = c0; k < c1; k++) gwp[k] = 1.0 / P;   // :742
+	PHD_STAMP(6);
+	for (int i = tid; i < P; i += nt) gwp[i] = 1.0 / P;   // :742
+	PHD_STAMP(7);
+#ifdef PHD_STAMPS
+	if (tid == 0 && a.stamps && a.stamp_kernel == 6) { for (int s_ = 0; s_ < 8; s_++) a.stamps[s_] = (double) (stamp_[s_] - stamp_[0]); a.stamps[8] = (double) s_ok; }
+#endif
 	if (sel_next) {
 		__threadfence_block();
 		__syncthreads();   // src and the weights of every particle are written

@@ -386,14 +386,14 @@ int launch_map(phd_navigator* nav, const StepBufs& b, bool with_alpha)
 int launch_normalise(phd_navigator* nav, const StepBufs& b, double* gw, int P, double u, int force, int skipnorm, int* src, int* info,
                      int* sel_next = nullptr)
 {
-	// the weight vector is staged in LDS when it fits beside the kernel's static arrays (160 KB per CU); above that the
-	// kernel works on the vector in global memory
-	size_t lds = (size_t) P * 8;
+	// one workgroup; 256 / 512 threads for shorter weight vectors (fewer waves to meet at every barrier), 1024 beyond 4096
+	static const int nr_env = getenv("PHD_NR_THREADS") ? atoi(getenv("PHD_NR_THREADS")) : 0;
+	const int nthreads = (nr_env == 256 || nr_env == 512 || nr_env == 1024) ? nr_env : (P <= 512 ? 256 : (P <= 4096 ? 512 : 1024));
+	// the weight vector is staged in LDS (chunk-transposed: a whole chunk per thread, used or not) when it fits beside the
+	// kernel's static arrays (160 KB per CU); above that the kernel works on the vector in global memory
+	size_t lds = (size_t) ((P + nthreads - 1) / nthreads) * (nthreads + 1) * 8;
 	int use_lds = lds + (size_t) nav->nr_static_lds + 256 <= 160 * 1024;
 	if (!use_lds) lds = 0;
-	// one workgroup; 256 threads for a short weight vector (fewer waves to meet at every barrier), 1024 beyond
-	static const int nr_env = getenv("PHD_NR_THREADS") ? atoi(getenv("PHD_NR_THREADS")) : 0;
-	const int nthreads = (nr_env == 256 || nr_env == 512 || nr_env == 1024) ? nr_env : (P <= 512 ? 256 : 1024);
 	hipLaunchKernelGGL(k_normalise_resample, dim3(1), dim3(nthreads), lds, nav->stream, b, gw, P, nav->dp.min_eff, u, force, skipnorm,
 	                   use_lds, src, info, sel_next, nav->frozen ? 1 : 0, nav->d_inslot);
 	HC(hipGetLastError());
@@ -723,6 +723,7 @@ phd_navigator* phd_create(const phd_params* params, int device)
 		nav->chain_ok[0] = fits[0] && fits[3];
 		nav->chain_ok[1] = fits[1];
 		nav->chain_ok[2] = fits[2];
+		ok = ok && hipFuncSetAttribute((const void*) k_plan_migration, hipFuncAttributeMaxDynamicSharedMemorySize, PLAN_LDS_MAX + 1024) == hipSuccess;
 		hipFuncAttributes fa;
 		if (ok && hipFuncGetAttributes(&fa, (const void*) k_normalise_resample) == hipSuccess) {
 			nav->nr_static_lds = (int) fa.sharedSizeBytes;
@@ -1578,8 +1579,7 @@ static int step_global(phd_navigator* nav, int rank, int world_size, double u, u
 	rc = launch_normalise(nav, b, nav->d_gw, Pg, u, onlymapping ? -1 : 0, onlymapping ? 1 : 0, nav->d_plan, nav->d_info);
 	timer_end(nav, T_NR);
 	if (rc) return rc;
-	hipLaunchKernelGGL(k_scatter_weights, dim3((nav->P + 255) / 256), dim3(256), 0, nav->stream, b, nav->d_gw, rank * nav->P);
-	const size_t lds = ((size_t) world_size * world_size + 2 * world_size + 24 + (nav->P + 31) / 32) * 4;
+	const size_t lds = plan_lds_bytes(nav->P, world_size);
 	int* hc = nullptr;
 	if (hostcounts) {
 		HC(hipHostGetDevicePointer((void**) &hc, nav->h_counts, 0));
@@ -1588,7 +1588,7 @@ static int step_global(phd_navigator* nav, int rank, int world_size, double u, u
 	}
 	timer_begin(nav, T_PL);
 	hipLaunchKernelGGL(k_plan_migration, dim3(1), dim3(1024), lds, nav->stream, (const int*) nav->d_plan, (const int*) nav->d_info, (const int*) nav->d_flags,
-	                   nav->d_gflags, nav->P, world_size, rank, nav->plan, hc, nav->plan_seq);
+	                   nav->d_gflags, nav->P, world_size, rank, nav->plan, hc, nav->plan_seq, b, (const double*) nav->d_gw);
 	timer_end(nav, T_PL);
 	HC(hipGetLastError());
 	return PHD_OK;
@@ -1681,10 +1681,10 @@ int phd_test_migration_plan(phd_navigator* nav, const int32_t* gsrc, int particl
 	const int info[3] = {0, resampled ? 1 : 0, 0};
 	hipError_t e = hipMemcpy(d_g, gsrc, (size_t) Pl * n * 4, hipMemcpyHostToDevice);
 	if (e == hipSuccess) e = hipMemcpy(d_i, info, 12, hipMemcpyHostToDevice);
-	const size_t lds = ((size_t) n * n + 2 * n + 24 + (Pl + 31) / 32) * 4;
+	const size_t lds = plan_lds_bytes(Pl, n);
 	if (e == hipSuccess) {
 		hipLaunchKernelGGL(k_plan_migration, dim3(1), dim3(1024), lds, nav->stream, (const int*) d_g, (const int*) d_i, (const int*) (d_i + 2), (const double*) nullptr,
-		                   Pl, n, rank, nav->plan, (int*) nullptr, 0);
+		                   Pl, n, rank, nav->plan, (int*) nullptr, 0, make_bufs(nav), (const double*) nullptr);
 		e = hipStreamSynchronize(nav->stream);
 	}
 	std::vector<int> c(2 * n + 4);
@@ -1746,14 +1746,22 @@ int phd_migration_plan(phd_navigator* nav, int rank, int world_size, int32_t* se
 	return PHD_OK;
 }
 
-void* phd_migration_send_buffer(phd_navigator* nav, int64_t* bytes_per_particle)
+// Did the last global step resample? As the host knows it from phd_migration_plan (per-rank host) — identical on every
+// rank, so all of them may skip the exchange together when it did not. -1: not known (no plan waited for yet).
+int phd_last_resampled(phd_navigator* nav)
 {
-	if (!nav || nav->multi) return nullptr;
-	if (bytes_per_particle) *bytes_per_particle = (int64_t) ((size_t) 8 + (size_t) 10 * nav->cap) * 8;
-	return nav->d_send;
+	if (!nav || nav->multi || !nav->sharded_used || nav->plan_waiting) return -1;
+	return nav->h_info[1] ? 1 : 0;
 }
 
-void* phd_migration_recv_buffer(phd_navigator* nav) { return (nav && !nav->multi) ? nav->d_recv : nullptr; }
+void* phd_migration_send_buffer(phd_navigator* nav, int64_t* bytes_per_particle)
+{
+	if (!nav || nav->multi || ensure_sharded(nav)) return nullptr;
+	if (bytes_per_particle) *bytes_per_particle = (int64_t) ((size_t) 8 + (size_t) 10 * nav->cap) * 8;
+	return nav->d_send;   // (a fixed address for the life of the handle)
+}
+
+void* phd_migration_recv_buffer(phd_navigator* nav) { return (nav && !nav->multi && !ensure_sharded(nav)) ? nav->d_recv : nullptr; }
 
 // grid of k_pack_particles / its like: the records are counted on the device, a fixed grid strides over them
 static int pack_grid(const phd_navigator* nav) { return std::min(nav->plan.sendcap, 1024); }

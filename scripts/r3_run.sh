@@ -20,3 +20,4 @@ done
 timeout -k 10 300 python bench.py --single-process --gpus 2 --devices 0,0 --config B1024 --weights steady --steps 40 --warmup 3 > $O/multi2_B1024.json 2> $O/multi2_B1024.err; echo "multi2 rc=$?"
 timeout -k 10 200 python bench.py --force-dist --weights steady --steps 40 --warmup 3 --no-cpu-baseline --no-extra > $O/forcedist.json 2> $O/forcedist.err; echo "forcedist rc=$?"
 timeout -k 10 200 python scripts/dist_phases.py > $O/dist_phases.log 2>&1; echo "phases rc=$?"
+timeout -k 10 200 python scripts/global_phase.py 8 steady > $O/global_phase.log 2>&1; echo "global phase rc=$?"; tail -5 $O/global_phase.log

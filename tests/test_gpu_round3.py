@@ -237,12 +237,11 @@ def test_a_quasi_batch_with_big_clusters_leaves_the_association_slab_to_the_next
     nav._check(nav._lib.phd_set_association_workspace(nav._h, 1 << 20))
     v = nav.QuasiSetLogLikelihood(f.z, lm, poses)       # gate 12 sigma: one cluster of 90 rows per pose -> a slab block each
     assert np.isclose(v[0], orc.quasi_set_log_likelihood(p, poses[0], lm, f.z), rtol=1e-9, atol=1e-9)
-    nav.SlamUpdate(None, f.z)                           # would fail with PHD_ERR_ASSOCIATION if the batch's blocks were still counted
+    nav.run_stages(f.z, with_alpha=True)                # a stage run takes three blocks as well, and gives them back
+    nav.SlamUpdate(None, f.z)                           # would fail with PHD_ERR_ASSOCIATION if the earlier blocks were still counted
     assert np.isclose(nav.VehicleWeights.sum(), 1.0)
     v2 = nav.QuasiSetLogLikelihood(f.z, lm, poses)
     assert np.array_equal(v, v2)
-    nav.run_stages(f.z, with_alpha=True)                # a stage run takes three blocks as well ...
-    nav.SlamUpdate(None, f.z)                           # ... and gives them back
     nav.close()
 
 
