@@ -639,7 +639,7 @@ def single_process(args):
                                   % (args.config, P, Cc, M, args.weights, devices),
                       "particles_per_gpu": P, "components": Cc, "measurements": M, "max_quantity": maxq,
                       "parallelism": "particles sharded x%d in one process" % n},
-           "multi_host": {"post_us_per_step": rep["post_us"], "worker_issue_us_per_step": rep["issue_us"],
+           "multi_host": {"post_us_per_step": rep["post_us"], "worker_issue_us_per_step": rep["issue_us"], "worker_hip_calls_us_per_step": rep["issue_calls_us"],
                           "posting_all_steps_ms": t_posted * 1e3, "phase_ms_first_shard": rep["phase_ms"], "phase_samples": rep["sampled_steps"],
                           "p2p": rep["p2p"], "resampled_every_step": resampled,
                           "note": "post = the caller's thread inside phd_step_async (it only posts); worker issue = host time one shard's thread needs to issue "

@@ -121,11 +121,11 @@ phd_navigator* phd_create(const phd_params* params, int device);
  * phd_quasi_set_loglik[_grad], phd_resample / phd_particle_depleted, the timing calls (first shard); the stage-level KAT entry
  * points and the per-rank sharding primitives below return PHD_ERR_BAD_ARGUMENT.                                       */
 phd_navigator* phd_create_multi(const phd_params* params, const int* devices, int ndevices);
-/* Diagnostics of a multi-device handle (bench.py --single-process). out8: [0..4] mean device time (ms) of the phases of the
+/* Diagnostics of a multi-device handle (bench.py --single-process). out8 (NINE doubles): [0..4] mean device time (ms) of the phases of the
  * sampled steps on the first shard's stream — local step | waiting for the other shards' weights | global resampling + plan
  * | pack (peer stores of the migrating particles) | waiting for the other shards' records + unpack; [5] mean time the caller
  * spent inside phd_step_async (us); [6] mean time the slowest shard's worker spent issuing one step (us); [7] sampled steps
- * (phd_timing_reset(nav, n) samples every n-th step). p2p (may be NULL): [nshards][nshards] bytes, 1 where shard s stores
+ * (phd_timing_reset(nav, n) samples every n-th step); [8] as [6] without the waits for the other workers' event records. p2p (may be NULL): [nshards][nshards] bytes, 1 where shard s stores
  * into shard t's memory directly (peer access or the same device; phd_create_multi fails when a pair cannot).        */
 int            phd_multi_report(phd_navigator* nav, double* out8, uint8_t* p2p, int* nshards);
 const char*    phd_create_error(void);

@@ -348,13 +348,13 @@ class PHDNavigator:
     def multi_report(self):
         """diagnostics of a multi-device handle (phd_multi_report): per-phase device time of the sampled steps on the first
         shard's stream, the host's cost of posting / issuing a step, and which shard pairs exchange by direct peer access"""
-        out = np.zeros(8)
+        out = np.zeros(9)
         p2p = np.zeros(64 * 64, np.uint8)
         n = C.c_int32(0)
         self._check(self._lib.phd_multi_report(self._h, _ptr(out), p2p.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(n)))
         k = n.value
         names = ("local", "gather_wait", "global_and_plan", "pack", "exchange_wait_and_unpack")
-        return {"phase_ms": {nm: float(out[i]) for i, nm in enumerate(names)}, "post_us": float(out[5]), "issue_us": float(out[6]),
+        return {"phase_ms": {nm: float(out[i]) for i, nm in enumerate(names)}, "post_us": float(out[5]), "issue_us": float(out[6]), "issue_calls_us": float(out[8]),
                 "sampled_steps": int(out[7]), "shards": k, "p2p": p2p[:k * k].reshape(k, k).astype(bool).tolist()}
 
     def test_migration_plan(self, gsrc, particles_per_rank, world, rank, resampled=True):
