@@ -559,17 +559,24 @@ __device__ void jacobian_p(const DevParams& prm, const PoseD& pose, const double
 	double rc[9], jlocal[18];
 	conj_matrix(pose, rc);
 	const double cross[9] = {0, -diff[2], diff[1],  diff[2], 0, -diff[0],  -diff[1], diff[0], 0};
+	// (every index static: the small matrices stay in registers — left to the compiler's own unrolling they went to scratch)
+#pragma unroll
 	for (int i = 0; i < 3; i++) {
+#pragma unroll
 		for (int j = 0; j < 3; j++) {
 			double acc = 0;
+#pragma unroll
 			for (int k = 0; k < 3; k++) acc += (-1.0 * rc[i * 3 + k]) * cross[k * 3 + j];
 			jlocal[i * 6 + j]     = -1.0 * rc[i * 3 + j];
 			jlocal[i * 6 + 3 + j] = acc;
 		}
 	}
+#pragma unroll
 	for (int i = 0; i < 3; i++) {
+#pragma unroll
 		for (int j = 0; j < 6; j++) {
 			double acc = 0;
+#pragma unroll
 			for (int k = 0; k < 3; k++) acc += jp[i * 3 + k] * jlocal[k * 6 + j];
 			Jp[i * 6 + j] = acc;
 		}
@@ -580,8 +587,10 @@ __device__ void jacobian_p(const DevParams& prm, const PoseD& pose, const double
 __device__ __forceinline__ double pair_gradient(const DevParams& prm, const double* nu, const double* Jp, int t)
 {
 	double acc = 0;
+#pragma unroll
 	for (int b = 0; b < 3; b++) {
 		double u = 0;
+#pragma unroll
 		for (int e = 0; e < 3; e++) u += nu[e] * prm.Rinv[e * 3 + b];
 		acc += u * Jp[b * 6 + t];
 	}
@@ -711,8 +720,17 @@ __host__ __device__ inline size_t alpha_jscratch_doubles(int Jcap)
 // GRAD (with QUASI): also the pose gradient (:543-548). Every cluster is then enumerated literally and in the
 //                reference's order by wave 0 — TemperedAverage rewrites logcomp in place (MatrixExtensions.cs:429-431)
 //                and normalises over the whole array, so each cluster sees what the previous ones left.
+// gws (gradient mode): QGRAD_LDS_DOUBLES of LDS for the clusters of up to 5 rows — their matrix, Jacobians, member lists
+// and per-pairing gradient vectors. (They went through the particle's workspace in HBM, as the large clusters' do: a
+// dozen dependent trips to memory per cluster, and a typical pose has forty clusters of two or three rows, replayed in
+// order by one wave.)
+#define QGRAD_WAVE_DOUBLES (25 + 5 * 18 + 120 * 6 + 120 + 9)   // per wave: matrix, Jacobians, gradient vectors, log components | member lists
+#define QGRAD_LDS_DOUBLES (4 * QGRAD_WAVE_DOUBLES)           // (an even count: the dynamic LDS behind it stays 16-byte aligned)
+#define QGRAD_G2_CLUSTERS 64                                  // headers / weights of the first pass kept in LDS for the ordered replay
+#define QGRAD_G2_WEIGHTS 384
+#define QGRAD_HDR 10                                         // doubles per cluster in the particle's scratch: pairings, G[6], list offset, finite
 template <int ZB, bool QUASI, bool GRAD = false, int TAG = 0>
-__device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const StepBufs& a, int ncap, double* smem)
+__device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const StepBufs& a, int ncap, double* smem, double* gws = nullptr)
 {
 	constexpr int MP = ZB * 64;
 	constexpr int MW = ZB;   // 64-bit adjacency words per landmark
@@ -723,6 +741,9 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 	double* etab = red;                    // [256] exp table (filled before the cluster sums, once `red` is idle)
 	__shared__ int s_J, s_changed, s_nroots, s_big;
 	__shared__ double s_ccount, s_total;
+	__shared__ int s_ebump, s_g2lds;                                                    // gradient mode (see the first pass below)
+	__shared__ double s_g2[GRAD ? QGRAD_G2_CLUSTERS * QGRAD_HDR + QGRAD_G2_WEIGHTS : 2];
+	if (GRAD && threadIdx.x == 0) s_g2lds = 0;
 
 	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int M = a.M, cap = a.cap;
@@ -1262,6 +1283,139 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 			}
 		}
 		__syncthreads();
+		if (GRAD && gws && inlds) {
+			// Gradient mode, first pass: what a cluster of up to 5 rows contributes does not depend on the clusters before it
+			// except through the normalisation of TemperedAverage (MatrixExtensions.cs:400-440, over the whole logcomp array):
+			// its pairings, their log components and gradient vectors, the log-sum-exp, the weights exp(l - max) and the
+			// weighted gradient sum G are computed here, the clusters shared among the four waves; the ordered replay below
+			// (one wave) then only moves the weights into logcomp and divides G by the norm. Larger clusters (MurtyPairing with
+			// its cut on the array's stale entries) are left to the replay whole.
+			double* const wsm = gws + wv * QGRAD_WAVE_DOUBLES;
+			double* const gmat = wsm;                                  // [5][5]
+			double* const gjp = wsm + 25;                              // [5][18]
+			double (*gdv)[6] = (double (*)[6]) (wsm + 25 + 5 * 18);    // [120][6]
+			double* const glc = wsm + 25 + 5 * 18 + 120 * 6;           // [120]
+			int* const gL = (int*) (glc + 120);
+			int* const gZ = gL + 8;
+			// the particle's scratch: cluster headers | MeasurementJacobianP of every landmark (:591), computed here by all
+			// threads at once rather than by the one or two lanes a cluster has landmarks for | the clusters' weight lists
+			double* const jpall = gj + (size_t) QGRAD_HDR * JL;
+			double* const elist = jpall + (size_t) 18 * JL;
+			const int ecap = (int) alpha_jscratch_doubles(a.Jcap) - (QGRAD_HDR + 18) * JL;
+			const int gt = (lane < 6) ? lane : 0;
+			if (tid == 0) s_ebump = 0;
+			if (ecap > 0) {
+				for (int j = tid; j < J; j += 256) {
+					const double m3[3] = {lm[j], lm[JS + j], lm[2 * JS + j]};
+					jacobian_p(prm, pose, m3, jpall + (size_t) j * 18);
+				}
+			}
+			__threadfence_block();
+			__syncthreads();
+			for (int ri = wv; ri < nroots; ri += 4) {
+				const int root = roots[ri];
+				double* const h = gj + (size_t) ri * QGRAD_HDR;
+				int nl = 0, nz = 0;
+				for (int j0 = root; j0 < J; j0 += 64) {
+					const int j = j0 + lane;
+					const bool in = j < J && labl[j] == root;
+					const unsigned long long bal = ballot64(in);
+					const int pos = nl + __popcll(bal & lanemask_lt());
+					if (in && pos < 6) gL[pos] = j;
+					nl += __popcll(bal);
+				}
+				for (int k0 = 0; k0 < M; k0 += 64) {
+					const int k = k0 + lane;
+					const bool in = k < M && labz[k] == root;
+					const unsigned long long bal = ballot64(in);
+					const int pos = nz + __popcll(bal & lanemask_lt());
+					if (in && pos < 6) gZ[pos] = k;
+					nz += __popcll(bal);
+				}
+				const int nrow = nl + nz;
+				if (nrow > 5) {
+					if (lane == 0) h[0] = -1;   // the replay takes it whole
+					continue;
+				}
+				lds_fence();
+				if (lane < nrow * nrow) {
+					const int x = lane / nrow, y = lane - x * nrow;
+					double v = -INFINITY;
+					if (x < nl) {
+						const int j = gL[x];
+						if (y < nz) {
+							const int k = gZ[y];
+							if ((adj[(size_t) j * MW + (k >> 6)] >> (k & 63)) & 1ull) {
+								double dist = sqrt(quad_gen(prm.Rinv, zh[j] - zs[k * 3], zh[JS + j] - zs[k * 3 + 1], zh[2 * JS + j] - zs[k * 3 + 2]));
+								v = lpd[j] + logmult - 0.5 * dist * dist;
+							}
+						}
+						else if (y - nz == x) v = lmd[j];
+					}
+					else {
+						if (y < nz) { if (y == x - nl) v = prm.logkappa; }
+						else v = 0;
+					}
+					gmat[x * 5 + y] = v;
+				}
+				if (ecap <= 0) {
+					if (lane == 0) h[0] = -2;   // (a scratch too small for the lists: everything goes to the replay)
+					continue;
+				}
+				for (int e = lane; e < nl * 18; e += 64) gjp[e] = jpall[(size_t) gL[e / 18] * 18 + e % 18];
+				lds_fence();
+				const int mcount = cluster_enumerate_wave(gmat, nrow, J, glc, lane, [&](int m, unsigned int perm) {
+					double acc = 0;
+					for (int x = 0; x < nl; x++) {
+						const int y = pk_get(perm, x);
+						if (y >= nz) continue;
+						const int j = gL[x], k = gZ[y];
+						if (!((adj[(size_t) j * MW + (k >> 6)] >> (k & 63)) & 1ull)) continue;
+						const double nu[3] = {zs[k * 3] - zh[j], zs[k * 3 + 1] - zh[JS + j], zs[k * 3 + 2] - zh[2 * JS + j]};
+						acc += pair_gradient(prm, nu, gjp + x * 18, gt);
+					}
+					if (lane < 6) gdv[m][lane] = acc;
+				});
+				// LogSumExp(logcomp, 0, m), MatrixExtensions.cs:361-389
+				double mx = -INFINITY, value = 0;
+				for (int i = 0; i < mcount; i++) mx = fmax(mx, glc[i]);
+				const bool finite = !(isinf(mx) && mx < 0);
+				double lse = -INFINITY;
+				if (finite) {
+					for (int i = 0; i < mcount; i++) value += exp(glc[i] - mx);   // (as cluster_enumerate does: the value of this mode equals the value kernel's bit for bit)
+					lse = mx + log(value);
+				}
+				int off = 0;
+				if (lane == 0) off = atomicAdd(&s_ebump, mcount);
+				off = __shfl(off, 0, 64);
+				if (lane == 0) res[ri] = lse;
+				if (off + mcount > ecap) {
+					if (lane == 0) h[0] = -2;   // no room for its weights: the replay enumerates it again
+					continue;
+				}
+				lds_fence();
+				if (finite) {
+					for (int i = lane; i < mcount; i += 64) glc[i] = exp_neg(glc[i] - mx, etab);
+					lds_fence();
+				}
+				for (int i = lane; i < mcount; i += 64) elist[off + i] = glc[i];   // (all -inf: the raw components stay, as in the reference)
+				double G = 0;
+				if (finite) for (int i = 0; i < mcount; i++) G += glc[i] * gdv[i][gt];
+				if (lane < 6) h[1 + lane] = G;
+				if (lane == 0) { h[0] = (double) mcount; h[7] = (double) off; h[8] = finite ? 1.0 : 0.0; }
+			}
+			__threadfence_block();
+			__syncthreads();
+			// what the replay reads per cluster, brought into LDS in one go when it is little (it usually is: forty clusters, a
+			// few weights each): the replay is one wave walking the clusters in order, every read a dependent trip otherwise
+			if (nroots <= QGRAD_G2_CLUSTERS && s_ebump <= QGRAD_G2_WEIGHTS) {
+				for (int i = tid; i < nroots * QGRAD_HDR; i += 256) s_g2[i] = gj[i];
+				for (int i = tid; i < s_ebump; i += 256) s_g2[QGRAD_G2_CLUSTERS * QGRAD_HDR + i] = elist[i];
+				if (tid == 0) s_g2lds = 1;
+			}
+			__syncthreads();
+		}
+		PHD_STAMP(8);
 		if (s_big) {
 			// Some cluster has more than 5 rows: it is enumerated best-first (MurtyPairing) under the
 			// early-exit test of PHDNavigator.cs:503, which reads logcomp[m] as left behind by the clusters
@@ -1278,7 +1432,7 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 				MurtyNodes* nodes = a.murty + p;
 				const int gt = (lane < 6) ? lane : 0;   // gradient component of this lane
 				double gacc = 0;
-				for (int ri = 0; ri <= lastbig; ri++) {
+				auto replay_one = [&](int ri) {
 					const int root = roots[ri];
 					int nl = 0, nz = 0;
 					for (int j0 = root; j0 < J; j0 += 64) nl += __popcll(ballot64(j0 + lane < J && labl[j0 + lane] == root));
@@ -1294,9 +1448,14 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 						if (!a.bigws || nrow > MURTY_NBIG || off + need > a.bigws_bytes) {
 							// more rows than the solver takes, or the slab is used up: the step is dropped (PHD_ERR_ASSOCIATION)
 							if (lane == 0) { atomicOr(a.flags, PHD_FLAG_BIG_CLUSTER); res[ri] = 0; }
-							continue;
+							return;
 						}
 						nd = murty_ws_carve(a.bigws + off, nrow);
+					}
+					double (*dvec)[6] = nodes->dvec;
+					if (GRAD && gws && nrow <= 5) {   // a small cluster of the gradient replay: everything in LDS
+						nd.reduced = gws; nd.jp = gws + 25; dvec = (double (*)[6]) (gws + 25 + 5 * 18);
+						nd.L = (int*) (gws + 25 + 5 * 18 + 120 * 6 + 120); nd.Z = nd.L + 8;
 					}
 					nl = 0; nz = 0;
 					for (int j0 = root; j0 < J; j0 += 64) {
@@ -1369,7 +1528,7 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 						if (GRAD) {
 							mcount = cluster_enumerate_wave(mat, nrow, J, ws.logcomp, lane, [&](int m, unsigned int perm) {
 								const double g = pairing_gradient([&](int x) { return pk_get(perm, x); });
-								if (lane < 6) nodes->dvec[m][lane] = g;
+								if (lane < 6) dvec[m][lane] = g;
 							});
 						}
 						else {
@@ -1383,7 +1542,7 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 							if (!GRAD) return;
 							double g = 0;
 							if (!unsolved) g = pairing_gradient(colof);
-							if (lane < 6) nodes->dvec[m][lane] = g;
+							if (lane < 6) dvec[m][lane] = g;
 						});
 					}
 					if (mcount >= 0) {
@@ -1417,11 +1576,39 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 							double val = 0;
 							for (int i = 0; i < mcount; i++) {
 								const double wn = (norm == 0) ? ws.logcomp[i] : ws.logcomp[i] / norm;
-								val += wn * nodes->dvec[i][gt];
+								val += wn * dvec[i][gt];
 							}
 							gacc += val;
 						}
 					}
+				};
+				for (int ri = 0; ri <= lastbig; ri++) {
+					if (GRAD && gws && inlds) {
+						// a cluster the four waves have already enumerated: only what depends on the clusters before it is left —
+						// its weights take their place in logcomp, which TemperedAverage normalises as a whole
+						const double* h = s_g2lds ? s_g2 + ri * QGRAD_HDR : gj + (size_t) ri * QGRAD_HDR;
+						const int m = (int) h[0];
+						if (m >= 0) {
+							const double* el = (s_g2lds ? s_g2 + QGRAD_G2_CLUSTERS * QGRAD_HDR : gj + (size_t) (QGRAD_HDR + 18) * JL) + (int) h[7];
+							for (int i = lane; i < m; i += 64) ws.logcomp[i] = el[i];
+							lds_fence();
+							if (h[8] != 0) {
+								double part = 0;
+								if (a.qavg == 0) {
+									for (int i = lane; i < MURTY_OUT; i += 64) part += ws.logcomp[i] * ws.logcomp[i];
+								}
+								else {
+									for (int i = lane; i < m; i += 64) part += ws.logcomp[i];
+								}
+#pragma unroll
+								for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+								const double norm = (a.qavg == 0) ? sqrt(part) : part;
+								gacc += (norm == 0) ? h[1 + gt] : h[1 + gt] / norm;
+							}
+							continue;
+						}
+					}
+					replay_one(ri);
 				}
 				if (GRAD && lane < 6) a.qgrad[(size_t) p * 6 + lane] = gacc;
 			}
@@ -1450,7 +1637,7 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 		__syncthreads();
 	}
 	PHD_STAMP(7);
-	PHD_STAMP_FLUSH(3, 8);
+	PHD_STAMP_FLUSH(3, 9);
 	if (tid == 0) {
 		a.setll[p] = s_total;
 		if (!QUASI) {
@@ -1471,11 +1658,15 @@ __global__ __launch_bounds__(256, PHD_ASSOC_WAVES) void k_alpha_assoc(const DevP
 }
 
 // one workgroup per candidate pose (the smoother's pose x landmark x measurement batches)
+#ifndef PHD_QGRAD_WAVES
+#define PHD_QGRAD_WAVES 2   // waves per SIMD the register allocation aims at: the gradient replay does not fit 128 registers
+#endif                      // (at four waves per SIMD it ran out of 1.3 KB of scratch per lane, 18 times the value kernel's time)
 template <int ZB>
-__global__ __launch_bounds__(256, 4) void k_quasi_setll_grad(const DevParams prm, const StepBufs a, int ncap)
+__global__ __launch_bounds__(256, PHD_QGRAD_WAVES) void k_quasi_setll_grad(const DevParams prm, const StepBufs a, int ncap)
 {
 	extern __shared__ __align__(16) double smem[];
-	alpha_assoc_body<ZB, true, true>(prm, a, ncap, smem);
+	__shared__ __align__(16) double gws[QGRAD_LDS_DOUBLES];
+	alpha_assoc_body<ZB, true, true>(prm, a, ncap, smem, gws);
 }
 
 template <int ZB>

@@ -13,9 +13,10 @@
 #include "phd_device.h"
 
 #ifndef SW_TILE1
-#define SW_TILE1  192   // prior components staged per LDS tile in the one-block kernel (up to 64 measurements): 128 or 192. With 192
-#endif                  // three waves share the dear part of the staging; the kernel's LDS then just fits four workgroups per CU.
-                        // The two- and four-block kernels (more partial-sum arrays) keep 128.
+#define SW_TILE1  128   // prior components staged per LDS tile in the one-block kernel (up to 64 measurements): 128 or 192. With 192
+#endif                  // three waves share the dear part of the staging (and the kernel's LDS just fits four workgroups per CU):
+                        // measured, no change (0.2007 vs 0.2003 ms) — the kernel is bound by the instructions it issues, not by the
+                        // longest wave. The two- and four-block kernels (more partial-sum arrays) are 128 either way.
 #define SW_REC    20    // doubles per staged component: zh[3] G[6] lw | m[3] Gm[6] lwm  (two gauss_logw records)
 #define SW_UMAX   16    // measurements still unexplored when the density part leaves the pair loop (see the sweep)
 
@@ -409,8 +410,9 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 #ifndef PHD_SWEEP_WAVES
 #define PHD_SWEEP_WAVES 4
 #endif
+// (four measurement blocks per lane need 220 registers: two waves per SIMD is what that kernel gets, and what it asks for)
 template <int ZB, bool HALF = false>
-__global__ __launch_bounds__(256, PHD_SWEEP_WAVES) void k_sweep(const DevParams prm, const StepBufs a)
+__global__ __launch_bounds__(256, (ZB == 4 ? 2 : PHD_SWEEP_WAVES)) void k_sweep(const DevParams prm, const StepBufs a)
 {
 	__shared__ __align__(16) double pool[SweepLds<ZB>::doubles];
 	sweep_body<ZB, HALF>(prm, a, pool);
