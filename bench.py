@@ -319,6 +319,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    host_issue = time.perf_counter() - t0      # the host's own time to issue the steps (it runs ahead of the device)
     barrier()
     elapsed = time.perf_counter() - t0
     if use_dist:
@@ -501,6 +502,7 @@ def main():
                                       % (args.config, P, Cc, M, args.weights),
                           "particles_per_gpu": P, "components": Cc, "measurements": M, "max_quantity": maxq,
                           "parallelism": "particles sharded x%d" % world}}
+        out["host_issue_us_per_step"] = host_issue / args.steps * 1e6   # time inside the step calls, one caller thread
         if use_dist:
             out["rccl_ranks"] = dist.get_world_size()
         if kernels:

@@ -39,6 +39,7 @@ public class PhdHipLib
 	const string Lib = "libphdhip.so";
 	[DllImport(Lib)] public extern static IntPtr phd_create(ref PhdParams p, int device);
 	[DllImport(Lib)] public extern static IntPtr phd_create_multi(ref PhdParams p, int[] devices, int ndevices);
+	[DllImport(Lib)] public extern static int    phd_multi_report(HandleRef nav, double[] out9, byte[] p2p, out int nshards);
 	[DllImport(Lib)] public extern static IntPtr phd_create_error();
 	[DllImport(Lib)] public extern static void   phd_destroy(HandleRef nav);
 	[DllImport(Lib)] public extern static IntPtr phd_last_error(HandleRef nav);
