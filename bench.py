@@ -62,7 +62,7 @@ def launch_ranks(args):
     """`bench.py --gpus N` started as ONE process: start the N ranks as children (torch.distributed.run, one per GPU) and
     pass rank 0's JSON line through. Nothing here touches a GPU (counting devices does not initialise HIP on this image);
     the current process is never re-executed."""
-    have = count_gpus_without_hip()
+    have = count_gpus_without_hip(args.gpus)
     if have < args.gpus:
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible to this process; refusing to report a %d-GPU number "
                          "from fewer devices" % (args.gpus, have, args.gpus))
@@ -80,7 +80,7 @@ def launch_ranks(args):
     return 0
 
 
-def count_gpus_without_hip():
+def count_gpus_without_hip(want=1):
     """GPUs this process would see, counted without loading or initialising the HIP runtime: the parent of the rank
     processes must stay GPU-free (a process that has initialised the GPU must not start other programs on this pool).
     KFD's topology in sysfs lists every node of the host; a GPU node has simd_count > 0 and counts when its DRM render node
@@ -107,13 +107,14 @@ def count_gpus_without_hip():
                 pass
     except OSError:
         n = 0
-    if n == 0:
-        # no KFD topology to read (unusual): ask a short-lived child, which may initialise whatever it likes
+    if n < want:
+        # fewer than asked for by that count (no KFD topology to read, or render nodes named otherwise): ask a short-lived
+        # child, which may initialise whatever it likes, before refusing anything
         try:
             out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
-            n = int(out.stdout.strip().splitlines()[-1])
+            n = max(n, int(out.stdout.strip().splitlines()[-1]))
         except Exception:
-            n = 0
+            pass
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:

@@ -227,11 +227,66 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 		int n = 256;                                      // (at least the width of the register sort: small maps, too, skip the barrier-per-stage version)
 		while (n < ne && n < NS) n <<= 1;                 // width of the first pass
 		int taken = 0;                                    // emitted entries consumed so far
-		bool first = true;
+		bool first = true, prefilled = false;
+		// Only the `cut` heaviest entries are kept, and a sort costs by its width: when more than 1024 entries were emitted
+		// (config B's survey frame: 1080; config S: thousands, several passes of the full width), a histogram over the weights'
+		// leading bits (exponent and five mantissa bits, counted from MinWeight up: every emitted weight is at least that)
+		// finds the bin the cut-th heaviest entry lies in, and only the entries from that bin up are sorted, in one pass of the
+		// smallest width that holds them. Nothing changes in the order of what is kept: whole bins are taken.
+		const int xsize = lay.scan - lay.x;
+		if (ne > 1024 && cut > 0 && xsize >= NS + 520) {
+			int* const hist = (int*) (smem + lay.x + NS);   // [1024] behind the two sort arrays
+			int& s_T = hist[1024];
+			int& s_cnt = hist[1025];
+			int& s_fill = hist[1026];
+			const unsigned int base = (unsigned int) (((unsigned long long) __double_as_longlong(prm.minw) << 1) >> 48);
+			auto bin_of = [&](double w) {
+				const unsigned int k = (unsigned int) (((unsigned long long) __double_as_longlong(w) << 1) >> 48);
+				return (int) min(max((int) k - (int) base, 0), 1023);
+			};
+			for (int t = tid; t < 1027; t += 256) hist[t] = 0;
+			__syncthreads();
+			for (int e = tid; e < ne; e += 256) atomicAdd(&hist[bin_of(a.emit_w[eb + e])], 1);
+			__syncthreads();
+			if (wv == 0) {   // from the top bin down: the first bin at which `cut` entries are reached. Lane l: bins 1023 - 16 l .. 1008 - 16 l
+				int mine = 0;
+#pragma unroll
+				for (int q = 0; q < 16; q++) mine += hist[1023 - (16 * lane + q)];
+				int incl = mine;
+#pragma unroll
+				for (int o = 1; o < 64; o <<= 1) {
+					const int y = __shfl_up(incl, o, 64);
+					if (lane >= o) incl += y;
+				}
+				const int before = incl - mine;
+				if (before < cut && cut <= incl) {
+					int run = before, T = 0;
+					for (int q = 0; q < 16; q++) {
+						run += hist[1023 - (16 * lane + q)];
+						if (run >= cut) { T = 1023 - (16 * lane + q); break; }
+					}
+					s_T = T; s_cnt = run;
+				}
+			}
+			__syncthreads();
+			const int T = s_T, cnt = s_cnt;
+			if (cnt <= NS) {   // (else: a crowd of equal weights at the cut — the passes below take everything)
+				n = 256;
+				while (n < cnt) n <<= 1;
+				for (int e = tid; e < ne; e += 256) {
+					const double w = a.emit_w[eb + e];
+					if (e < NS) w2[e] = prune_next32(w, sbits);
+					if (bin_of(w) >= T) sw[atomicAdd(&s_fill, 1)] = prune_pack32(w, e, sbits);
+				}
+				for (int t = cnt + tid; t < n; t += 256) sw[t] = 0u;
+				taken = ne;
+				prefilled = true;
+			}
+		}
 		while (first || taken < ne) {
 			// first pass: fill [0, n); later passes (n == NS): refill the worse half [n/2, n)
 			const int from = first ? 0 : (n >> 1);
-			for (int t = from + tid; t < n; t += 256) {
+			for (int t = from + tid; t < n && !prefilled; t += 256) {
 				int e = taken + (t - from);
 				unsigned int word = 0u;
 				if (e < ne) {
@@ -241,7 +296,7 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 				}
 				sw[t] = word;
 			}
-			taken += n - from;
+			if (!prefilled) taken += n - from;
 			first = false;
 			__syncthreads();
 			PHD_STAMP(6);    // (the last pass: fill | sort | runs)

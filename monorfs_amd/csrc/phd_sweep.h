@@ -12,6 +12,9 @@
 #pragma once
 #include "phd_device.h"
 
+#ifndef SW_FIRST1
+#define SW_FIRST1 128   // length of the first tile of the one-block kernel (64 or SW_TILE1)
+#endif
 #ifndef SW_TILE1
 #define SW_TILE1  128   // prior components staged per LDS tile in the one-block kernel (up to 64 measurements): 128 or 192. With 192
 #endif                  // three waves share the dear part of the staging (and the kernel's LDS just fits four workgroups per CU):
@@ -162,7 +165,10 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 	// wave reduction per tile. The terms are the same; only their order of addition differs.
 	bool compact = false;   // block-uniform
 	constexpr int SW_TILE = L::T, SW_NMAP = L::NMAP, SW_MAPEACH = L::MAPEACH;
-	for (int c0 = 0; c0 < n; c0 += SW_TILE) {
+	// (the first tile may be shorter — SW_FIRST1: the sooner the tile ends at which at most SW_UMAX measurements are still
+	// unexplored, the sooner the Explored density leaves the pair loop)
+	constexpr int SW_FIRST = (ZB == 1 && SW_FIRST1 < SW_TILE) ? SW_FIRST1 : SW_TILE;
+	for (int c0 = 0, tl = SW_FIRST; c0 < n; c0 += tl, tl = SW_TILE) {
 		{   // the measurement-space record of a component (h(m), S^-1, PD: ~650 dependent FP64 instructions, :857-870) is built by
 			// one thread of the last SW_TILE / 64 waves; its map-space record (P^-1: ~110) by the first waves, SW_MAPEACH
 			// components per thread — with 192-component tiles three waves share the dear part and one takes the cheap one
@@ -170,7 +176,7 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 #pragma unroll
 				for (int q = 0; q < SW_MAPEACH; q++) {
 					const int cl = tid + q * SW_NMAP, c = c0 + cl;
-					if (c < n) {
+					if (c < n && cl < tl) {
 						double P[6], m[3], Pi[6], det;
 #pragma unroll
 						for (int t = 0; t < 6; t++) P[t] = vin.P[t][sb + c];
@@ -186,7 +192,7 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 				const int cl = tid - SW_NMAP, c = c0 + cl;
 				bool mis = false;
 				double wm = 0;
-				if (c < n) {
+				if (c < n && cl < tl) {
 					double* tt = tile + cl * SW_REC;
 					double P[6], m[3];
 #pragma unroll
@@ -227,7 +233,7 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 		}
 		__syncthreads();
 		load_z();
-		const int cend = min(SW_TILE, n - c0);
+		const int cend = min(tl, n - c0);
 		if (compact) {
 			const int nu = s_nu;
 			for (int u = wv; u < nu; u += 4) {   // (wave-uniform) this wave alone adds to s_du[u]
