@@ -17,7 +17,7 @@ from monorfs_amd.synth import Frame
 
 def one(seq, nsteps):
     rng = np.random.default_rng(5000 + seq)
-    shards = int(rng.choice([2, 3, 4, 6]))
+    shards = int(rng.choice([2, 3, 4, 6, 8]))
     P = shards * int(rng.choice([16, 64, 200]))
     C = int(rng.choice([30, 90]))
     M = int(rng.choice([8, 24, 60]))
@@ -34,9 +34,19 @@ def one(seq, nsteps):
         u = float(rng.uniform(0.01, 0.99))
         reading = rng.normal(0, 1, 6) * [0.01, 0.01, 0.01, 0.003, 0.003, 0.003]
         noise = rng.normal(0, 1, (P, 6)) * [5e-3, 5e-3, 5e-3, 2e-4, 2e-4, 2e-4]
-        for nav in (single, multi):
-            nav.UpdateOdometry(None, reading, noise)
-            nav.SlamUpdate(None, z, u_resample=u)
+        if step % 5 == 4:
+            # a batch of steps posted back to back (the multi handle's workers run ahead of the caller), one wait at the end
+            us = [float(x) for x in rng.uniform(0.01, 0.99, int(rng.integers(2, 6)))]
+            for nav in (single, multi):
+                nav.UpdateOdometry(None, reading, noise)
+                nav.set_measurements(z)
+                for ub in us:
+                    nav.step_async(ub)
+                nav.sync()
+        else:
+            for nav in (single, multi):
+                nav.UpdateOdometry(None, reading, noise)
+                nav.SlamUpdate(None, z, u_resample=u)
         assert np.array_equal(single.VehicleWeights, multi.VehicleWeights), (seq, step, "weights")
         assert np.array_equal(single.poses(), multi.poses()), (seq, step, "poses")
         assert single.BestParticle == multi.BestParticle, (seq, step, "best")
