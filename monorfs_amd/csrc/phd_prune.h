@@ -885,7 +885,10 @@ PHD_REF_ARITH
 	PHD_STAMP_FLUSH(2, 12);
 }
 
-__global__ __launch_bounds__(256, 4) void k_prune_merge(const DevParams prm, const StepBufs a, int cutcap)
+#ifndef PHD_PRUNE_WAVES
+#define PHD_PRUNE_WAVES 4
+#endif
+__global__ __launch_bounds__(256, PHD_PRUNE_WAVES) void k_prune_merge(const DevParams prm, const StepBufs a, int cutcap)
 {
 	extern __shared__ __align__(16) double smem[];
 	prune_merge_body(prm, a, cutcap, smem);
