@@ -284,3 +284,64 @@ def test_non_finite_input_is_a_bad_argument(nav_mod):
     nav.SlamUpdate(None, f.z, u_resample=0.6)   # and the handle goes on
     assert np.isclose(nav.VehicleWeights.sum(), 1.0)
     nav.close()
+
+
+def test_resample_every_launch_shape_and_degenerate_weights(nav_mod):
+    """k_normalise_resample decides a particle's slots from prefix sums with an error margin and falls back to the
+    recurrence itself (PHDNavigator.cs:724-760) when a boundary is closer than the margin. Sizes around every change of its
+    launch shape (256 / 512 / 1024 threads, chunks of 1, 2, ... weights), and weight vectors that sit ON the boundaries
+    (exactly uniform: every slot boundary is a tie, the fallback runs), vectors of mostly zeros, one particle holding
+    everything, u at both ends of [0, 1): sources and BestParticle bit-exact against the sequential recurrence."""
+    p = prm3d_defaults(max_particles=4, max_components=600, max_measurements=8)
+    nav = nav_mod.PHDNavigator(p, particlecount=4)
+    rng = np.random.default_rng(11)
+    sizes = [1, 2, 3, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1000, 1023, 1024, 1025, 4095, 4096, 4097, 8192, 12345]
+    for P in sizes:
+        vectors = {"uniform": np.full(P, 1.0 / P)}
+        w = rng.random(P) ** 6
+        vectors["random^6"] = w / w.sum()
+        w = rng.random(P) * (rng.random(P) < 0.1)
+        w[rng.integers(P)] += 1e-3
+        vectors["nine tenths zero"] = w / w.sum()
+        for at in sorted({0, P // 2, P - 1}):
+            w = np.zeros(P)
+            w[at] = 1.0
+            vectors["all in %d" % at] = w
+        w = np.where(np.arange(P) % 2 == 0, 1.0, 1e-12)
+        vectors["alternating"] = w / w.sum()
+        for name, w in vectors.items():
+            for u in (0.0, 2.0 ** -60, 0.5, 1.0 - 2.0 ** -53):
+                src, best = nav.ResampleParticles(w, u)
+                osrc, obest = orc.resample(w, u)
+                assert np.array_equal(src, osrc), "P=%d %s u=%g: %d sources differ" % (P, name, u, np.count_nonzero(src != osrc))
+                assert best == obest, "P=%d %s u=%g: best %d, oracle %d" % (P, name, u, best, obest)
+            assert nav.ParticleDepleted(w) == orc.particle_depleted(p, w), "P=%d %s" % (P, name)
+    nav.close()
+
+
+@pytest.mark.parametrize("holder", [0, 37, 63])
+def test_multi_handle_when_one_particle_takes_every_slot(nav_mod, holder):
+    """The extreme of the migration: one particle holds all the weight, so after the step every slot of every shard has
+    it as its source — each other shard receives ONE record that all its slots share, the holder's shard sends to everybody.
+    Then a second step on the cloned set. Bit for bit the single handle's."""
+    shards, P = 4, 64
+    f = Frame(P, 60, 14, 909 + holder, weight_profile="steady")
+    p = prm3d_defaults(max_particles=P, max_components=600, max_measurements=14)
+    single = nav_mod.PHDNavigator(p, particlecount=P)
+    multi = nav_mod.PHDNavigator(p, particlecount=P, devices=[0] * shards)
+    w = np.zeros(P)
+    w[holder] = 1.0
+    for nav in (single, multi):
+        nav.upload_state(f.planes(), f.counts, f.poses, w)
+        nav.SlamUpdate(None, f.z, u_resample=0.41)
+    src, resampled = single.resample_sources()
+    assert resampled and np.all(src == holder)
+    same_state(single, multi, range(P))
+    rng = np.random.default_rng(holder)
+    noise = rng.normal(0, 1, (P, 6)) * [5e-3, 5e-3, 5e-3, 2e-4, 2e-4, 2e-4]
+    for nav in (single, multi):
+        nav.UpdateOdometry(None, np.zeros(6), noise)
+        nav.SlamUpdate(None, f.z[:9], u_resample=0.83)
+    same_state(single, multi, range(P))
+    single.close()
+    multi.close()
