@@ -47,6 +47,24 @@ __device__ __forceinline__ unsigned int pk_next(unsigned int perm, int n, int me
 	return pk_reverse(perm, measurestart, n);
 }
 
+// the m-th permutation of 0 .. n - 1 (n <= 5) in lexicographic order, the identity being number 0: what pk_next reaches from
+// the identity in m steps when measurestart == n
+__device__ __forceinline__ unsigned int pk_unrank(int m, int n)
+{
+	unsigned int avail = 0x43210u, perm = 0x43210u & ~((1u << (4 * n)) - 1u);
+	int fct = 1;
+	for (int i = 2; i < n; i++) fct *= i;   // (n - 1)!
+	for (int i = 0; i < n; i++) {
+		int d = 0;
+		while (m >= fct) { m -= fct; d++; }
+		perm |= ((avail >> (4 * d)) & 15u) << (4 * i);
+		const unsigned int low = (1u << (4 * d)) - 1u;
+		avail = (avail & low) | ((avail >> 4) & ~low);
+		if (n - 1 - i > 1) fct /= (n - 1 - i);
+	}
+	return perm;
+}
+
 // the first n (<= 5) 12-bit fields of v in ascending order (9-comparator network)
 __device__ __forceinline__ unsigned long long pk_sort5(unsigned long long v, int n)
 {
@@ -1312,8 +1330,61 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 			}
 			__threadfence_block();
 			__syncthreads();
+			// A cluster of ONE landmark and ONE measurement — in a scene whose landmarks stand apart, nearly every cluster — needs
+			// no wave: its two pairings are (detection | -) and (misdetection | clutter), in this order when the map estimate
+			// has at least as many landmarks as the cluster has rows (LexicographicalPairing's `modelsize`; J >= 5 as in the
+			// value kernel's register path). One LANE per such cluster computes what the loop below computes for it, in the same
+			// arithmetic and order; the loop then passes it by.
+			const bool pairfast = J >= 5 && ecap > 0;
+			if (pairfast) {
+				for (int ri = tid; ri < nroots; ri += 256) {
+					const int root = roots[ri];
+					if (cnt[root] != 0x10001) continue;
+					const int j = (int) (memL[root] & 4095), k = (int) (memZ[root] & 4095);
+					double* const h = gj + (size_t) ri * QGRAD_HDR;
+					const bool gated = (adj[(size_t) j * MW + (k >> 6)] >> (k & 63)) & 1ull;
+					double c0 = -INFINITY;
+					if (gated) {
+						double dist = sqrt(quad_gen(prm.Rinv, zh[j] - zs[k * 3], zh[JS + j] - zs[k * 3 + 1], zh[2 * JS + j] - zs[k * 3 + 2]));
+						c0 = lpd[j] + logmult - 0.5 * dist * dist;
+					}
+					c0 = (0.0 + c0) + 0.0;                            // AssignmentValue: rows in order, from 0
+					const double c1 = (0.0 + lmd[j]) + prm.logkappa;
+					// LogSumExp(logcomp, 0, 2), MatrixExtensions.cs:361-389
+					const double mx = fmax(fmax(-INFINITY, c0), c1);
+					const bool finite = !(isinf(mx) && mx < 0);
+					double lse = -INFINITY, w0 = c0, w1 = c1;
+					if (finite) {
+						double value = 0;
+						value += exp(c0 - mx);
+						value += exp(c1 - mx);
+						lse = mx + log(value);
+						w0 = exp_neg(c0 - mx, etab);
+						w1 = exp_neg(c1 - mx, etab);
+					}
+					res[ri] = lse;
+					const int off = atomicAdd(&s_ebump, 2);
+					if (off + 2 > ecap) { h[0] = -2; continue; }     // no room for its weights: the replay enumerates it again
+					elist[off] = w0;
+					elist[off + 1] = w1;
+					double G[6] = {0, 0, 0, 0, 0, 0};
+					if (finite && gated) {
+						const double nu[3] = {zs[k * 3] - zh[j], zs[k * 3 + 1] - zh[JS + j], zs[k * 3 + 2] - zh[2 * JS + j]};
+						const double* Jp = jpall + (size_t) j * 18;
+#pragma unroll
+						for (int t = 0; t < 6; t++) G[t] = w0 * (0.0 + pair_gradient(prm, nu, Jp, t));
+					}
+					h[0] = 2.0;
+#pragma unroll
+					for (int t = 0; t < 6; t++) h[1 + t] = G[t];
+					h[7] = (double) off;
+					h[8] = finite ? 1.0 : 0.0;
+				}
+			}
+			PHD_STAMP(9);
 			for (int ri = wv; ri < nroots; ri += 4) {
 				const int root = roots[ri];
+				if (pairfast && cnt[root] == 0x10001) continue;
 				double* const h = gj + (size_t) ri * QGRAD_HDR;
 				int nl = 0, nz = 0;
 				for (int j0 = root; j0 < J; j0 += 64) {
@@ -1362,29 +1433,97 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 					if (lane == 0) h[0] = -2;   // (a scratch too small for the lists: everything goes to the replay)
 					continue;
 				}
-				for (int e = lane; e < nl * 18; e += 64) gjp[e] = jpall[(size_t) gL[e / 18] * 18 + e % 18];
-				lds_fence();
-				const int mcount = cluster_enumerate_wave(gmat, nrow, J, glc, lane, [&](int m, unsigned int perm) {
-					double acc = 0;
-					for (int x = 0; x < nl; x++) {
-						const int y = pk_get(perm, x);
-						if (y >= nz) continue;
-						const int j = gL[x], k = gZ[y];
-						if (!((adj[(size_t) j * MW + (k >> 6)] >> (k & 63)) & 1ull)) continue;
-						const double nu[3] = {zs[k * 3] - zh[j], zs[k * 3 + 1] - zh[JS + j], zs[k * 3 + 2] - zh[2 * JS + j]};
-						acc += pair_gradient(prm, nu, gjp + x * 18, gt);
-					}
-					if (lane < 6) gdv[m][lane] = acc;
-				});
-				// LogSumExp(logcomp, 0, m), MatrixExtensions.cs:361-389
+				int mcount;
 				double mx = -INFINITY, value = 0;
-				for (int i = 0; i < mcount; i++) mx = fmax(mx, glc[i]);
-				const bool finite = !(isinf(mx) && mx < 0);
-				double lse = -INFINITY;
-				if (finite) {
-					for (int i = 0; i < mcount; i++) value += exp(glc[i] - mx);   // (as cluster_enumerate does: the value of this mode equals the value kernel's bit for bit)
-					lse = mx + log(value);
+				if (nrow <= J) {
+					// The map estimate has at least as many landmarks as the cluster has rows: LexicographicalPairing walks all n!
+					// pairings in plain lexicographic order from the identity. One LANE per pairing instead of the walk: first the
+					// pair gradients dlldp[x, y] (:605-608), once each, into the Jacobians' place (lane 6 (x nz + y) + t: component
+					// t); then every lane unranks its pairing and adds up its log component and its gradient vector — rows in
+					// order, as the walk does.
+					double* const pgt = gjp;   // [x * 4 + y][6]; x * 4 + y <= 12 with nl + nz <= 5
+					const int npair = nl * nz;
+					bool g = false;
+					{
+						const int pr = lane / 6, t = lane - 6 * pr;
+						if (pr < npair) {
+							const int x = pr / nz, y = pr - x * nz;
+							const int j = gL[x], k = gZ[y];
+							g = (adj[(size_t) j * MW + (k >> 6)] >> (k & 63)) & 1ull;
+							double v = 0;
+							if (g) {
+								const double nu[3] = {zs[k * 3] - zh[j], zs[k * 3 + 1] - zh[JS + j], zs[k * 3 + 2] - zh[2 * JS + j]};
+								v = pair_gradient(prm, nu, jpall + (size_t) j * 18, t);
+							}
+							pgt[(x * 4 + y) * 6 + t] = v;
+						}
+					}
+					const unsigned long long gb = ballot64(g);
+					unsigned int gmask = 0;   // bit x * 4 + y: the pair is gated
+					for (int pr = 0; pr < npair; pr++) {
+						if ((gb >> (6 * pr)) & 1ull) gmask |= 1u << ((pr / nz) * 4 + (pr % nz));
+					}
+					lds_fence();
+					mcount = 1;
+					for (int i = 2; i <= nrow; i++) mcount *= i;
+					double vv[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+					for (int pass = 0; pass < 2; pass++) {
+						const int m = lane + 64 * pass;
+						if (m < mcount) {
+							const unsigned int perm = pk_unrank(m, nrow);
+							double v = 0;
+							for (int i = 0; i < nrow; i++) v += gmat[i * 5 + pk_get(perm, i)];   // AssignmentValue
+							double acc[6] = {0, 0, 0, 0, 0, 0};
+							for (int x = 0; x < nl; x++) {
+								const int y = pk_get(perm, x);
+								if (y < nz && ((gmask >> (x * 4 + y)) & 1u)) {
+#pragma unroll
+									for (int t = 0; t < 6; t++) acc[t] += pgt[(x * 4 + y) * 6 + t];
+								}
+							}
+							glc[m] = v;
+#pragma unroll
+							for (int t = 0; t < 6; t++) gdv[m][t] = acc[t];
+							vv[pass] = v;
+						}
+					}
+					// LogSumExp(logcomp, 0, m), MatrixExtensions.cs:361-389: the terms by their lanes, the sum in the walk's order
+					mx = fmax(vv[0], vv[1]);
+#pragma unroll
+					for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+					if (!(isinf(mx) && mx < 0)) {
+						const double e0 = (lane < mcount) ? exp(vv[0] - mx) : 0.0, e1 = (lane + 64 < mcount) ? exp(vv[1] - mx) : 0.0;
+						auto rld = [](double v, int l) {
+							return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+						};
+						for (int i = 0; i < mcount; i++) value += (i < 64) ? rld(e0, i) : rld(e1, i - 64);
+					}
+					lds_fence();
 				}
+				else {
+					for (int e = lane; e < nl * 18; e += 64) gjp[e] = jpall[(size_t) gL[e / 18] * 18 + e % 18];
+					lds_fence();
+					mcount = cluster_enumerate_wave(gmat, nrow, J, glc, lane, [&](int m, unsigned int perm) {
+						double acc = 0;
+						for (int x = 0; x < nl; x++) {
+							const int y = pk_get(perm, x);
+							if (y >= nz) continue;
+							const int j = gL[x], k = gZ[y];
+							if (!((adj[(size_t) j * MW + (k >> 6)] >> (k & 63)) & 1ull)) continue;
+							const double nu[3] = {zs[k * 3] - zh[j], zs[k * 3 + 1] - zh[JS + j], zs[k * 3 + 2] - zh[2 * JS + j]};
+							acc += pair_gradient(prm, nu, gjp + x * 18, gt);
+						}
+						if (lane < 6) gdv[m][lane] = acc;
+					});
+					// LogSumExp(logcomp, 0, m)
+					for (int i = 0; i < mcount; i++) mx = fmax(mx, glc[i]);
+					if (!(isinf(mx) && mx < 0)) {
+						for (int i = 0; i < mcount; i++) value += exp(glc[i] - mx);   // (as cluster_enumerate does: the value of this mode equals the value kernel's bit for bit)
+					}
+				}
+				const bool finite = !(isinf(mx) && mx < 0);
+				const double lse = finite ? mx + log(value) : -INFINITY;
 				int off = 0;
 				if (lane == 0) off = atomicAdd(&s_ebump, mcount);
 				off = __shfl(off, 0, 64);
@@ -1406,6 +1545,7 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 			}
 			__threadfence_block();
 			__syncthreads();
+			PHD_STAMP(10);
 			// what the replay reads per cluster, brought into LDS in one go when it is little (it usually is: forty clusters, a
 			// few weights each): the replay is one wave walking the clusters in order, every read a dependent trip otherwise
 			if (nroots <= QGRAD_G2_CLUSTERS && s_ebump <= QGRAD_G2_WEIGHTS) {
@@ -1582,33 +1722,128 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 						}
 					}
 				};
-				for (int ri = 0; ri <= lastbig; ri++) {
-					if (GRAD && gws && inlds) {
-						// a cluster the four waves have already enumerated: only what depends on the clusters before it is left —
-						// its weights take their place in logcomp, which TemperedAverage normalises as a whole
-						const double* h = s_g2lds ? s_g2 + ri * QGRAD_HDR : gj + (size_t) ri * QGRAD_HDR;
-						const int m = (int) h[0];
-						if (m >= 0) {
-							const double* el = (s_g2lds ? s_g2 + QGRAD_G2_CLUSTERS * QGRAD_HDR : gj + (size_t) (QGRAD_HDR + 18) * JL) + (int) h[7];
-							for (int i = lane; i < m; i += 64) ws.logcomp[i] = el[i];
-							lds_fence();
-							if (h[8] != 0) {
-								double part = 0;
-								if (a.qavg == 0) {
-									for (int i = lane; i < MURTY_OUT; i += 64) part += ws.logcomp[i] * ws.logcomp[i];
-								}
-								else {
-									for (int i = lane; i < m; i += 64) part += ws.logcomp[i];
+				if (GRAD && gws && inlds) {
+					// The clusters the four waves have already enumerated: only what depends on the clusters before them is left —
+					// their weights take their place in logcomp, which TemperedAverage normalises as a whole (the stale entries of
+					// earlier, longer clusters included). Here the array lives in registers (entry lane + 64 q): a cluster costs a
+					// predicated copy and the lane's share of the norm, written to a row of LDS; the rows of a run of clusters are
+					// then summed by one lane each and the clusters' G / norm added in cluster order. A cluster left to the replay
+					// whole (more than 5 rows, or no room for its weights) ends the run: the registers go to the LDS array it works
+					// on and come back.
+					constexpr int LQ = (MURTY_OUT + 63) / 64, SEG = 32, ROW = 65;
+					double* const prow = gws + QGRAD_WAVE_DOUBLES;   // [SEG][ROW] (the other waves' workspaces of the first pass: free now)
+					double* const nrm  = prow + SEG * ROW;           // [SEG]
+					static_assert(SEG * ROW + SEG <= 3 * QGRAD_WAVE_DOUBLES, "the rows of a run do not fit the three idle workspaces");
+					const double* const hb = s_g2lds ? s_g2 : gj;
+					const double* const eb = s_g2lds ? s_g2 + QGRAD_G2_CLUSTERS * QGRAD_HDR : gj + (size_t) (QGRAD_HDR + 18) * JL;
+					double l[LQ];
+#pragma unroll
+					for (int q = 0; q < LQ; q++) l[q] = 0;
+					int ri = 0, maxm = 0;   // (entries from maxm on are still the zeros the array started with)
+					while (ri <= lastbig) {
+						const int r0 = ri;
+						// the headers of the run: lane s reads cluster r0 + s; the run ends before the first cluster left to the replay
+						const int avail = min(SEG, lastbig + 1 - ri);
+						int hm = 0, hoff = 0;
+						if (lane < avail) {
+							const double* h = hb + (size_t) (r0 + lane) * QGRAD_HDR;
+							hm = (int) h[0];
+							hoff = (int) h[7];
+						}
+						const unsigned long long whole = ballot64(lane < avail && hm < 0);
+						const int ns = whole ? min(avail, __ffsll((long long) whole) - 1) : avail;
+						int runmax = 0;
+						for (int sidx = 0; sidx < ns; sidx++) runmax = max(runmax, __builtin_amdgcn_readlane(hm, sidx));
+						if (max(maxm, runmax) <= 64) {
+							// (the usual case: no cluster of the run or before it has more than 64 pairings — one register per lane)
+							for (int s0 = 0; s0 < ns; s0 += 4) {   // four clusters' weights fetched at once (the loads do not wait for the stores)
+								int mm[4];
+								double ev[4];
+#pragma unroll
+								for (int q = 0; q < 4; q++) {
+									const int sidx = min(s0 + q, ns - 1);
+									mm[q] = (s0 + q < ns) ? __builtin_amdgcn_readlane(hm, sidx) : 0;
+									const double* el = eb + __builtin_amdgcn_readlane(hoff, sidx);
+									ev[q] = (lane < mm[q]) ? el[lane] : 0.0;
 								}
 #pragma unroll
-								for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-								const double norm = (a.qavg == 0) ? sqrt(part) : part;
-								gacc += (norm == 0) ? h[1 + gt] : h[1 + gt] / norm;
+								for (int q = 0; q < 4; q++) {
+									if (s0 + q < ns) {
+										if (lane < mm[q]) l[0] = ev[q];
+										prow[(s0 + q) * ROW + lane] = (a.qavg == 0) ? l[0] * l[0] : ((lane < mm[q]) ? l[0] : 0.0);
+									}
+								}
 							}
-							continue;
+							maxm = max(maxm, runmax);
+						}
+						else {
+							for (int sidx = 0; sidx < ns; sidx++) {
+								const int m = __builtin_amdgcn_readlane(hm, sidx);
+								const double* el = eb + __builtin_amdgcn_readlane(hoff, sidx);
+								maxm = max(maxm, m);
+								double part = 0;
+#pragma unroll
+								for (int q = 0; q < LQ; q++) {
+									if (64 * q < maxm) {   // (wave-uniform)
+										const int i = lane + 64 * q;
+										if (i < m) l[q] = el[i];
+										if (a.qavg == 0) { if (i < MURTY_OUT) part += l[q] * l[q]; }
+										else if (i < m) part += l[q];
+									}
+								}
+								prow[sidx * ROW + lane] = part;
+							}
+						}
+						ri += ns;
+						lds_fence();
+						if (ns > 0) {
+							if (lane < ns) {
+								// (lanes from maxm on wrote exact zeros when no entry beyond 64 is alive: adding them changes nothing)
+								const int tn = (maxm <= 64) ? maxm : 64;
+								double tot = 0;
+#pragma unroll 8
+								for (int t = 0; t < tn; t++) tot += prow[lane * ROW + t];
+								nrm[lane] = (a.qavg == 0) ? sqrt(tot) : tot;
+							}
+							lds_fence();
+							// G / norm, added in cluster order (the divisions of neighbouring clusters are independent: unrolled)
+							for (int s0 = 0; s0 < ns; s0 += 8) {
+								double vq[8];
+								bool onq[8];
+#pragma unroll
+								for (int q = 0; q < 8; q++) {
+									const int sidx = min(s0 + q, ns - 1);
+									const double* h = hb + (size_t) (r0 + sidx) * QGRAD_HDR;
+									const double norm = nrm[sidx], g = h[1 + gt];
+									vq[q] = (norm == 0) ? g : g / norm;
+									onq[q] = s0 + q < ns && h[8] != 0;
+								}
+#pragma unroll
+								for (int q = 0; q < 8; q++) {
+									if (onq[q]) gacc += vq[q];
+								}
+							}
+						}
+						if (ri <= lastbig && ns < SEG) {
+#pragma unroll
+							for (int q = 0; q < LQ; q++) {
+								if (lane + 64 * q < MURTY_OUT) ws.logcomp[lane + 64 * q] = l[q];
+							}
+							lds_fence();
+							replay_one(ri);
+#ifdef PHD_STAMPS
+							stamp_[11] += 1000;
+#endif
+							lds_fence();
+#pragma unroll
+							for (int q = 0; q < LQ; q++) l[q] = (lane + 64 * q < MURTY_OUT) ? ws.logcomp[lane + 64 * q] : 0.0;
+							maxm = MURTY_OUT;
+							ri++;
 						}
 					}
-					replay_one(ri);
+				}
+				else {
+					for (int ri = 0; ri <= lastbig; ri++) replay_one(ri);
 				}
 				if (GRAD && lane < 6) a.qgrad[(size_t) p * 6 + lane] = gacc;
 			}
@@ -1637,7 +1872,10 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 		__syncthreads();
 	}
 	PHD_STAMP(7);
-	PHD_STAMP_FLUSH(3, 9);
+#ifdef PHD_STAMPS
+	stamp_[11] += stamp_[0] + s_nroots;   // (diagnostic: clusters + 1000 x clusters replayed whole, in slot 11)
+#endif
+	PHD_STAMP_FLUSH(3, 12);
 	if (tid == 0) {
 		a.setll[p] = s_total;
 		if (!QUASI) {

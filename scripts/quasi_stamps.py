@@ -25,6 +25,7 @@ for name, fn in (("value", lambda: nav.QuasiSetLogLikelihood(qz, lms, qposes)), 
     out = np.zeros((P, 16))
     nav._lib.phd_debug_stamps(nav._h, out.ctypes.data_as(C.POINTER(C.c_double)))
     m = out.mean(0)
-    idx = [i for i in np.argsort(m[:12], kind="stable") if i == 0 or m[i] > 0]
-    print(name, "cycles between stamps:", " ".join("%d->%d:%d" % (a, b, m[b] - m[a]) for a, b in zip(idx[:-1], idx[1:])), "total", int(m[:12].max()))
+    idx = [i for i in np.argsort(m[:11], kind="stable") if i == 0 or m[i] > 0]
+    print(name, "cycles between stamps:", " ".join("%d->%d:%d" % (a, b, m[b] - m[a]) for a, b in zip(idx[:-1], idx[1:])), "total", int(m[:11].max()),
+          "| clusters per pose %.1f, of them replayed whole %.2f" % (np.mean(out[:, 11] % 1000), np.mean(out[:, 11] // 1000)))
 nav.close()

@@ -324,7 +324,8 @@ def test_quasi_set_log_likelihood_batch(nav_mod, J, M, seed):
     nav.close()
 
 
-@pytest.mark.parametrize("J,M,seed", [(3, 4, 181), (40, 30, 182), (12, 70, 183), (300, 64, 184), (0, 5, 185), (6, 0, 186), (2, 3, 187)])
+@pytest.mark.parametrize("J,M,seed", [(3, 4, 181), (40, 30, 182), (12, 70, 183), (300, 64, 184), (0, 5, 185), (6, 0, 186), (2, 3, 187),
+                                      (64, 60, 188), (110, 100, 189)])   # ... more clusters than one run of the ordered pass takes (32), than its LDS copy holds (64)
 @pytest.mark.parametrize("mode", [0, 1])
 def test_quasi_set_log_likelihood_gradient_batch(nav_mod, J, M, seed, mode):
     """Row f4, gradient part: QuasiSetLogLikelihood(..., out gradient) (PHDNavigator.cs:543-713) for a batch of poses
