@@ -1732,18 +1732,18 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 					// on and come back.
 					constexpr int LQ = (MURTY_OUT + 63) / 64, SEG = 32, ROW = 65;
 					double* const prow = gws + QGRAD_WAVE_DOUBLES;   // [SEG][ROW] (the other waves' workspaces of the first pass: free now)
-					double* const nrm  = prow + SEG * ROW;           // [SEG]
-					static_assert(SEG * ROW + SEG <= 3 * QGRAD_WAVE_DOUBLES, "the rows of a run do not fit the three idle workspaces");
-					const double* const hb = s_g2lds ? s_g2 : gj;
-					const double* const eb = s_g2lds ? s_g2 + QGRAD_G2_CLUSTERS * QGRAD_HDR : gj + (size_t) (QGRAD_HDR + 18) * JL;
+					static_assert(SEG * ROW <= 3 * QGRAD_WAVE_DOUBLES, "the rows of a run do not fit the three idle workspaces");
 					double l[LQ];
 #pragma unroll
 					for (int q = 0; q < LQ; q++) l[q] = 0;
 					int ri = 0, maxm = 0;   // (entries from maxm on are still the zeros the array started with)
-					while (ri <= lastbig) {
-						const int r0 = ri;
+					double T = 0;           // TemperedAverage's first reading (a.qavg 0): this lane's share of the squares of the entries from 64 on
+					// one run of clusters, from r0 on; returns their number. (Inlined once per place the headers and weight lists
+					// can be in — LDS or the particle's scratch —, so that each copy knows its address space: through one pointer
+					// chosen at run time every access was a flat one.)
+					auto light_run = [&](const double* const hb, const double* const eb, const int r0) __attribute__((always_inline)) {
 						// the headers of the run: lane s reads cluster r0 + s; the run ends before the first cluster left to the replay
-						const int avail = min(SEG, lastbig + 1 - ri);
+						const int avail = min(SEG, lastbig + 1 - r0);
 						int hm = 0, hoff = 0;
 						if (lane < avail) {
 							const double* h = hb + (size_t) (r0 + lane) * QGRAD_HDR;
@@ -1752,78 +1752,92 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 						}
 						const unsigned long long whole = ballot64(lane < avail && hm < 0);
 						const int ns = whole ? min(avail, __ffsll((long long) whole) - 1) : avail;
-						int runmax = 0;
-						for (int sidx = 0; sidx < ns; sidx++) runmax = max(runmax, __builtin_amdgcn_readlane(hm, sidx));
-						if (max(maxm, runmax) <= 64) {
-							// (the usual case: no cluster of the run or before it has more than 64 pairings — one register per lane)
-							for (int s0 = 0; s0 < ns; s0 += 4) {   // four clusters' weights fetched at once (the loads do not wait for the stores)
-								int mm[4];
+						for (int s0 = 0; s0 < ns; s0 += 4) {   // four clusters at a time: their weights are fetched before any row is stored
+							int mm[4], mx4 = 0;
+#pragma unroll
+							for (int q = 0; q < 4; q++) {
+								mm[q] = (s0 + q < ns) ? __builtin_amdgcn_readlane(hm, min(s0 + q, ns - 1)) : 0;
+								mx4 = max(mx4, mm[q]);
+							}
+							if (mx4 <= 64) {
+								// (the usual case — at most 64 pairings each: one register per lane; the entries from 64 on stay, T is their share)
 								double ev[4];
 #pragma unroll
 								for (int q = 0; q < 4; q++) {
-									const int sidx = min(s0 + q, ns - 1);
-									mm[q] = (s0 + q < ns) ? __builtin_amdgcn_readlane(hm, sidx) : 0;
-									const double* el = eb + __builtin_amdgcn_readlane(hoff, sidx);
+									const double* el = eb + __builtin_amdgcn_readlane(hoff, min(s0 + q, ns - 1));
 									ev[q] = (lane < mm[q]) ? el[lane] : 0.0;
 								}
 #pragma unroll
 								for (int q = 0; q < 4; q++) {
 									if (s0 + q < ns) {
 										if (lane < mm[q]) l[0] = ev[q];
-										prow[(s0 + q) * ROW + lane] = (a.qavg == 0) ? l[0] * l[0] : ((lane < mm[q]) ? l[0] : 0.0);
+										prow[(s0 + q) * ROW + lane] = (a.qavg == 0) ? fma(l[0], l[0], T) : ((lane < mm[q]) ? l[0] : 0.0);
 									}
 								}
 							}
-							maxm = max(maxm, runmax);
-						}
-						else {
-							for (int sidx = 0; sidx < ns; sidx++) {
-								const int m = __builtin_amdgcn_readlane(hm, sidx);
-								const double* el = eb + __builtin_amdgcn_readlane(hoff, sidx);
-								maxm = max(maxm, m);
-								double part = 0;
+							else {
 #pragma unroll
-								for (int q = 0; q < LQ; q++) {
-									if (64 * q < maxm) {   // (wave-uniform)
-										const int i = lane + 64 * q;
-										if (i < m) l[q] = el[i];
-										if (a.qavg == 0) { if (i < MURTY_OUT) part += l[q] * l[q]; }
-										else if (i < m) part += l[q];
+								for (int q = 0; q < 4; q++) {
+									if (s0 + q < ns) {
+										const int m = mm[q];
+										const double* el = eb + __builtin_amdgcn_readlane(hoff, min(s0 + q, ns - 1));
+										double sum = 0;
+										T = 0;
+#pragma unroll
+										for (int qq = 0; qq < LQ; qq++) {
+											const int i = lane + 64 * qq;
+											if (i < m) { l[qq] = el[i]; sum += l[qq]; }
+											if (qq > 0) T = fma(l[qq], l[qq], T);
+										}
+										prow[(s0 + q) * ROW + lane] = (a.qavg == 0) ? fma(l[0], l[0], T) : sum;
 									}
 								}
-								prow[sidx * ROW + lane] = part;
 							}
+							maxm = max(maxm, mx4);
 						}
-						ri += ns;
 						lds_fence();
 						if (ns > 0) {
+							// the rows summed by one lane each (lanes from maxm on wrote exact zeros when no entry beyond 64 is alive: adding
+							// them changes nothing); that lane divides its cluster's G by the norm
+							double* const cbuf = prow;   // [SEG][6] once the rows are summed
+							bool on = false;
+							double c6[6];
 							if (lane < ns) {
-								// (lanes from maxm on wrote exact zeros when no entry beyond 64 is alive: adding them changes nothing)
 								const int tn = (maxm <= 64) ? maxm : 64;
 								double tot = 0;
 #pragma unroll 8
 								for (int t = 0; t < tn; t++) tot += prow[lane * ROW + t];
-								nrm[lane] = (a.qavg == 0) ? sqrt(tot) : tot;
+								const double norm = (a.qavg == 0) ? sqrt(tot) : tot;
+								const double* h = hb + (size_t) (r0 + lane) * QGRAD_HDR;
+#pragma unroll
+								for (int t = 0; t < 6; t++) c6[t] = (norm == 0) ? h[1 + t] : h[1 + t] / norm;
+								on = h[8] != 0;
+							}
+							const unsigned long long onb = ballot64(on);
+							lds_fence();   // (every row has been read)
+							if (lane < ns) {
+#pragma unroll
+								for (int t = 0; t < 6; t++) cbuf[lane * 6 + t] = c6[t];
 							}
 							lds_fence();
-							// G / norm, added in cluster order (the divisions of neighbouring clusters are independent: unrolled)
+							// ... and the quotients are added in cluster order (a cluster whose components were all -inf adds nothing)
 							for (int s0 = 0; s0 < ns; s0 += 8) {
 								double vq[8];
-								bool onq[8];
 #pragma unroll
 								for (int q = 0; q < 8; q++) {
-									const int sidx = min(s0 + q, ns - 1);
-									const double* h = hb + (size_t) (r0 + sidx) * QGRAD_HDR;
-									const double norm = nrm[sidx], g = h[1 + gt];
-									vq[q] = (norm == 0) ? g : g / norm;
-									onq[q] = s0 + q < ns && h[8] != 0;
+									const double v = cbuf[min(s0 + q, ns - 1) * 6 + gt];
+									vq[q] = (s0 + q < ns && ((onb >> (s0 + q)) & 1ull)) ? v : 0.0;
 								}
 #pragma unroll
-								for (int q = 0; q < 8; q++) {
-									if (onq[q]) gacc += vq[q];
-								}
+								for (int q = 0; q < 8; q++) gacc += vq[q];
 							}
 						}
+						return ns;
+					};
+					while (ri <= lastbig) {
+						const int ns = s_g2lds ? light_run(s_g2, s_g2 + QGRAD_G2_CLUSTERS * QGRAD_HDR, ri)
+						                       : light_run(gj, gj + (size_t) (QGRAD_HDR + 18) * JL, ri);
+						ri += ns;
 						if (ri <= lastbig && ns < SEG) {
 #pragma unroll
 							for (int q = 0; q < LQ; q++) {
@@ -1838,6 +1852,9 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 #pragma unroll
 							for (int q = 0; q < LQ; q++) l[q] = (lane + 64 * q < MURTY_OUT) ? ws.logcomp[lane + 64 * q] : 0.0;
 							maxm = MURTY_OUT;
+							T = 0;
+#pragma unroll
+							for (int q = 1; q < LQ; q++) T = fma(l[q], l[q], T);
 							ri++;
 						}
 					}

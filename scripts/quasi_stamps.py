@@ -6,6 +6,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from monorfs_amd import _lib
 _lib.SO_PATH = os.path.join(_lib.CSRC, "libphdhip_stamps.so")
+if not os.path.exists(_lib.SO_PATH):
+    import subprocess
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + _lib.HIPCC_FLAGS + ["-DPHD_STAMPS", "-o", _lib.SO_PATH, os.path.join(_lib.CSRC, "phdhip.hip")], cwd=_lib.CSRC)
 os.environ["PHD_STAMP_KERNEL"] = "3"
 from monorfs_amd import navigator
 from monorfs_amd.abi import prm3d_defaults
