@@ -75,7 +75,7 @@ struct StepBufs {
 	struct MurtyNodes* murty;   // [P] workspace of the big-cluster solver (clusters of 6 .. 64 rows)
 	char*   bigws;       // association slab: workspaces of the clusters beyond 64 rows, handed out by a bump counter
 	unsigned long long  bigws_bytes;
-	unsigned long long* bigws_used;   // reset at the end of every step (k_normalise_resample) / by the host before a stage or quasi launch
+	unsigned long long* bigws_used;   // reset at the end of every step (k_normalise_resample) / by the host behind a stage launch; a quasi batch brings its own
 	double* jscratch;    // [P] landmark-indexed arrays of k_weight_alpha when the map estimate outgrows LDS
 	// (component, measurement) pairs that may reach MinWeight, queued by k_sweep for k_emit_finish
 	int*    cand;        // [P][candcap]

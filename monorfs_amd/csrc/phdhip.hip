@@ -79,7 +79,7 @@ struct phd_navigator {
 	double* d_wcopy = nullptr; int* d_cover = nullptr;   // k_prune_merge -> k_alpha_density (see StepBufs)
 	double* d_motion = nullptr;   // odometry[6] + noise[P][6] of phd_update_motion
 	double* d_quasi = nullptr;    // phd_quasi_set_loglik: poses[Pcap][7], landmarks[Jcap][3], z[256][3], out[Pcap]
-	std::vector<double> h_quasi;
+	double* h_quasi = nullptr;    // ... its pinned mirror on the host (+ one word for the flags): one stream wait per call, no pageable copies
 	double* d_gw = nullptr; int gwcap = 0;           // gathered weights of all ranks (+ their status words behind them: flagslot)
 	double* d_stage = nullptr;                       // device staging of phd_set_poses / phd_set_weights (stored into the IN bank by k_store_small)
 	// pinned host staging of the per-frame inputs (poses, weights, odometry + noise, measurements): the caller's buffers are
@@ -766,6 +766,7 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_murty); hipFree(nav->d_bigws); hipFree(nav->d_bigws_used); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_wcopy); hipFree(nav->d_cover); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	hipFree(nav->d_lw); hipFree(nav->d_dst_tab); hipFree(nav->d_recv_tab); hipFree(nav->plan.code); hipFree(nav->plan.fslot); hipFree(nav->plan.sendlist); hipFree(nav->plan.senddst); hipFree(nav->plan.counts);
 	if (nav->h_counts) hipHostFree(nav->h_counts);
+	if (nav->h_quasi) hipHostFree(nav->h_quasi);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
 	for (int i = 0; i < 2; i++) {
 		if (nav->h_stage[i]) hipHostFree(nav->h_stage[i]);
@@ -890,20 +891,32 @@ static int quasi_batch(phd_navigator* nav, const double* poses7, int nposes, con
 	FINITE_OR_FAIL(nav, landmarks3, (size_t) nlandmarks * 3, "phd_quasi_set_loglik");
 	FINITE_OR_FAIL(nav, z3, (size_t) nmeasurements * 3, "phd_quasi_set_loglik");
 	hipSetDevice(nav->device);
-	const size_t op = 0, ol = op + (size_t) nav->Pcap * 7, oz = ol + (size_t) nav->Jcap * 3, oo = oz + 256 * 3, og = oo + nav->Pcap,
-	             total = og + (size_t) nav->Pcap * 6;
-	if (!nav->d_quasi) HC(hipMalloc((void**) &nav->d_quasi, total * 8));
-	HC(hipMemcpyAsync(nav->d_quasi + op, poses7, (size_t) nposes * 7 * 8, hipMemcpyHostToDevice, nav->stream));
-	if (nlandmarks) HC(hipMemcpyAsync(nav->d_quasi + ol, landmarks3, (size_t) nlandmarks * 3 * 8, hipMemcpyHostToDevice, nav->stream));
-	if (nmeasurements) HC(hipMemcpyAsync(nav->d_quasi + oz, z3, (size_t) nmeasurements * 3 * 8, hipMemcpyHostToDevice, nav->stream));
+	// One buffer on the device and its pinned mirror on the host, packed per call:
+	//   poses[n][7] | landmarks[J][3] | z[M][3] | flag word | slab counter | out[n] | gradients[n][6]
+	// so that a call is ONE copy in (inputs, with the two words zeroed), the kernel, ONE copy out (from the flag word on) and
+	// one wait. The smoother calls this in a loop: six copies from and to pageable memory, two memsets and a blocking read of
+	// the step's flag word cost more than the value kernel's 40 us. The batch has a flag word and a slab counter of its own:
+	// nothing it raises can drop the next step, and the step's association kernel finds its counter as it left it.
+	const size_t cap = (size_t) nav->Pcap * 14 + (size_t) nav->Jcap * 3 + 256 * 3 + 2;
+	const size_t op = 0, ol = op + (size_t) nposes * 7, oz = ol + (size_t) nlandmarks * 3, of = oz + (size_t) nmeasurements * 3, ou = of + 1,
+	             oo = ou + 1, og = oo + nposes, end = og + (gradients6 ? (size_t) nposes * 6 : 0);
+	if (!nav->d_quasi) HC(hipMalloc((void**) &nav->d_quasi, cap * 8));
+	if (!nav->h_quasi) HC(hipHostMalloc((void**) &nav->h_quasi, cap * 8, hipHostMallocDefault));
+	double* const hq = nav->h_quasi;
+	std::memcpy(hq + op, poses7, (size_t) nposes * 7 * 8);
+	if (nlandmarks) std::memcpy(hq + ol, landmarks3, (size_t) nlandmarks * 3 * 8);
+	if (nmeasurements) std::memcpy(hq + oz, z3, (size_t) nmeasurements * 3 * 8);
+	hq[of] = 0; hq[ou] = 0;
+	HC(hipMemcpyAsync(nav->d_quasi, hq, oo * 8, hipMemcpyHostToDevice, nav->stream));
 	StepBufs b = make_bufs(nav);
 	b.P = nposes; b.M = nmeasurements; b.z = nav->d_quasi + oz;
 	b.qposes = nav->d_quasi + op; b.qlm = nav->d_quasi + ol; b.qJ = nlandmarks;
 	b.setll = nav->d_quasi + oo;
 	b.qgrad = nav->d_quasi + og;
 	b.qavg  = average_mode;
+	b.flags = (int*) (nav->d_quasi + of);
+	b.bigws_used = (unsigned long long*) (nav->d_quasi + ou);
 	const bool gradient = gradients6 != nullptr;
-	HC(hipMemsetAsync(nav->d_bigws_used, 0, 8, nav->stream));
 	int rc;
 	switch (zb_of(nmeasurements)) {
 	case 1:  rc = launch_quasi<1>(nav, b, nposes, gradient); break;
@@ -911,16 +924,13 @@ static int quasi_batch(phd_navigator* nav, const double* poses7, int nposes, con
 	default: rc = launch_quasi<4>(nav, b, nposes, gradient); break;
 	}
 	if (rc) return rc;
-	// (the slab blocks this batch took are free again: the next step's association kernel must find the whole slab, and
-	// only a step's own k_normalise_resample resets the counter otherwise)
-	HC(hipMemsetAsync(nav->d_bigws_used, 0, 8, nav->stream));
-	HC(hipMemcpyAsync(out, nav->d_quasi + oo, (size_t) nposes * 8, hipMemcpyDeviceToHost, nav->stream));
-	if (gradient) HC(hipMemcpyAsync(gradients6, nav->d_quasi + og, (size_t) nposes * 6 * 8, hipMemcpyDeviceToHost, nav->stream));
+	HC(hipMemcpyAsync(hq + of, nav->d_quasi + of, (end - of) * 8, hipMemcpyDeviceToHost, nav->stream));
 	HC(hipStreamSynchronize(nav->stream));
+	std::memcpy(out, hq + oo, (size_t) nposes * 8);
+	if (gradient) std::memcpy(gradients6, hq + og, (size_t) nposes * 6 * 8);
 	int flags = 0;
-	HC(hipMemcpy(&flags, nav->d_flags, 4, hipMemcpyDeviceToHost));
+	std::memcpy(&flags, hq + of, 4);
 	if (flags & PHD_FLAG_BIG_CLUSTER) {
-		hipMemset(nav->d_flags, 0, 4);
 		return nav->fail(PHD_ERR_ASSOCIATION, "phd_quasi_set_loglik: an association cluster exceeds the on-device solver");
 	}
 	return PHD_OK;
