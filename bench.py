@@ -403,8 +403,15 @@ def main():
             for prof in ("steady", "survey"):
                 fa = Frame(Pa, Ca, Ma, seeda, weight_profile=prof)
                 ma = short_run(fa, xs)
+                # ... and as the reference's host calls it: one synchronous SlamUpdate per frame (phd_slam_update = measurements
+                # uploaded, the step, phd_sync with its status read-back), from Python through ctypes
+                t3 = time.perf_counter()
+                for _ in range(xs):
+                    nav.SlamUpdate(None, fa.z, u_resample=0.5)
+                msync = (time.perf_counter() - t3) / xs * 1e3
                 modes["config_A" if prof == "steady" else "config_A_survey"] = {
                     "ms_per_step": ma, "value": Pa * Ca * Ma / (ma * 1e-3), "unit": "PHD updates/s", "steps": xs,
+                    "ms_per_synchronous_update": msync,
                     "workload": "%d particles x %d components x %d measurements, prior weights '%s'" % (Pa, Ca, Ma, prof)}
 
         # QuasiSetLogLikelihood of a batch of candidate poses against one landmark set and one measurement

@@ -79,6 +79,7 @@ struct phd_navigator {
 	double* d_wcopy = nullptr; int* d_cover = nullptr;   // k_prune_merge -> k_alpha_density (see StepBufs)
 	double* d_motion = nullptr;   // odometry[6] + noise[P][6] of phd_update_motion
 	double* d_quasi = nullptr;    // phd_quasi_set_loglik: poses[Pcap][7], landmarks[Jcap][3], z[256][3], out[Pcap]
+	int*    h_status = nullptr;   // pinned mirror of [d_sel (two parities) | d_info | d_flags], one block on the device
 	double* h_quasi = nullptr;    // ... its pinned mirror on the host (+ one word for the flags): one stream wait per call, no pageable copies
 	double* d_gw = nullptr; int gwcap = 0;           // gathered weights of all ranks (+ their status words behind them: flagslot)
 	double* d_stage = nullptr;                       // device staging of phd_set_poses / phd_set_weights (stored into the IN bank by k_store_small)
@@ -481,10 +482,11 @@ int upload_particle(phd_navigator* nav, int bankidx, int particle, const double*
 
 int sync_state(phd_navigator* nav)
 {
+	HC(hipMemcpyAsync(nav->h_status, nav->d_sel, (2 * SEL_STRIDE + 3) * sizeof(int), hipMemcpyDeviceToHost, nav->stream));
 	HC(hipStreamSynchronize(nav->stream));
-	HC(hipMemcpy(nav->h_sel, nav->d_sel + nav->parity * SEL_STRIDE, SEL_STRIDE * sizeof(int), hipMemcpyDeviceToHost));
-	HC(hipMemcpy(nav->h_info, nav->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost));
-	HC(hipMemcpy(&nav->h_flags, nav->d_flags, sizeof(int), hipMemcpyDeviceToHost));
+	std::memcpy(nav->h_sel, nav->h_status + nav->parity * SEL_STRIDE, SEL_STRIDE * sizeof(int));
+	std::memcpy(nav->h_info, nav->h_status + 2 * SEL_STRIDE, 2 * sizeof(int));
+	nav->h_flags = nav->h_status[2 * SEL_STRIDE + 2];
 	nav->sel_host_valid = true;
 	return PHD_OK;
 }
@@ -641,7 +643,11 @@ phd_navigator* phd_create(const phd_params* params, int device)
 		}
 	}
 	size_t E = (size_t) nav->Pcap * nav->ecap;
-	ok = ok && dalloc((void**) &nav->d_sel, 2 * SEL_STRIDE * 4) && dalloc((void**) &nav->d_inslot, (size_t) nav->Pcap * 4);
+	// the role tables (two parities), the step's info words and its flag word in ONE block: phd_sync reads it with one copy
+	// queued on the stream it then waits for (three blocking copies before: 40 us of a 90 us step at config A)
+	ok = ok && dalloc((void**) &nav->d_sel, (2 * SEL_STRIDE + 4) * 4) && dalloc((void**) &nav->d_inslot, (size_t) nav->Pcap * 4);
+	if (ok) { nav->d_info = nav->d_sel + 2 * SEL_STRIDE; nav->d_flags = nav->d_info + 2; }
+	ok = ok && hipHostMalloc((void**) &nav->h_status, (2 * SEL_STRIDE + 4) * 4, hipHostMallocDefault) == hipSuccess;
 	ok = ok && dalloc((void**) &nav->d_z, (size_t) nav->Mcap * 3 * 8);
 	ok = ok && dalloc((void**) &nav->d_emit_w, E * 8) && dalloc((void**) &nav->d_emit_idx, E * 4);
 	ok = ok && dalloc((void**) &nav->d_emit_rec, E * 9 * 8) && dalloc((void**) &nav->d_emit_count, (size_t) nav->Pcap * 4);
@@ -649,7 +655,6 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	ok = ok && dalloc((void**) &nav->d_born_k, (size_t) nav->Pcap * nav->Mcap * 4);
 	ok = ok && dalloc((void**) &nav->d_born_mean, (size_t) nav->Pcap * nav->Mcap * 3 * 8);
 	ok = ok && dalloc((void**) &nav->d_alpha, (size_t) nav->Pcap * 8) && dalloc((void**) &nav->d_setll, (size_t) nav->Pcap * 8);
-	ok = ok && dalloc((void**) &nav->d_flags, 4) && dalloc((void**) &nav->d_info, 8);
 	ok = ok && dalloc((void**) &nav->d_src, (size_t) nav->Pcap * 4);
 	ok = ok && dalloc((void**) &nav->d_murty, (size_t) nav->Pcap * sizeof(MurtyNodes));
 	nav->bigws_bytes = 128ull << 20;
@@ -762,11 +767,12 @@ void phd_destroy(phd_navigator* nav)
 	}
 	hipFree(nav->d_sel); hipFree(nav->d_inslot); hipFree(nav->d_mslot); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
-	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_flags); hipFree(nav->d_info); hipFree(nav->d_src);
+	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_src);
 	hipFree(nav->d_murty); hipFree(nav->d_bigws); hipFree(nav->d_bigws_used); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_wcopy); hipFree(nav->d_cover); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	hipFree(nav->d_lw); hipFree(nav->d_dst_tab); hipFree(nav->d_recv_tab); hipFree(nav->plan.code); hipFree(nav->plan.fslot); hipFree(nav->plan.sendlist); hipFree(nav->plan.senddst); hipFree(nav->plan.counts);
 	if (nav->h_counts) hipHostFree(nav->h_counts);
 	if (nav->h_quasi) hipHostFree(nav->h_quasi);
+	if (nav->h_status) hipHostFree(nav->h_status);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
 	for (int i = 0; i < 2; i++) {
 		if (nav->h_stage[i]) hipHostFree(nav->h_stage[i]);
