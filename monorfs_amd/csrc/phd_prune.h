@@ -223,54 +223,150 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 	int sbits = 1;
 	while ((1 << sbits) < ne) sbits++;                    // bits of a slot number
 	const unsigned int smask = (1u << sbits) - 1u;
+	const unsigned int* order = sw;                       // the kept entries' slots in sorted order (low `sbits` bits)
 	{
 		int n = 256;                                      // (at least the width of the register sort: small maps, too, skip the barrier-per-stage version)
 		while (n < ne && n < NS) n <<= 1;                 // width of the first pass
 		int taken = 0;                                    // emitted entries consumed so far
 		bool first = true, prefilled = false;
-		// Only the `cut` heaviest entries are kept, and a sort costs by its width: when more than 1024 entries were emitted
-		// (config B's survey frame: 1080; config S: thousands, several passes of the full width), a histogram over the weights'
-		// leading bits (exponent and five mantissa bits, counted from MinWeight up: every emitted weight is at least that)
-		// finds the bin the cut-th heaviest entry lies in, and only the entries from that bin up are sorted, in one pass of the
-		// smallest width that holds them. Nothing changes in the order of what is kept: whole bins are taken.
+		// Only the `cut` heaviest entries are kept. A histogram over the weights' leading bits (exponent and five mantissa
+		// bits, counted from MinWeight up: every emitted weight is at least that) finds the bin the cut-th heaviest entry lies
+		// in; whole bins are taken, so nothing changes in the order of what is kept.
+		//   * ranked: the entries from that bin up are scattered to their bins' places (a counting sort: the bins' starts are
+		//     the suffix sums of the histogram) and every entry counts, among the few entries of its own bin, those that
+		//     go before it — by the full weight, then the canonical index: the reference's sort made stable, with no sorting
+		//     network, no runs of equal keys to order afterwards;
+		//   * when that does not fit (more entries than the LDS arrays hold, or a bin crowded with hundreds of equal weights):
+		//     the entries from the threshold bin up are sorted in one pass of the smallest width (more than 1024 emitted), or
+		//     everything goes through the passes below.
 		const int xsize = lay.scan - lay.x;
-		if (ne > 1024 && cut > 0 && xsize >= NS + 520) {
-			int* const hist = (int*) (smem + lay.x + NS);   // [1024] behind the two sort arrays
+		const int capN = (NS * 2) / 3;                                 // entries the ranked path holds: 12 bytes each in the sort arrays' place
+		bool ranked = false;
+		if (ne > 256 && cut > 0 && xsize >= NS + 516 + capN / 2 + 2) {
+			int* const hist = (int*) (smem + lay.x + NS);   // [1024] behind the sort arrays: counts, then starts, then ends of the bins
 			int& s_T = hist[1024];
 			int& s_cnt = hist[1025];
 			int& s_fill = hist[1026];
+			int& s_maxb = hist[1027];
+			unsigned int* const out = (unsigned int*) (hist + 1032);   // [capN]
 			const unsigned int base = (unsigned int) (((unsigned long long) __double_as_longlong(prm.minw) << 1) >> 48);
-			auto bin_of = [&](double w) {
-				const unsigned int k = (unsigned int) (((unsigned long long) __double_as_longlong(w) << 1) >> 48);
+			auto bin_of_bits = [&](unsigned long long bits) {          // bits of a positive double, or its prune_key (the top bit falls out)
+				const unsigned int k = (unsigned int) ((bits << 1) >> 48);
 				return (int) min(max((int) k - (int) base, 0), 1023);
 			};
-			for (int t = tid; t < 1027; t += 256) hist[t] = 0;
+			auto bin_of = [&](double w) { return bin_of_bits((unsigned long long) __double_as_longlong(w)); };
+			for (int t = tid; t < 1028; t += 256) hist[t] = 0;
 			__syncthreads();
-			for (int e = tid; e < ne; e += 256) atomicAdd(&hist[bin_of(a.emit_w[eb + e])], 1);
-			__syncthreads();
-			if (wv == 0) {   // from the top bin down: the first bin at which `cut` entries are reached. Lane l: bins 1023 - 16 l .. 1008 - 16 l
-				int mine = 0;
+			// (up to 2048 emitted entries a thread keeps its weights for the scatter below: one trip to memory instead of two)
+			constexpr int WK = 8;
+			const bool keepw = ne <= 256 * WK;
+			double wk[WK];
 #pragma unroll
-				for (int q = 0; q < 16; q++) mine += hist[1023 - (16 * lane + q)];
+			for (int q = 0; q < WK; q++) {
+				const int e = tid + 256 * q;
+				wk[q] = (keepw && e < ne) ? a.emit_w[eb + e] : 0.0;
+			}
+			if (keepw) {
+#pragma unroll
+				for (int q = 0; q < WK; q++) {
+					if (tid + 256 * q < ne) atomicAdd(&hist[bin_of(wk[q])], 1);
+				}
+			}
+			else {
+				for (int e = tid; e < ne; e += 256) atomicAdd(&hist[bin_of(a.emit_w[eb + e])], 1);
+			}
+			__syncthreads();
+			if (wv == 0) {
+				// from the top bin down (lane l: bins 1023 - 16 l .. 1008 - 16 l): every bin's count gives way to its start, the
+				// number of entries in the bins above it; the first bin at which `cut` entries are reached is the threshold
+				int cq[16], mine = 0;
+#pragma unroll
+				for (int q = 0; q < 16; q++) { cq[q] = hist[1023 - (16 * lane + q)]; mine += cq[q]; }
 				int incl = mine;
 #pragma unroll
 				for (int o = 1; o < 64; o <<= 1) {
 					const int y = __shfl_up(incl, o, 64);
 					if (lane >= o) incl += y;
 				}
-				const int before = incl - mine;
-				if (before < cut && cut <= incl) {
-					int run = before, T = 0;
-					for (int q = 0; q < 16; q++) {
-						run += hist[1023 - (16 * lane + q)];
-						if (run >= cut) { T = 1023 - (16 * lane + q); break; }
+				int run = incl - mine, mxb = 0;
+#pragma unroll
+				for (int q = 0; q < 16; q++) {
+					const int bq = 1023 - (16 * lane + q);
+					hist[bq] = run;
+					if (run < cut) {
+						mxb = max(mxb, cq[q]);
+						if (cut <= run + cq[q]) { s_T = bq; s_cnt = run + cq[q]; }
 					}
-					s_T = T; s_cnt = run;
+					run += cq[q];
 				}
+#pragma unroll
+				for (int o = 32; o > 0; o >>= 1) mxb = max(mxb, __shfl_xor(mxb, o, 64));
+				if (lane == 0) s_maxb = mxb;
 			}
 			__syncthreads();
 			const int T = s_T, cnt = s_cnt;
-			if (cnt <= NS) {   // (else: a crowd of equal weights at the cut — the passes below take everything)
+			if (cnt <= capN && s_maxb <= 512) {
+				unsigned long long* const kw = (unsigned long long*) (smem + lay.x);   // [capN] full keys, bin after bin
+				unsigned int* const ks = (unsigned int*) (kw + capN);                  // [capN] their slots
+				// their canonical indices, which decide between equal weights (components never detected since birth: dozens of
+				// them), beside the slots when the pool has the room; read from memory pair by pair otherwise
+				const bool haveki = xsize >= NS + 516 + capN + 2;
+				unsigned int* const ki = out + capN;
+				auto place = [&](double w, int e) {
+					const int bq = bin_of(w);
+					if (bq >= T) {
+						const int pos = atomicAdd(&hist[bq], 1);   // (the start becomes the end)
+						kw[pos] = prune_key(w);
+						ks[pos] = (unsigned int) e;
+						if (haveki) ki[pos] = (unsigned int) a.emit_idx[eb + e];
+					}
+				};
+				if (keepw) {
+#pragma unroll
+					for (int q = 0; q < WK; q++) {
+						if (tid + 256 * q < ne) place(wk[q], tid + 256 * q);
+					}
+				}
+				else {
+					for (int e = tid; e < ne; e += 256) place(a.emit_w[eb + e], e);
+				}
+				__syncthreads();
+				PHD_STAMP(6);
+				for (int pos = tid; pos < cnt; pos += 256) {
+					const unsigned long long key = kw[pos];
+					const int bq = bin_of_bits(key);
+					const int f0 = (bq == 1023) ? 0 : hist[bq + 1], f1 = hist[bq];
+					const unsigned int myslot = ks[pos];
+					int rank = 0, ties = 0;
+					for (int f = f0; f < f1; f += 4) {   // four bin-mates per trip, their keys fetched together
+						unsigned long long kf[4];
+#pragma unroll
+						for (int q = 0; q < 4; q++) kf[q] = kw[min(f + q, f1 - 1)];
+#pragma unroll
+						for (int q = 0; q < 4; q++) {
+							const bool in = f + q < f1;
+							rank += (in && kf[q] > key) ? 1 : 0;
+							ties += (in && kf[q] == key) ? 1 : 0;
+						}
+					}
+					if (ties > 1) {   // others with this very weight: the canonical index decides
+						const int myidx = haveki ? (int) ki[pos] : a.emit_idx[eb + myslot];
+						for (int f = f0; f < f1; f++) {
+							if (f != pos && kw[f] == key) {
+								const int fidx = haveki ? (int) ki[f] : a.emit_idx[eb + ks[f]];
+								if (fidx < myidx) rank++;
+							}
+						}
+					}
+					out[f0 + rank] = myslot;
+				}
+				__syncthreads();
+				PHD_STAMP(11);
+				order = out;
+				ranked = true;
+				taken = ne;
+			}
+			else if (ne > 1024 && cnt <= NS) {   // (else: a crowd of equal weights at the cut — the passes below take everything)
 				n = 256;
 				while (n < cnt) n <<= 1;
 				for (int e = tid; e < ne; e += 256) {
@@ -283,7 +379,7 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 				prefilled = true;
 			}
 		}
-		while (first || taken < ne) {
+		while (!ranked && (first || taken < ne)) {
 			// first pass: fill [0, n); later passes (n == NS): refill the worse half [n/2, n)
 			const int from = first ? 0 : (n >> 1);
 			for (int t = from + tid; t < n && !prefilled; t += 256) {
@@ -344,7 +440,7 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 	const MixView vpre = bank_view(a, SEL_IN);
 	const int nprior = vpre.count[p], npredicted = nprior + a.born_count[p];
 	for (int r = tid; r < cut; r += 256) {
-		const int slt = (int) (sw[r] & smask);
+		const int slt = (int) (order[r] & smask);
 		const int cidx = a.emit_idx[eb + slt];   // position in the reference's `corrected` list
 		double v[9];
 		if (cidx < npredicted) {
