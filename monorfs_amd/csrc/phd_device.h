@@ -279,9 +279,9 @@ __device__ __forceinline__ double exp_neg(double x, const double* __restrict__ T
 	return ldexp(t * p, ni >> 8);
 }
 
-// The same for the dense pair loops (k_sweep's weight sums, k_alpha_density), three instructions leaner at the front: the
+// The same for the dense pair loops (k_sweep's weight sums, k_alpha_density), four instructions leaner at the front: the
 // argument is clamped by one v_max_f64 and rounded by adding 1.5 * 2^52, which leaves the integer in the low word of the
-// sum (no v_rndne / v_cvt). Same table, same polynomial, same results as exp_neg for finite arguments and -inf; a NaN
+// sum (no v_rndne / v_cvt). Same table, same polynomial, results within an ulp of exp_neg's for the arguments that matter; a NaN
 // argument counts as exp(-800) = 0 here (v_max_f64 returns the other operand), where exp_neg keeps it a NaN.
 // keep = false: the result is 0 (the exponent handed to v_ldexp_f64 is replaced: one 32-bit select instead of two on the value)
 __device__ __forceinline__ double exp_pair(double x, const double* __restrict__ T, bool keep = true)
@@ -293,8 +293,10 @@ __device__ __forceinline__ double exp_pair(double x, const double* __restrict__ 
 	const double nd = fma(x, 369.3299304675746, 6755399441055744.0);   // 256 / ln 2; 1.5 * 2^52
 	const int ni = __double2loint(nd);
 	const double n = nd - 6755399441055744.0;
-	double r = fma(-n, 0.002707606166950427, x);
-	r = fma(-n, 7.111859369156821e-12, r);
+	// (ln 2 / 256 as ONE constant: the product inside the fused multiply-add is exact, what is lost is the constant's own
+	// rounding, 2.2e-19, times n = 369 |x| — a relative 8e-17 |x| of exp(x), i.e. below an ulp for the terms that carry a sum
+	// (|x| of a few) and far below the sum's own rounding for the terms that are small against them. exp_neg keeps both parts.)
+	const double r = fma(-n, 0.0027076061740622863, x);
 	const double t = T[ni & (EXPTAB_N - 1)];
 	double p;
 	asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "s"(c4), "v"(r), "v"(c3));
