@@ -16,9 +16,16 @@ def short(name):
     return re.sub(r"<.*>$", "", name)
 
 
+def newest(pattern):
+    """gpurun merges a run's files into what earlier runs left under the same directory (the file names carry the process
+    id): only the newest file of a kind is this run's."""
+    fs = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return fs[-1:]
+
+
 def load_counters(d):
     out = defaultdict(lambda: defaultdict(list))
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(d, "*", "*_counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             out[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
     return out
@@ -28,13 +35,13 @@ def main():
     src, name = sys.argv[1], sys.argv[2]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     stats = {}
-    for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
+    for f in newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
         for row in csv.DictReader(open(f)):
             stats[short(row["Name"])] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3,
                                          "min_us": float(row["MinNs"]) / 1e3, "max_us": float(row["MaxNs"]) / 1e3,
                                          "pct": float(row["Percentage"])}
     res = {}
-    for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv")):
+    for f in newest(os.path.join(src, "trace", "*", "*_kernel_trace.csv")):
         for row in csv.DictReader(open(f)):
             res.setdefault(short(row["Kernel_Name"]), {"vgpr": int(row["VGPR_Count"]), "agpr": int(row["Accum_VGPR_Count"]),
                                                         "sgpr": int(row["SGPR_Count"]), "lds": int(row["LDS_Block_Size"]),
