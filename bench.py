@@ -49,6 +49,13 @@ def parse():
     ap.add_argument("--no-events", action="store_true", help="skip the per-kernel HIP events")
     ap.add_argument("--events-every", type=int, default=8, help="time the launches of every n-th step of the timed region (each event costs the device a few microseconds)")
     ap.add_argument("--force-dist", action="store_true", help="take the sharded (RCCL) step path even with one rank (rehearsal)")
+    ap.add_argument("--collective", default="allgather", choices=["allgather", "allreduce"],
+                    help="how the particle weights meet (sharded step): allgather = RCCL all-gather of P + 1 doubles per rank (SURVEY 8e's recommendation, the default); "
+                         "allreduce = the north star's wording, one RCCL all-reduce(sum) over the zero-padded global vector (every element has one non-zero "
+                         "contributor, so the result is the gathered vector, bit for bit)")
+    ap.add_argument("--host-plan", action="store_true",
+                    help="sharded step as in round 3: the host waits for the plan's split sizes and moves the migrating particles with all_to_all_single "
+                         "(default: no host wait — peer stores through IPC-opened receive buffers, a one-word all-reduce as the landing barrier)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra legs of the N = 1 run (isolated kernel times, other modes)")
     ap.add_argument("--extra-steps", type=int, default=100, help="timed steps of every extra leg (SURVEY 8d: >= 100)")
     ap.add_argument("--single-process", action="store_true",
@@ -264,19 +271,36 @@ def main():
     nav.set_all_pairs(True)  # benchmark mode: all C x M pairs evaluated, the gate only masks — the unit count is exact
     lib, h = nav._lib, nav._h
 
+    sharded_info = None
     if use_dist:
         # the library launches on torch's current stream: RCCL collectives and kernels are ordered by the stream
         nav._check(lib.phd_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream), 1))
         Pg = P * world
-        gw = torch.as_tensor(DevArray(lib.phd_device_global_weights(h, Pg), Pg), device="cuda")
-        scounts = np.zeros(world, np.int32)
-        rcounts = np.zeros(world, np.int32)
-        ip = C.POINTER(C.c_int32)
         lw_ptr = lib.phd_device_local_weights(h)          # fixed addresses: the export buffer and the migration buffers
-        bpp = C.c_int64(0)
-        mig_send = lib.phd_migration_send_buffer(h, C.byref(bpp))
-        mig_recv = lib.phd_migration_recv_buffer(h)
-        mig_rec = bpp.value // 8
+        if args.host_plan:
+            gw = torch.as_tensor(DevArray(lib.phd_device_global_weights(h, Pg), Pg), device="cuda")
+            scounts = np.zeros(world, np.int32)
+            rcounts = np.zeros(world, np.int32)
+            ip = C.POINTER(C.c_int32)
+            bpp = C.c_int64(0)
+            mig_send = lib.phd_migration_send_buffer(h, C.byref(bpp))
+            mig_recv = lib.phd_migration_recv_buffer(h)
+            mig_rec = bpp.value // 8
+            sharded_info = {"plan": "device, its split sizes waited for by the host", "migration": "all_to_all_single", "collective": "allgather"}
+        else:
+            # every rank's receive buffer, opened by every other rank (hipIpcMemHandle): the senders' kernels store the
+            # migrating particles straight into them
+            graw = torch.as_tensor(DevArray(lib.phd_device_gather_buffer(h, world), world * (P + 1)), device="cuda")
+            lw1 = torch.as_tensor(DevArray(lw_ptr, P + 1), device="cuda")
+            hbuf = C.create_string_buffer(64)
+            nav._check(lib.phd_migration_ipc_export(h, hbuf, None))
+            handles = [None] * world
+            dist.all_gather_object(handles, bytes(hbuf.raw))
+            nav._check(lib.phd_migration_ipc_open(h, b"".join(handles), rank, world))
+            token = torch.zeros(1, dtype=torch.float32, device="cuda")
+            sharded_info = {"plan": "device", "migration": "peer stores into IPC-opened receive buffers, one-word all-reduce as the landing barrier",
+                            "collective": args.collective, "recv_buffer_finegrained": bool(lib.phd_migration_recv_is_finegrained(h) == 1),
+                            "p2p": [bool(r == local_rank or torch.cuda.can_device_access_peer(local_rank, r)) for r in range(torch.cuda.device_count())][:max(world, 1)]}
 
     cache = {}
 
@@ -289,9 +313,36 @@ def main():
 
     empty = torch.empty(0, dtype=torch.float64, device="cuda") if use_dist else None
 
+    phase_ev = None   # (set for a few steps behind the timed region: torch events at the phase boundaries of a sharded step)
+
+    def mark(i):
+        if phase_ev is not None:
+            phase_ev[-1][i].record()
+
     def step(u=0.5):
         if not use_dist:
             nav.step_async(u)
+            return
+        if not args.host_plan:
+            # nothing here waits for the device: five enqueues and two collectives per step, all on one stream
+            mark(0)
+            nav._check(lib.phd_step_local_async(h, 0))
+            mark(1)
+            if args.collective == "allgather":
+                dist.all_gather_into_tensor(graw, lw1)
+            else:
+                graw.zero_()
+                graw[rank * (P + 1):(rank + 1) * (P + 1)].copy_(lw1)
+                dist.all_reduce(graw)
+            mark(2)
+            nav._check(lib.phd_step_global_device_async(h, rank, world, u, 0))
+            mark(3)
+            nav._check(lib.phd_migration_push_async(h))
+            mark(4)
+            dist.all_reduce(token)       # stream-ordered behind the push: once it has run, every rank's records have landed
+            mark(5)
+            nav._check(lib.phd_migration_unpack_async(h))
+            mark(6)
             return
         nav._check(lib.phd_step_local_async(h, 0))
         dist.all_gather_into_tensor(gw, dev_tensor(lw_ptr, P))
@@ -329,6 +380,35 @@ def main():
         elapsed = float(t.item())
     kernels = nav.last_timings()
     launches = nav.last_timing_counts() if kernels else {}
+    if use_dist and not args.host_plan:
+        # per-phase device time of the sharded step (torch events on the stream, 16 steps behind the timed region), and
+        # what the collectives cost on this node, alone on the stream
+        phase_ev = []
+        for _ in range(16):
+            phase_ev.append([torch.cuda.Event(enable_timing=True) for _ in range(7)])
+            step()
+        barrier()
+        names = ("local_step", "weights_collective", "global_resample_and_plan", "push", "landing_barrier", "unpack")
+        sharded_info["phase_ms"] = {nm: float(np.mean([e[i].elapsed_time(e[i + 1]) for e in phase_ev])) for i, nm in enumerate(names)}
+        phase_ev = None
+
+        def probe(fn, n=20):
+            fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(n):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / n * 1e3
+        stats = torch.zeros(3, dtype=torch.float64, device="cuda")
+        big = torch.zeros(world * (P + 1), dtype=torch.float64, device="cuda")
+        sharded_info["rccl_probe_us"] = {
+            "all_gather_P_plus_1_doubles": probe(lambda: dist.all_gather_into_tensor(big, lw1)),
+            "all_reduce_sum_3_doubles (SURVEY 8e's {sum w, sum w^2, max} variant: G-dependent order, normalisation constants only)": probe(lambda: dist.all_reduce(stats)),
+            "all_reduce_sum_zero_padded_global_vector": probe(lambda: dist.all_reduce(big)),
+            "all_reduce_1_word (the landing barrier)": probe(lambda: dist.all_reduce(token))}
 
     # ---- extra legs of the single-GPU run, all outside the timed region ------------------------------------------------
     # (1) every kernel alone on the chip: the same step on ONE stream (phd_set_split(1)), HIP events around every launch.
@@ -513,6 +593,7 @@ def main():
         out["host_issue_us_per_step"] = host_issue / args.steps * 1e6   # time inside the step calls, one caller thread
         if use_dist:
             out["rccl_ranks"] = dist.get_world_size()
+            out["sharded_step"] = sharded_info
         if kernels:
             # the step's per-particle kernels run once per particle sub-range (phd_set_split): a kernel's cost per
             # step is its mean launch duration x launches per step, and the dominant kernel is the largest of those

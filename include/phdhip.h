@@ -38,8 +38,10 @@
 extern "C" {
 #endif
 
-#define PHD_API_VERSION 3   /* 2: phd_create_multi, phd_set_association_workspace; phd_migration_local_async gone
-                               3: phd_multi_report; phd_device_local_weights is an export buffer; the migration plan is made on the device */
+#define PHD_API_VERSION 4   /* 2: phd_create_multi, phd_set_association_workspace; phd_migration_local_async gone
+                               3: phd_multi_report; phd_device_local_weights is an export buffer; the migration plan is made on the device
+                               4: the sharded step without a host wait (phd_step_global_device_async, phd_migration_push_async, the IPC
+                                  calls); phd_device_local_weights holds P + 1 doubles; the device keeps one 80-byte record per component */
 
 /* status codes */
 #define PHD_OK                    0
@@ -111,15 +113,19 @@ phd_navigator* phd_create(const phd_params* params, int device);
 /* The same over several devices of one node (SURVEY §8b "device list", §8e): ONE handle, ONE caller thread — what a C# host
  * can drive (Simulation.Update runs the solver from one thread, Simulation.cs:636-673; it has no RCCL). The particles are
  * sharded contiguously, ndevices equal shards: params->max_particles and every particle count are TOTALS and multiples of
- * ndevices. A step runs the shards' kernels concurrently, all-gathers the un-normalised weights with peer copies over xGMI
- * (16 KB per pair at 2048 particles per GPU), computes the identical normalisation / BestParticle / systematic resampling on
- * every device and migrates the particles whose source lives elsewhere, again with peer copies: results are bit-identical
- * to a single-device handle holding all particles, for any ndevices. A device may be listed more than once (tests).
+ * ndevices. Inside, one worker thread per shard issues that shard's launches; the shards' kernels run concurrently, the
+ * un-normalised weights (16 KB per pair at 2048 particles per GPU) and the migrating particles are stored by the kernels
+ * straight into the other shards' memory over xGMI (peer stores into fine-grained buffers: no copy engine, no host call per
+ * pair), the normalisation / BestParticle / systematic resampling and the migration plan are computed identically on every
+ * device: results are bit-identical to a single-device handle holding all particles, for any ndevices. Every pair of
+ * distinct devices must have direct peer access (the call fails, naming the pair, otherwise). A device may be listed more
+ * than once (tests; the distinct-device path has not been run on hardware by the builder: one-GPU boxes).
  * Available on such a handle: phd_reset, phd_set_poses / _weights / _map, phd_update_motion, phd_slam_update,
- * phd_set_measurements / phd_step_async / phd_sync (the step returns once the resampling plan is known: it is not fully
- * asynchronous), the getters, phd_upload / download_state_soa, phd_set_frozen / _split / _association_workspace,
- * phd_quasi_set_loglik[_grad], phd_resample / phd_particle_depleted, the timing calls (first shard); the stage-level KAT entry
- * points and the per-rank sharding primitives below return PHD_ERR_BAD_ARGUMENT.                                       */
+ * phd_set_measurements / phd_step_async / phd_sync — phd_step_async only POSTS the step to the workers and returns (a ring
+ * of 256 posted steps; nothing of a step waits for the host, what it finds surfaces at phd_sync) —, the getters, phd_upload /
+ * download_state_soa, phd_set_frozen / _split / _all_pairs / _association_workspace, phd_quasi_set_loglik[_grad], phd_resample /
+ * phd_particle_depleted, the timing calls (first shard); the stage-level KAT entry points and the per-rank sharding primitives
+ * below return PHD_ERR_BAD_ARGUMENT.                                                                                     */
 phd_navigator* phd_create_multi(const phd_params* params, const int* devices, int ndevices);
 /* Diagnostics of a multi-device handle (bench.py --single-process). out8 (NINE doubles): [0..4] mean device time (ms) of the phases of the
  * sampled steps on the first shard's stream — local step | waiting for the other shards' weights | global resampling + plan
@@ -236,8 +242,9 @@ int phd_particle_depleted(phd_navigator* nav, const double* weights, int npartic
  *                          the gathered vector (identical on every rank), local part of the copy;
  * Device pointers are exposed so the collective runs on device memory without staging.          */
 int   phd_step_local_async(phd_navigator* nav, uint8_t onlymapping);
-void* phd_device_local_weights(phd_navigator* nav);                 /* double[local particles]: an export buffer at a fixed
-                                                                       address, filled by phd_step_local_async on the handle's stream */
+void* phd_device_local_weights(phd_navigator* nav);                 /* double[local particles + 1]: an export buffer at a fixed
+                                                                       address, filled by phd_step_local_async on the handle's stream —
+                                                                       the un-normalised weights and, behind them, the step's status word */
 void* phd_device_global_weights(phd_navigator* nav, int world_particles); /* double[world]         */
 int   phd_step_global_async(phd_navigator* nav, int rank, int world_size, double u_resample);
 /* Particle migration after a global resample: packs the particles other ranks need into a
@@ -268,6 +275,29 @@ void* phd_migration_send_buffer(phd_navigator* nav, int64_t* bytes_per_particle)
 void* phd_migration_recv_buffer(phd_navigator* nav);
 int   phd_migration_pack_async(phd_navigator* nav);
 int   phd_migration_unpack_async(phd_navigator* nav);
+/* The sharded step with NOTHING for the host to wait for (round 4; what `bench.py --gpus N` runs). The senders store each
+ * migrating particle straight into its place in the receiver's buffer, from the plan the device made; RCCL carries exactly
+ * what the north star names, the particle weights:
+ *   once      every rank: phd_migration_ipc_export -> 64 bytes (hipIpcMemHandle_t of its receive buffer, fine-grained device
+ *             memory); the hosts exchange them; phd_migration_ipc_open(all of them, in rank order). Shards that live in ONE
+ *             process hand each other's phd_migration_recv_buffer to phd_migration_set_peers instead.
+ *   per step  phd_step_local_async
+ *             all-gather of the P + 1 doubles of phd_device_local_weights into phd_device_gather_buffer(world) [world][P + 1]
+ *             phd_step_global_device_async   the status words of ALL ranks are read (a flag anywhere drops the step everywhere),
+ *                                            global normalise / BestParticle / resampling, the migration plan — on the device
+ *             phd_migration_push_async       peer stores of the migrating records
+ *             a one-word all-reduce on the same stream: "every rank's records have landed"
+ *             phd_migration_unpack_async
+ * The host never learns whether the step resampled, how many particles moved, or whether a flag dropped it, before phd_sync
+ * (which reports a step dropped here because ANOTHER rank raised a flag as PHD_ERR_GENERIC; that rank's own phd_sync names
+ * the flag). Results are bit-identical to the host-plan sequence above and to a single handle holding all particles.   */
+void* phd_device_gather_buffer(phd_navigator* nav, int world_size);   /* double[world_size][max_particles + 1]; rank r's P + 1 doubles at r * (P + 1) */
+int   phd_step_global_device_async(phd_navigator* nav, int rank, int world_size, double u_resample, uint8_t onlymapping);
+int   phd_migration_ipc_export(phd_navigator* nav, void* handle64, int64_t* buffer_bytes);
+int   phd_migration_ipc_open(phd_navigator* nav, const void* handles /* [world_size][64] */, int rank, int world_size);
+int   phd_migration_set_peers(phd_navigator* nav, void* const* recv_buffers /* [world_size], entry `rank` ignored */, int rank, int world_size);
+int   phd_migration_recv_is_finegrained(phd_navigator* nav);         /* 1 / 0; -1: no buffer                                         */
+int   phd_migration_push_async(phd_navigator* nav);
 void* phd_stream(phd_navigator* nav);                               /* hipStream_t of the handle   */
 /* Lend the handle a host stream (hipStream_t, NULL = the default stream): kernels and the host's
  * collectives are then ordered by that stream and need no synchronisation in between;
@@ -312,10 +342,12 @@ int phd_last_timings(phd_navigator* nav, const char*** names, const double** ms)
  * once per particle sub-range).                                                                  */
 int phd_last_timing_counts(phd_navigator* nav, const int** counts);
 
-/* Bulk upload / download of the whole particle set in the device layout (benchmark and tests):
+/* Bulk upload / download of the whole particle set (benchmark and tests), host arrays plane per field:
  * planes[10][nparticles][stride] = w, mean x y z, covariance xx xy xz yy yz zz; counts[nparticles];
- * poses7[nparticles][7]; weights[nparticles]. The upload sets the particle count; the download gathers the maps of a
- * resampled state into place first (see phd_set_map).                                           */
+ * poses7[nparticles][7]; weights[nparticles]. (The device keeps ONE 80-byte record per component — w, mean, covariance
+ * upper triangle —, [particle][slot][10]: the conversion happens here, at the edge; only the first counts[i] slots of a
+ * particle are read / written.) The upload sets the particle count; the download gathers the maps of a resampled state
+ * into place first (see phd_set_map).                                                            */
 int phd_upload_state_soa(phd_navigator* nav, int nparticles, int stride, const double* planes,
                          const int32_t* counts, const double* poses7, const double* weights);
 int phd_download_state_soa(phd_navigator* nav, int stride, double* planes, int32_t* counts,

@@ -4,7 +4,7 @@ Field order and types must match `struct phd_params` exactly (include/phdhip.h).
 import ctypes as C
 import math
 
-PHD_API_VERSION = 3
+PHD_API_VERSION = 4
 
 PHD_OK, PHD_ERR_GENERIC = 0, -1
 PHD_ERR_BAD_ARGUMENT, PHD_ERR_CAPACITY, PHD_ERR_ASSOCIATION, PHD_ERR_DEVICE, PHD_ERR_NO_DEVICE = 1, 2, 3, 4, 5

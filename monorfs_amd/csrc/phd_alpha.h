@@ -794,7 +794,7 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 	};
 	double wpart = 0;
 	for (int c = tid; c < no; c += 256) {
-		double wc = vout.w[sbo + c];
+		double wc = a.outw[sbo + c];   // (k_prune_merge's plane of the pruned weights: the records themselves are read for the picks only)
 		keyw[c] = wc;
 		wpart += wc;
 	}
@@ -1027,7 +1027,9 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 		}
 		else {
 			int c = pick[j];
-			double l0 = vout.m[0][sbo + c], l1 = vout.m[1][sbo + c], l2 = vout.m[2][sbo + c];
+			const double2* rc = (const double2*) (vout.rec + (sbo + c) * MIX_REC);   // its mean: the first 32 bytes of the record
+			const double2 r0 = rc[0], r1 = rc[1];
+			double l0 = r0.y, l1 = r1.x, l2 = r1.y;
 			lm[j] = l0; lm[JS + j] = l1; lm[2 * JS + j] = l2;
 			double* glm = a.alm + (size_t) p * 3 * a.Jcap;   // for k_alpha_density
 			glm[j] = l0; glm[a.Jcap + j] = l1; glm[2 * a.Jcap + j] = l2;
@@ -1983,7 +1985,8 @@ __device__ __forceinline__ void alpha_density_body(const DevParams& prm, const S
 	double plog_part = 0, clog_part = 0, pcount_part = 0;
 	{
 		const int JB = (J + 63) >> 6;
-		for (int c = tid; c < n; c += 256) pcount_part += vin.w[sbi + c];
+		// (the sum of the prior weights, sum w_pred: added up where the records are staged below — thread tid takes the
+		// components tid, tid + 256, ... there, in this order)
 		for (int i = tid; i < JB * 256; i += 256) { partp[i] = 0; partc[i] = 0; }
 		for (int src = 0; src < 2; src++) {
 			const int total = (src == 0) ? np : no;
@@ -1994,11 +1997,8 @@ __device__ __forceinline__ void alpha_density_body(const DevParams& prm, const S
 					if (c < total) {
 						double w, m[3], P[6], Pi[6], det;
 						if (c < n) {
-							w = vin.w[sbi + c];
-#pragma unroll
-							for (int t = 0; t < 3; t++) m[t] = vin.m[t][sbi + c];
-#pragma unroll
-							for (int t = 0; t < 6; t++) P[t] = vin.P[t][sbi + c];
+							load_comp(vin.rec + (sbi + c) * MIX_REC, w, m, P);
+							pcount_part += w;
 						}
 						else {
 							const double* bm = a.born_mean + ((size_t) p * a.Mcap + (c - n)) * 3;
@@ -2024,11 +2024,7 @@ __device__ __forceinline__ void alpha_density_body(const DevParams& prm, const S
 					cend = s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
 					if (other) {
 						double w, m[3], P[6], Pi[6], det;
-						w = vout.w[sbo + c];
-#pragma unroll
-						for (int t = 0; t < 3; t++) m[t] = vout.m[t][sbo + c];
-#pragma unroll
-						for (int t = 0; t < 6; t++) P[t] = vout.P[t][sbo + c];
+						load_comp(vout.rec + (sbo + c) * MIX_REC, w, m, P);
 						inv_sym3(P, Pi, det);
 						gauss_record(w, m, Pi, PHD_INV_2PI / sqrt(fabs(det)), tile + slot * DENS_REC);
 					}

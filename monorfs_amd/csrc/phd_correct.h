@@ -18,14 +18,7 @@
 __device__ __forceinline__ void load_predicted(const DevParams& prm, const StepBufs& a, const MixView& vin, int p, int n, int c,
                                                double& w, double m[3], double P[6])
 {
-	if (c < n) {
-		const size_t i = in_base(a, p) + c;
-		w = vin.w[i];
-#pragma unroll
-		for (int t = 0; t < 3; t++) m[t] = vin.m[t][i];
-#pragma unroll
-		for (int t = 0; t < 6; t++) P[t] = vin.P[t][i];
-	}
+	if (c < n) load_comp(vin.rec + (in_base(a, p) + c) * MIX_REC, w, m, P);
 	else {
 		const double* bm = a.born_mean + ((size_t) p * a.Mcap + (c - n)) * 3;
 		w = prm.birthw;
@@ -87,10 +80,7 @@ __device__ __forceinline__ void emit_finish_body(const DevParams& prm, const Ste
 		const size_t e = (size_t) p * a.ecap + slot;
 		a.emit_w[e]   = wgt;
 		a.emit_idx[e] = np + k * np + c;   // position in the reference's `corrected` list: after the np copies, z-major
-		double* r = a.emit_rec + e * 9;
-		r[0] = mn[0]; r[1] = mn[1]; r[2] = mn[2];
-#pragma unroll
-		for (int t = 0; t < 6; t++) r[3 + t] = Pn[t];
+		store_comp(a.emit_rec + e * MIX_REC, wgt, mn, Pn);   // the update as a component record, as the banks hold them
 	};
 	if (!overflow) {
 		// Most queued pairs fail once the real denominator is known. Their exponent x = log(PD w q) travels with

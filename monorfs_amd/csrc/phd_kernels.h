@@ -1,9 +1,11 @@
 // phd_kernels.h — hand-written HIP kernels (gfx950, wave64) of the RB-PHD-SLAM inner loop.
 //
 // One workgroup per particle everywhere (particles are independent through predict / correct /
-// prune / reweight: PHDNavigator.cs:326-339). Mixtures live in HBM as struct-of-arrays planes
-// (w, mean x/y/z, covariance xx/xy/xz/yy/yz/zz), each [particle][slot], so a wavefront reads 64
-// consecutive components of one particle as one 512-B line per plane.
+// prune / reweight: PHDNavigator.cs:326-339). Mixtures live in HBM as ONE 80-byte record per component
+// (w, mean x/y/z, covariance xx/xy/xz/yy/yz/zz), [particle][slot][10] doubles (round 4; ten planes before): a
+// wavefront that reads 64 consecutive components of a particle reads 5 KB of whole lines with five 16-byte loads per
+// lane, and a component picked by index (the gathers of k_prune_merge, the queued pairs of k_emit_finish, the picks of
+// BestMapEstimate) costs two 64-byte sectors instead of ten.
 //
 //   k_sweep (phd_sweep.h), k_emit_finish (phd_correct.h) : PredictConditional + CorrectConditional
 //                       (+ the MinWeight cut of PruneModel)
@@ -18,14 +20,41 @@
 #define PHD_FLAG_J_OVERFLOW      2   // map estimate larger than the landmark scratch
 #define PHD_FLAG_BIG_CLUSTER     4   // association cluster beyond the on-device solver's cap
 
+#define MIX_REC 10   // doubles per component record: w, m[3], P[6] (upper triangle)
+
 struct MixView {
-	double* w;
-	double* m[3];
-	double* P[6];
+	double* rec;      // component i of the bank (particle slot s, index c: i = s * cap + c) at rec + i * MIX_REC
 	int*    count;
 };
 
-// one of the three state banks: mixture slabs (10 planes of [Pcap][cap]), counts, poses, weights
+// a component record in and out of registers: five 16-byte accesses (records are 80 bytes apart, 16-byte aligned)
+__device__ __forceinline__ void load_comp(const double* __restrict__ r, double& w, double m[3], double P[6])
+{
+	const double2* q = (const double2*) r;
+	const double2 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
+	w = a.x; m[0] = a.y; m[1] = b.x; m[2] = b.y;
+	P[0] = c.x; P[1] = c.y; P[2] = d.x; P[3] = d.y; P[4] = e.x; P[5] = e.y;
+}
+
+__device__ __forceinline__ void store_comp(double* __restrict__ r, double w, const double m[3], const double P[6])
+{
+	double2* q = (double2*) r;
+	q[0] = make_double2(w, m[0]);
+	q[1] = make_double2(m[1], m[2]);
+	q[2] = make_double2(P[0], P[1]);
+	q[3] = make_double2(P[2], P[3]);
+	q[4] = make_double2(P[4], P[5]);
+}
+
+// `n` whole records from one place to another by the threads of the workgroup (16 bytes per thread and trip: whole lines)
+__device__ __forceinline__ void copy_comps(double* __restrict__ dst, const double* __restrict__ src, int n, int tid, int nthreads)
+{
+	double2* d = (double2*) dst;
+	const double2* s = (const double2*) src;
+	for (int i = tid; i < n * (MIX_REC / 2); i += nthreads) d[i] = s[i];
+}
+
+// one of the three state banks: mixture records [Pcap][cap][10], counts, poses, weights
 struct Bank {
 	double* mix;
 	int*    count;
@@ -33,7 +62,7 @@ struct Bank {
 	double* weights;  // [Pcap]
 };
 
-// Roles of the three banks. A bank holds the mixture planes of all particles and their small arrays (count, pose,
+// Roles of the three banks. A bank holds the mixture records of all particles and their small arrays (count, pose,
 // weight). Resampling does not copy mixtures: after it the small arrays of the new particles sit in one bank (SEL_IN)
 // while their mixtures are still the ones the step wrote into another (SEL_INMIX), particle p's at slot inslot[p]
 // (the deep copies of PHDNavigator.cs:740-741 are what an indirection makes of them). OUT differs from IN and INMIX;
@@ -54,7 +83,6 @@ struct StepBufs {
 	int Mcap;       // stride of per-measurement scratch
 	int ecap;       // emit scratch slots per particle
 	int Jcap;       // landmark scratch per particle
-	size_t plane;   // doubles per plane = Pcap * cap
 	Bank bank[3];
 	const int* sel; // [SEL_STRIDE] device-resident roles of the banks for this step (no host round trip to rotate them)
 	const int* inslot;   // [P] slot of particle p's mixture in the INMIX bank
@@ -62,7 +90,7 @@ struct StepBufs {
 	// corrected-but-unpruned components (weight >= MinWeight), unsorted
 	double* emit_w;      // [P][ecap]
 	int*    emit_idx;    // [P][ecap] canonical position in the reference's `corrected` list
-	double* emit_rec;    // [P][ecap][9]  mean, covariance upper triangle
+	double* emit_rec;    // [P][ecap][10] the detection updates as component records (w, mean, covariance upper triangle); not written for the misdetection copies
 	int*    emit_count;  // [P]
 	// births of the predict step
 	int*    born_count;  // [P]
@@ -82,7 +110,8 @@ struct StepBufs {
 	int     candcap;
 	int*    cand_count;  // [P][4] entries in each wave's segment of the queue (above candcap / 4: it overflowed)
 	double* denom;       // [P][Mcap] kappa + weightsum[z]
-	double* srec;        // [P][10][cutcap] k_prune_merge: the kept records in sorted order (mean, covariance, weight)
+	double* srec;        // [P][cutcap][12] k_prune_merge: the kept records in sorted order (component record, canonical index, spare)
+	double* outw;        // [P][cap] the weights of the pruned mixture once more, as a plane of their own (k_prune_merge -> BestMapEstimate of k_alpha_assoc, which reads nothing else of most components)
 	// map estimate handed from k_alpha_assoc to k_alpha_density
 	double* alm;         // [P][3][Jcap] landmark means
 	int*    aJ;          // [P] landmarks
@@ -115,18 +144,14 @@ __device__ __forceinline__ Bank bank_of(const StepBufs& a, int role)
 	return b;
 }
 
-// The mixtures of the bank playing `role` and the counts that go with them. For SEL_IN the planes are those of the
+// The mixtures of the bank playing `role` and the counts that go with them. For SEL_IN the records are those of the
 // INMIX bank: particle p's components start at in_base(a, p), its count is count[p].
 __device__ __forceinline__ MixView bank_view(const StepBufs& a, int role)
 {
 	const Bank b = bank_of(a, role);
 	const double* mix = (role == SEL_IN) ? bank_of(a, SEL_INMIX).mix : b.mix;
 	MixView v;
-	v.w = const_cast<double*>(mix);
-#pragma unroll
-	for (int t = 0; t < 3; t++) v.m[t] = const_cast<double*>(mix) + (size_t) (1 + t) * a.plane;
-#pragma unroll
-	for (int t = 0; t < 6; t++) v.P[t] = const_cast<double*>(mix) + (size_t) (4 + t) * a.plane;
+	v.rec = const_cast<double*>(mix);
 	v.count = b.count;
 	return v;
 }
@@ -202,11 +227,9 @@ __global__ __launch_bounds__(256) void k_expand_emit(const DevParams prm, const 
 	for (int e = tid; e < ne; e += 256) {
 		const int cidx = a.emit_idx[eb + e];
 		if (cidx < np) {
-			double w, v[9];
-			load_predicted(prm, a, vin, p, n, cidx, w, v, v + 3);
-			double* r = a.emit_rec + (eb + e) * 9;
-#pragma unroll
-			for (int t = 0; t < 9; t++) r[t] = v[t];
+			double w, m[3], P[6];
+			load_predicted(prm, a, vin, p, n, cidx, w, m, P);
+			store_comp(a.emit_rec + (eb + e) * MIX_REC, a.emit_w[eb + e], m, P);
 		}
 	}
 }
@@ -223,12 +246,7 @@ __global__ __launch_bounds__(256) void k_materialise(const StepBufs a, int* insl
 	const Bank bi = bank_of(a, SEL_IN);
 	const int n = bi.count[i];
 	const size_t db = (size_t) i * a.cap, fb = in_base(a, i);
-	double* w = bi.mix;
-	for (int c = tid; c < n; c += 256) {
-		w[db + c] = from.w[fb + c];
-#pragma unroll
-		for (int t = 0; t < 9; t++) w[(size_t) (1 + t) * a.plane + db + c] = from.w[(size_t) (1 + t) * a.plane + fb + c];
-	}
+	copy_comps(bi.mix + db * MIX_REC, from.rec + fb * MIX_REC, n, tid, 256);
 	__syncthreads();
 	if (tid == 0) inslot[i] = i;   // only this workgroup reads inslot[i]
 }
@@ -306,13 +324,7 @@ __global__ __launch_bounds__(256) void k_replicate(const StepBufs a, double weig
 	const MixView from = bank_view(a, SEL_IN), dst = bank_view(a, SEL_OUT);
 	const int n = from.count[0];
 	const size_t db = (size_t) i * a.cap, fb = in_base(a, 0);
-	for (int c = tid; c < n; c += 256) {
-		dst.w[db + c] = from.w[fb + c];
-#pragma unroll
-		for (int t = 0; t < 3; t++) dst.m[t][db + c] = from.m[t][fb + c];
-#pragma unroll
-		for (int t = 0; t < 6; t++) dst.P[t][db + c] = from.P[t][fb + c];
-	}
+	copy_comps(dst.rec + db * MIX_REC, from.rec + fb * MIX_REC, n, tid, 256);
 	const Bank bi = bank_of(a, SEL_IN);
 	const Bank bo = bank_of(a, SEL_OUT);
 	if (tid == 0) {
@@ -325,7 +337,7 @@ __global__ __launch_bounds__(256) void k_replicate(const StepBufs a, double weig
 // =================================================================================================
 // Sharded step: particles are sharded contiguously over ranks (one rank = one GPU: a process of its own
 // with RCCL, or a shard of a phd_create_multi handle); after the global resampling a slot may need a particle that lives
-// on another rank. A migrating particle travels as one fixed-size record: [count, pose(7), planes(10 x cap)] doubles.
+// on another rank. A migrating particle travels as one fixed-size record: [count, pose(7), component records (cap x 10)] doubles.
 // Everything between the global resampling kernel and the next step is decided ON THE DEVICE (k_plan_migration): the host
 // never needs the source vector, only — where a collective wants split sizes (RCCL all-to-all) — 2 n counts.
 // =================================================================================================
@@ -346,6 +358,21 @@ __global__ __launch_bounds__(256) void k_push_weights(const StepBufs a, double* 
 	if (i == 0 && flagslot >= 0) {
 		const double f = (double) *a.flags;
 		for (int t = 0; t < ndst; t++) dst[t][flagslot] = f;
+	}
+}
+
+// Per-rank host: the all-gather lands as [rank][Pl + 1] — a rank's un-normalised weights and, behind them, its status word.
+// The weights go to the contiguous vector the global kernel takes (gw[world Pl]), the status words behind it (gw[world Pl + r]).
+__global__ __launch_bounds__(256) void k_ungather(const double* __restrict__ graw, double* __restrict__ gw, int Pl, int world)
+{
+	const int g = blockIdx.x * 256 + threadIdx.x, Pg = Pl * world;
+	if (g < Pg) {
+		const int r = g / Pl, i = g - r * Pl;
+		gw[g] = graw[(size_t) r * (Pl + 1) + i];
+	}
+	else if (g < Pg + world) {
+		const int r = g - Pg;
+		gw[g] = graw[(size_t) r * (Pl + 1) + Pl];
 	}
 }
 
@@ -632,14 +659,7 @@ __global__ __launch_bounds__(256) void k_pack_particles(const StepBufs a, const 
 		const int nc = from.count[s];
 		if (tid == 0) o[0] = (double) nc;
 		if (tid < 7) o[1 + tid] = bo.poses[(size_t) s * 7 + tid];
-		const size_t fb = (size_t) s * a.cap;
-		for (int c = tid; c < nc; c += 256) {
-			o[8 + c] = from.w[fb + c];
-#pragma unroll
-			for (int t = 0; t < 3; t++) o[8 + (size_t) (1 + t) * a.cap + c] = from.m[t][fb + c];
-#pragma unroll
-			for (int t = 0; t < 6; t++) o[8 + (size_t) (4 + t) * a.cap + c] = from.P[t][fb + c];
-		}
+		copy_comps(o + 8, from.rec + (size_t) s * a.cap * MIX_REC, nc, tid, 256);
 	}
 }
 
@@ -683,13 +703,7 @@ __global__ __launch_bounds__(256) void k_finish_sharded(const StepBufs a, const 
 		const double* r = recvbuf + (size_t) i * rec;
 		const int nc = min(max((int) r[0], 0), a.cap);   // (a record is what a peer packed; never trust a count with a store loop)
 		const size_t db = (size_t) pl.fslot[i] * a.cap;
-		for (int c = tid; c < nc; c += 256) {
-			dst.w[db + c] = r[8 + c];
-#pragma unroll
-			for (int t = 0; t < 3; t++) dst.m[t][db + c] = r[8 + (size_t) (1 + t) * a.cap + c];
-#pragma unroll
-			for (int t = 0; t < 6; t++) dst.P[t][db + c] = r[8 + (size_t) (4 + t) * a.cap + c];
-		}
+		copy_comps(dst.rec + db * MIX_REC, r + 8, nc, tid, 256);
 	}
 	const Bank bo = bank_of(a, SEL_OUT), bt = bank_of(a, SEL_TMP);
 	const int code = pl.code[i];

@@ -10,8 +10,10 @@
 //                 registers (thread exchanges, lane shuffles, LDS only for the longest distances), the best
 //                 half kept while further chunks stream in; runs of equal weights are then put in
 //                 canonical-index order, which makes the order the reference's sort made stable
-//   S. stage    : the kept records are gathered once, in sorted order, into a plane-per-field slab in HBM
-//                 (every later read is coalesced); means and Euclidean bounds go to LDS
+//   S. stage    : the kept records are gathered once, in sorted order, into a slab of 96-byte rows in HBM (the
+//                 component record, as the banks and the emitted list hold it, + its canonical index: a gathered row
+//                 is two 64-byte sectors whatever its origin, a row read back is one or two lines); the Euclidean
+//                 bounds go to LDS, the means of a thread's rows stay in its registers for the grid
 //   B. pairs    : every closeness test close_i(k), k > i, in parallel, one row per thread. A Euclidean bound
 //                 |d|^2 > T^2 trace(P_i)  =>  d^T P_i^-1 d >= |d|^2 / lambda_max(P_i) > T^2
 //                 limits the candidates of a row to a ball; the rows are binned in a uniform grid (hashed
@@ -31,6 +33,7 @@
 #define PRUNE_NBR 7
 #define PRUNE_NB 4096   // buckets of the spatial hash (16-bit counters, two per LDS word)
 #define PRUNE_HEAVY 32  // a row with more candidates than this is searched by a whole wave
+#define PRUNE_ROW 12    // doubles per row of the sorted slab: w, m[3], P[6] (a component record), canonical index, spare
 
 struct PruneLds {
 	int rad2, x, scan;       // offsets in doubles
@@ -216,7 +219,7 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 	const size_t eb = (size_t) p * a.ecap;
 	const double merge_thr2 = prm.merge_thr2;   // a local copy: a lambda that captured `prm` by reference would pin the argument block to memory
 	const int cut = min(min(prm.maxq, ne), cutcap);   // weightcut: every emitted weight is already >= MinWeight
-	double* srec = a.srec + (size_t) p * 11 * cutcap;  // [11][cutcap] the kept records in sorted order: mean, covariance, weight, canonical index
+	double* srec = a.srec + (size_t) p * PRUNE_ROW * cutcap;  // [cutcap][12] the kept records in sorted order: component record (w, mean, covariance), canonical index, spare
 
 	PHD_STAMP(0);
 	// ---- A. order by (weight desc, canonical index asc)
@@ -224,6 +227,11 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 	while ((1 << sbits) < ne) sbits++;                    // bits of a slot number
 	const unsigned int smask = (1u << sbits) - 1u;
 	const unsigned int* order = sw;                       // the kept entries' slots in sorted order (low `sbits` bits)
+	// ranked path: order[r] is the entry's place in the scatter arrays instead, where its key (= its weight), its slot and
+	// (rk_ki != NULL) its canonical index are — the gather then needs no trip to memory before the record's own
+	const unsigned long long* rk_kw = nullptr;
+	const unsigned int* rk_ks = nullptr;
+	const unsigned int* rk_ki = nullptr;
 	{
 		int n = 256;                                      // (at least the width of the register sort: small maps, too, skip the barrier-per-stage version)
 		while (n < ne && n < NS) n <<= 1;                 // width of the first pass
@@ -358,11 +366,12 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 							}
 						}
 					}
-					out[f0 + rank] = myslot;
+					out[f0 + rank] = (unsigned int) pos;
 				}
 				__syncthreads();
 				PHD_STAMP(11);
 				order = out;
+				rk_kw = kw; rk_ks = ks; rk_ki = haveki ? ki : nullptr;
 				ranked = true;
 				taken = ne;
 			}
@@ -439,34 +448,85 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 	double lo0 = INFINITY, lo1 = INFINITY, lo2 = INFINITY, hi0 = -INFINITY, hi1 = -INFINITY, hi2 = -INFINITY, rmx = 0;
 	const MixView vpre = bank_view(a, SEL_IN);
 	const int nprior = vpre.count[p], npredicted = nprior + a.born_count[p];
-	for (int r = tid; r < cut; r += 256) {
-		const int slt = (int) (order[r] & smask);
-		const int cidx = a.emit_idx[eb + slt];   // position in the reference's `corrected` list
-		double v[9];
-		if (cidx < npredicted) {
-			// a misdetection copy (PHDNavigator.cs:837-840): the predicted component with another weight, read where it is
-			double wp_;
-			load_predicted(prm, a, vpre, p, nprior, cidx, wp_, v, v + 3);
+	const double* prior = vpre.rec + in_base(a, p) * MIX_REC;
+	// Row r of the sorted order: where it comes from. A misdetection copy (canonical index below the size of the predicted
+	// mixture, PHDNavigator.cs:837-840) IS the predicted component with another weight: its record is read where it is, in the
+	// prior bank (a birth's is made up); a detection update's record is the one k_emit_finish wrote. Either is one 80-byte
+	// record. First the rows' descriptions (LDS on the ranked path, the emitted list otherwise), then their records: the
+	// two trips of a thread's rows overlap.
+	double birthP[6];
+#pragma unroll
+	for (int t = 0; t < 6; t++) birthP[t] = prm.birthP[t];   // (a local copy, as merge_thr2: the lambdas below must not capture `prm`)
+	struct RowSrc { const double* rec; double w; int cidx; };
+	auto resolve = [&](int r) {
+		RowSrc o;
+		int slt;
+		if (rk_kw) {
+			const unsigned int pos = order[r];
+			slt = (int) rk_ks[pos];
+			o.w = __longlong_as_double((long long) (rk_kw[pos] & 0x7fffffffffffffffull));   // prune_key of a positive weight, undone
+			o.cidx = rk_ki ? (int) rk_ki[pos] : a.emit_idx[eb + slt];
 		}
 		else {
-			const double* rec = a.emit_rec + (eb + slt) * 9;
-#pragma unroll
-			for (int t = 0; t < 9; t++) v[t] = rec[t];
+			slt = (int) (order[r] & smask);
+			o.w = a.emit_w[eb + slt];
+			o.cidx = a.emit_idx[eb + slt];
 		}
-		const double w = a.emit_w[eb + slt];
+		o.rec = (o.cidx < nprior) ? prior + (size_t) o.cidx * MIX_REC : a.emit_rec + (eb + slt) * MIX_REC;
+		return o;
+	};
+	// the record of a resolved row into the slab; its bound into LDS; the box and the largest radius; its mean handed back
+	auto stage = [&](int r, const RowSrc& o, double mo[3]) {
+		double w_, m[3], P[6];
+		if (o.cidx >= nprior && o.cidx < npredicted) {   // the copy of a birth: mean from the sweep, BirthCovariance
+			const double* bm = a.born_mean + ((size_t) p * a.Mcap + (o.cidx - nprior)) * 3;
+			m[0] = bm[0]; m[1] = bm[1]; m[2] = bm[2];
 #pragma unroll
-		for (int t = 0; t < 9; t++) srec[(size_t) t * cutcap + r] = v[t];
-		srec[(size_t) 9 * cutcap + r] = w;
-		srec[(size_t) 10 * cutcap + r] = (double) cidx;
-		const double P0 = v[3], P1 = v[4], P2 = v[5], P3 = v[6], P4 = v[7], P5 = v[8];
+			for (int t = 0; t < 6; t++) P[t] = birthP[t];
+		}
+		else load_comp(o.rec, w_, m, P);
+		double2* row = (double2*) (srec + (size_t) r * PRUNE_ROW);
+		row[0] = make_double2(o.w, m[0]); row[1] = make_double2(m[1], m[2]);
+		row[2] = make_double2(P[0], P[1]); row[3] = make_double2(P[2], P[3]); row[4] = make_double2(P[4], P[5]);
+		row[5] = make_double2((double) o.cidx, 0.0);
+		const double P0 = P[0], P1 = P[1], P2 = P[2], P3 = P[3], P4 = P[4], P5 = P[5];
 		double det = P0 * (P3 * P5 - P4 * P4) - P1 * (P1 * P5 - P4 * P2) + P2 * (P1 * P4 - P3 * P2);
 		bool pd = P0 > 0 && (P0 * P3 - P1 * P1) > 0 && det > 0;   // Sylvester
 		double rad = pd ? sqrt(merge_thr2 * (P0 + P3 + P5)) : INFINITY;
 		rad2[r] = rad * rad * (1.0 + 1e-6);
 		if (pd) rmx = fmax(rmx, rad);
-		lo0 = fmin(lo0, v[0]); lo1 = fmin(lo1, v[1]); lo2 = fmin(lo2, v[2]);
-		hi0 = fmax(hi0, v[0]); hi1 = fmax(hi1, v[1]); hi2 = fmax(hi2, v[2]);
+		lo0 = fmin(lo0, m[0]); lo1 = fmin(lo1, m[1]); lo2 = fmin(lo2, m[2]);
+		hi0 = fmax(hi0, m[0]); hi1 = fmax(hi1, m[1]); hi2 = fmax(hi2, m[2]);
+		mo[0] = m[0]; mo[1] = m[1]; mo[2] = m[2];
+	};
+	// (the means of a thread's first four rows — all of them up to 1024 kept entries — stay in registers for the grid below:
+	// it reads nothing back)
+	double kmean[4][3];
+#pragma unroll
+	for (int q = 0; q < 4; q++) { kmean[q][0] = 0; kmean[q][1] = 0; kmean[q][2] = 0; }
+#pragma unroll
+	for (int q = 0; q < 4; q += 2) {
+		const int ra = tid + 256 * q, rb = ra + 256;
+		if (ra < cut) {   // (two rows per trip)
+			const RowSrc oa = resolve(ra);
+			if (rb < cut) {
+				const RowSrc ob = resolve(rb);
+				stage(ra, oa, kmean[q]);
+				stage(rb, ob, kmean[q + 1]);
+			}
+			else stage(ra, oa, kmean[q]);
+		}
 	}
+	for (int r = tid + 1024; r < cut; r += 256) {
+		double mdummy[3];
+		stage(r, resolve(r), mdummy);
+	}
+	// the mean of slab row r: the 32 bytes at its head, one sector
+	auto slab_mean = [&](int r, double& x0, double& x1, double& x2) {
+		const double2* row = (const double2*) (srec + (size_t) r * PRUNE_ROW);
+		const double2 u0 = row[0], u1 = row[1];
+		x0 = u0.y; x1 = u1.x; x2 = u1.y;
+	};
 	{
 		double red7[7] = {-lo0, -lo1, -lo2, hi0, hi1, hi2, rmx};   // all as maxima
 #pragma unroll
@@ -509,11 +569,22 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 		for (int t = tid; t < (PRUNE_NB + 2) / 2 + 1; t += 256) cw[t] = 0;
 		__syncthreads();
 		// counting sort of the rows by bucket (16-bit counters: cut <= 65535)
-		for (int r = tid; r < cut; r += 256) {
-			const double s0 = srec[r] - mn0, s1 = srec[(size_t) cutcap + r] - mn1, s2 = srec[(size_t) 2 * cutcap + r] - mn2;
+		// (a row's mean: in this thread's registers since the gather — rows tid + 256 q, q < 4 — or, beyond 1024 kept
+		// entries, back from its slab row)
+		auto count_row = [&](int r, double x0, double x1, double x2) {
+			const double s0 = x0 - mn0, s1 = x1 - mn1, s2 = x2 - mn2;
 			const int b = bucket((int) (s0 * icell), (int) (s1 * icell), (int) (s2 * icell));
 			owner[r] = b;
 			atomicAdd(&cw[b >> 1], 1u << (16 * (b & 1)));
+		};
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			if (tid + 256 * q < cut) count_row(tid + 256 * q, kmean[q][0], kmean[q][1], kmean[q][2]);
+		}
+		for (int r = tid + 1024; r < cut; r += 256) {
+			double x0, x1, x2;
+			slab_mean(r, x0, x1, x2);
+			count_row(r, x0, x1, x2);
 		}
 		__syncthreads();
 		{   // inclusive prefix over the bucket counts: cstart[b] = end of bucket b; the fill below counts it down to its start
@@ -541,13 +612,22 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 			if (tid == 0) cw[PRUNE_NB / 2] = (unsigned int) cut;   // cstart[NB]: the end of the last bucket
 		}
 		__syncthreads();
-		for (int r = tid; r < cut; r += 256) {
-			const double s0 = srec[r] - mn0, s1 = srec[(size_t) cutcap + r] - mn1, s2 = srec[(size_t) 2 * cutcap + r] - mn2;
+		auto fill_row = [&](int r, double x0, double x1, double x2) {
+			const double s0 = x0 - mn0, s1 = x1 - mn1, s2 = x2 - mn2;
 			const int b = owner[r], sh = 16 * (b & 1);
 			const int pos = (int) ((atomicSub(&cw[b >> 1], 1u << sh) >> sh) & 0xffff) - 1;
 			cand[pos] = make_float4((float) s0, (float) s1, (float) s2, __int_as_float(r));
 			rowpos[r] = (unsigned short) pos;
 			owner[r] = -1;
+		};
+#pragma unroll
+		for (int q = 0; q < 4; q++) {
+			if (tid + 256 * q < cut) fill_row(tid + 256 * q, kmean[q][0], kmean[q][1], kmean[q][2]);
+		}
+		for (int r = tid + 1024; r < cut; r += 256) {
+			double x0, x1, x2;
+			slab_mean(r, x0, x1, x2);
+			fill_row(r, x0, x1, x2);
 		}
 		__syncthreads();
 		PHD_STAMP(7);
@@ -628,14 +708,15 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 			double m0 = 0, m1 = 0, m2 = 0, Pi[6] = {0, 0, 0, 0, 0, 0};
 			auto test = [&](int k) {
 				if (!have) {
-					double P[6], det;
-#pragma unroll
-					for (int u = 0; u < 6; u++) P[u] = srec[(size_t) (3 + u) * cutcap + i];
+					double P[6], mm[3], wi, det;
+					load_comp(srec + (size_t) i * PRUNE_ROW, wi, mm, P);
 					inv_sym3(P, Pi, det);
-					m0 = srec[i]; m1 = srec[(size_t) cutcap + i]; m2 = srec[(size_t) 2 * cutcap + i];
+					m0 = mm[0]; m1 = mm[1]; m2 = mm[2];
 					have = true;
 				}
-				double d0 = m0 - srec[k], d1 = m1 - srec[(size_t) cutcap + k], d2 = m2 - srec[(size_t) 2 * cutcap + k];
+				double k0, k1, k2;
+				slab_mean(k, k0, k1, k2);
+				double d0 = m0 - k0, d1 = m1 - k1, d2 = m2 - k2;
 				double sq = d0 * d0 + d1 * d1 + d2 * d2;
 				if (sq <= bound && quad_sym(Pi, d0, d1, d2) < merge_thr2) {   // Gaussian.SquareMahalanobis(b.Mean) < threshold^2
 					// keep the 7 smallest row numbers, ascending (insertion through a fixed network)
@@ -754,14 +835,15 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 			double m0 = 0, m1 = 0, m2 = 0, Pi[6] = {0, 0, 0, 0, 0, 0};
 			auto exact = [&](int k) {
 				if (!have) {
-					double P[6], det;
-#pragma unroll
-					for (int u = 0; u < 6; u++) P[u] = srec[(size_t) (3 + u) * cutcap + i];
+					double P[6], mm[3], wi, det;
+					load_comp(srec + (size_t) i * PRUNE_ROW, wi, mm, P);
 					inv_sym3(P, Pi, det);
-					m0 = srec[i]; m1 = srec[(size_t) cutcap + i]; m2 = srec[(size_t) 2 * cutcap + i];
+					m0 = mm[0]; m1 = mm[1]; m2 = mm[2];
 					have = true;
 				}
-				const double d0 = m0 - srec[k], d1 = m1 - srec[(size_t) cutcap + k], d2 = m2 - srec[(size_t) 2 * cutcap + k];
+				double k0, k1, k2;
+				slab_mean(k, k0, k1, k2);
+				const double d0 = m0 - k0, d1 = m1 - k1, d2 = m2 - k2;
 				return d0 * d0 + d1 * d1 + d2 * d2 <= bound && quad_sym(Pi, d0, d1, d2) < merge_thr2;
 			};
 			auto collect = [&](bool close, int k) {   // the close rows found by the lanes, into the sorted list all lanes keep
@@ -865,15 +947,16 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 				}
 				else {
 					// more close rows than the list holds: re-test row i against every later row, 64 at a time
-					double P[6], Pi[6], det;
-#pragma unroll
-					for (int t = 0; t < 6; t++) P[t] = srec[(size_t) (3 + t) * cutcap + i];
+					double P[6], Pi[6], mm[3], wi, det;
+					load_comp(srec + (size_t) i * PRUNE_ROW, wi, mm, P);
 					inv_sym3(P, Pi, det);
-					double m0 = srec[i], m1 = srec[(size_t) cutcap + i], m2 = srec[(size_t) 2 * cutcap + i];
+					const double m0 = mm[0], m1 = mm[1], m2 = mm[2];
 					for (int s = i >> 6; s < nslots; s++) {
 						int k = s * 64 + lane;
 						if (k > i && k < cut && !((absorbed >> s) & 1u)) {
-							if (quad_sym(Pi, m0 - srec[k], m1 - srec[(size_t) cutcap + k], m2 - srec[(size_t) 2 * cutcap + k]) < merge_thr2) {
+							double k0, k1, k2;
+							slab_mean(k, k0, k1, k2);
+							if (quad_sym(Pi, m0 - k0, m1 - k1, m2 - k2) < merge_thr2) {
 								absorbed |= 1u << s;
 								owner[k] = i;
 							}
@@ -913,27 +996,27 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 			// from the origin loses digits of the covariance to the difference (tests: test_reweight_far_from_the_origin)
 PHD_REF_ARITH
 			const int pos = base + __popcll(bal & lanemask_lt());
-			double rec[10];
-#pragma unroll
-			for (int t = 0; t < 10; t++) rec[t] = srec[(size_t) t * cutcap + i];
+			// (this row's slab record: the component record and, in the sixth 16 bytes, its canonical index)
+			double w, mi[3], Pr[6];
+			load_comp(srec + (size_t) i * PRUNE_ROW, w, mi, Pr);
+			const int cidx = (int) srec[(size_t) i * PRUNE_ROW + 10];
 			// Gaussian.Merge (Gaussian.cs:329-346): raw moments, the candidate first, then its set in list order
-			double w = rec[9], m0 = rec[0], m1 = rec[1], m2 = rec[2];
+			const double m0 = mi[0], m1 = mi[1], m2 = mi[2];
 			double W = 0.0 + w;
 			double M0 = 0.0 + w * m0, M1 = 0.0 + w * m1, M2 = 0.0 + w * m2;
-			double C0 = 0.0 + w * (rec[3] + m0 * m0), C1 = 0.0 + w * (rec[4] + m0 * m1), C2 = 0.0 + w * (rec[5] + m0 * m2);
-			double C3 = 0.0 + w * (rec[6] + m1 * m1), C4 = 0.0 + w * (rec[7] + m1 * m2), C5 = 0.0 + w * (rec[8] + m2 * m2);
+			double C0 = 0.0 + w * (Pr[0] + m0 * m0), C1 = 0.0 + w * (Pr[1] + m0 * m1), C2 = 0.0 + w * (Pr[2] + m0 * m2);
+			double C3 = 0.0 + w * (Pr[3] + m1 * m1), C4 = 0.0 + w * (Pr[4] + m1 * m2), C5 = 0.0 + w * (Pr[5] + m2 * m2);
 			int nabs = 0;
 			auto absorb = [&](int k) {
 PHD_REF_ARITH
 				nabs++;
-				double rk[10];
-#pragma unroll
-				for (int t = 0; t < 10; t++) rk[t] = srec[(size_t) t * cutcap + k];
-				double wk = rk[9], k0 = rk[0], k1 = rk[1], k2 = rk[2];
+				double wk, mk[3], Pk[6];
+				load_comp(srec + (size_t) k * PRUNE_ROW, wk, mk, Pk);
+				const double k0 = mk[0], k1 = mk[1], k2 = mk[2];
 				W += wk;
 				M0 += wk * k0; M1 += wk * k1; M2 += wk * k2;
-				C0 += wk * (rk[3] + k0 * k0); C1 += wk * (rk[4] + k0 * k1); C2 += wk * (rk[5] + k0 * k2);
-				C3 += wk * (rk[6] + k1 * k1); C4 += wk * (rk[7] + k1 * k2); C5 += wk * (rk[8] + k2 * k2);
+				C0 += wk * (Pk[0] + k0 * k0); C1 += wk * (Pk[1] + k0 * k1); C2 += wk * (Pk[2] + k0 * k2);
+				C3 += wk * (Pk[3] + k1 * k1); C4 += wk * (Pk[4] + k1 * k2); C5 += wk * (Pk[5] + k2 * k2);
 			};
 			const unsigned long long lo = nbr[2 * i], hi = nbr[2 * i + 1];
 			const int cnt = (int) (lo & 0xffff);
@@ -959,17 +1042,17 @@ PHD_REF_ARITH
 				oP[3] = C3 / W - o1 * o1; oP[4] = C4 / W - o1 * o2; oP[5] = C5 / W - o2 * o2;
 			}
 			const size_t ob = (size_t) p * a.cap + pos;
-			vout.w[ob] = ow;
-			vout.m[0][ob] = o0; vout.m[1][ob] = o1; vout.m[2][ob] = o2;
-#pragma unroll
-			for (int t = 0; t < 6; t++) vout.P[t][ob] = oP[t];
+			{
+				const double om[3] = {o0, o1, o2};
+				store_comp(vout.rec + ob * MIX_REC, ow, om, oP);
+			}
+			a.outw[ob] = ow;   // (the weights once more as a plane: all that BestMapEstimate reads of most components)
 			int covered = 0;
-			const int cidx = (int) srec[(size_t) 10 * cutcap + i];
 			if (nabs == 0 && cidx < npred && !(W < 1e-15)) {
-				const double pscale = 1e-9 * fmax(fabs(rec[3]), fmax(fabs(rec[6]), fabs(rec[8])));
+				const double pscale = 1e-9 * fmax(fabs(Pr[0]), fmax(fabs(Pr[3]), fabs(Pr[5])));
 				bool same = fabs(o0 - m0) <= 1e-9 * fabs(m0) && fabs(o1 - m1) <= 1e-9 * fabs(m1) && fabs(o2 - m2) <= 1e-9 * fabs(m2);
 #pragma unroll
-				for (int t = 0; t < 6; t++) same = same && fabs(oP[t] - rec[3 + t]) <= pscale;
+				for (int t = 0; t < 6; t++) same = same && fabs(oP[t] - Pr[t]) <= pscale;
 				if (same) { wcopy[cidx] = ow; covered = 1; }
 			}
 			a.cover[ob] = covered;

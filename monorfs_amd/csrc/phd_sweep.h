@@ -177,12 +177,8 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 				for (int q = 0; q < SW_MAPEACH; q++) {
 					const int cl = tid + q * SW_NMAP, c = c0 + cl;
 					if (c < n && cl < tl) {
-						double P[6], m[3], Pi[6], det;
-#pragma unroll
-						for (int t = 0; t < 6; t++) P[t] = vin.P[t][sb + c];
-#pragma unroll
-						for (int t = 0; t < 3; t++) m[t] = vin.m[t][sb + c];
-						const double w = vin.w[sb + c];
+						double P[6], m[3], Pi[6], det, w;
+						load_comp(vin.rec + (sb + c) * MIX_REC, w, m, P);
 						inv_sym3(P, Pi, det);
 						gauss_record(w, m, Pi, PHD_INV_2PI / sqrt(fabs(det)), tile + cl * SW_REC + 10);
 					}
@@ -194,12 +190,8 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 				double wm = 0;
 				if (c < n && cl < tl) {
 					double* tt = tile + cl * SW_REC;
-					double P[6], m[3];
-#pragma unroll
-					for (int t = 0; t < 6; t++) P[t] = vin.P[t][sb + c];
-#pragma unroll
-					for (int t = 0; t < 3; t++) m[t] = vin.m[t][sb + c];
-					const double w = vin.w[sb + c];
+					double P[6], m[3], w;
+					load_comp(vin.rec + (sb + c) * MIX_REC, w, m, P);
 					CompMeas q;
 					comp_measure(prm, pose, rq, m, P, q);
 					tt[0] = q.zh[0]; tt[1] = q.zh[1]; tt[2] = q.zh[2];

@@ -76,6 +76,7 @@ struct phd_navigator {
 	double* d_alm = nullptr; int* d_aJ = nullptr; double* d_account = nullptr;
 	double* d_stamps = nullptr;
 	double* d_srec = nullptr;
+	double* d_outw = nullptr;     // [Pcap][cap] the pruned weights as a plane (StepBufs::outw)
 	double* d_wcopy = nullptr; int* d_cover = nullptr;   // k_prune_merge -> k_alpha_density (see StepBufs)
 	double* d_motion = nullptr;   // odometry[6] + noise[P][6] of phd_update_motion
 	double* d_quasi = nullptr;    // phd_quasi_set_loglik: poses[Pcap][7], landmarks[Jcap][3], z[256][3], out[Pcap]
@@ -93,7 +94,9 @@ struct phd_navigator {
 	double*  d_lw = nullptr;                         // [Pcap] local weights, exported for the host's all-gather (per-rank host)
 	double** d_dst_tab = nullptr; int ndst = 1;      // device table: where k_push_weights stores the local weights (own d_lw | every shard's d_gw)
 	int      push_first = 0, push_flagslot = -1;     // ... at which offset, and where the status word goes (-1: nowhere)
-	double** d_recv_tab = nullptr;                   // device table: the receive buffer of every shard (multi-device handle; NULL: per-rank host)
+	double** d_recv_tab = nullptr;                   // device table: the receive buffer of every shard / rank (filled by phd_create_multi, phd_migration_set_peers / _ipc_open)
+	bool peers_set = false;                          // ... it is filled: migrating particles can be pushed
+	bool gw_shared = false;                          // other shards hold the address of d_gw (multi-device handle): it cannot grow
 	const double* d_gflags = nullptr;                // the gathered status words (multi-device handle)
 	double* d_send = nullptr; double* d_recv = nullptr; int* d_plan = nullptr; int sendrecs = 0, recvrecs = 0;
 	MigPlan plan = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};   // device-resident migration plan (k_plan_migration)
@@ -102,6 +105,11 @@ struct phd_navigator {
 	int world = 1, rank = 0;                         // of the last global step
 	int nsend = 0, nrecv = 0, last_world_particles = 1;
 	bool sharded_used = false;
+	bool sharded_ready = false;                      // every buffer of ensure_sharded is there (set behind the last allocation)
+	bool recv_finegrained = false;                   // d_recv is fine-grained device memory (coherent for the peers that store into it)
+	double* d_graw = nullptr; int grawcap = 0;       // per-rank host: the all-gather's landing buffer, [world][P + 1] (weights | status word)
+	std::vector<void*> ipc_opened;                   // peers' receive buffers opened with hipIpcOpenMemHandle (closed in phd_destroy)
+	bool plan_on_device = false;                     // the last global step left its plan on the device only (phd_step_global_device_async)
 	// host mirrors handed out by the getters
 	std::vector<double> h_weights, h_poses, h_mw, h_mm, h_mc, h_alpha, h_setll, h_tmp;
 	std::vector<int32_t> h_src;
@@ -209,7 +217,6 @@ StepBufs make_bufs(phd_navigator* nav)
 {
 	StepBufs b;
 	b.P = nav->P; b.p0 = 0; b.qposes = nullptr; b.qlm = nullptr; b.qJ = 0; b.cap = nav->cap; b.M = nav->M; b.Mcap = nav->Mcap; b.ecap = nav->ecap; b.Jcap = nav->Jcap;
-	b.plane = (size_t) nav->Pcap * nav->cap;
 	for (int i = 0; i < 3; i++) b.bank[i] = nav->bank[i];
 	b.sel = nav->d_sel + nav->parity * SEL_STRIDE;
 	b.inslot = nav->d_inslot;
@@ -220,7 +227,7 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.bigws = nav->d_bigws; b.bigws_bytes = nav->bigws_bytes; b.bigws_used = nav->d_bigws_used;
 	b.cand_count = nav->d_cand_count; b.denom = nav->d_denom;
 	b.cand = nav->d_cand; b.candcap = nav->candcap;
-	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account; b.srec = nav->d_srec; b.wcopy = nav->d_wcopy; b.cover = nav->d_cover; b.stamps = nav->d_stamps; b.all_pairs = nav->all_pairs ? 1 : 0; b.stamp_kernel = getenv("PHD_STAMP_KERNEL") ? atoi(getenv("PHD_STAMP_KERNEL")) : 2;
+	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account; b.srec = nav->d_srec; b.outw = nav->d_outw; b.wcopy = nav->d_wcopy; b.cover = nav->d_cover; b.stamps = nav->d_stamps; b.all_pairs = nav->all_pairs ? 1 : 0; b.stamp_kernel = getenv("PHD_STAMP_KERNEL") ? atoi(getenv("PHD_STAMP_KERNEL")) : 2;
 	return b;
 }
 
@@ -431,11 +438,10 @@ int fetch_map(phd_navigator* nav, int bankidx, int particle, int* ncomp, int mix
 	if (slot < 0 || slot >= nav->Pcap) return nav->fail(PHD_ERR_GENERIC, "corrupt particle slot");
 	const int srcbank = (mixbank >= 0) ? mixbank : bankidx;
 	if (n < 0 || n > nav->cap) return nav->fail(PHD_ERR_GENERIC, "corrupt component count");
-	nav->h_tmp.resize((size_t) 10 * std::max(n, 1));
-	size_t plane = (size_t) nav->Pcap * nav->cap;
-	if (n > 0) {
-		HC(hipMemcpy2DAsync(nav->h_tmp.data(), (size_t) n * 8, nav->bank[srcbank].mix + (size_t) slot * nav->cap,
-		                    plane * 8, (size_t) n * 8, 10, hipMemcpyDeviceToHost, nav->stream));
+	nav->h_tmp.resize((size_t) MIX_REC * std::max(n, 1));
+	if (n > 0) {   // the particle's records are one contiguous piece of its bank
+		HC(hipMemcpyAsync(nav->h_tmp.data(), nav->bank[srcbank].mix + (size_t) slot * nav->cap * MIX_REC, (size_t) n * MIX_REC * 8,
+		                  hipMemcpyDeviceToHost, nav->stream));
 		HC(hipStreamSynchronize(nav->stream));
 	}
 	nav->h_mw.resize(std::max(n, 1));
@@ -443,10 +449,10 @@ int fetch_map(phd_navigator* nav, int bankidx, int particle, int* ncomp, int mix
 	nav->h_mc.resize((size_t) 9 * std::max(n, 1));
 	const double* t = nav->h_tmp.data();
 	for (int c = 0; c < n; c++) {
-		nav->h_mw[c] = t[c];
-		for (int k = 0; k < 3; k++) nav->h_mm[c * 3 + k] = t[(size_t) (1 + k) * n + c];
-		double xx = t[(size_t) 4 * n + c], xy = t[(size_t) 5 * n + c], xz = t[(size_t) 6 * n + c];
-		double yy = t[(size_t) 7 * n + c], yz = t[(size_t) 8 * n + c], zz = t[(size_t) 9 * n + c];
+		const double* r = t + (size_t) c * MIX_REC;
+		nav->h_mw[c] = r[0];
+		for (int k = 0; k < 3; k++) nav->h_mm[c * 3 + k] = r[1 + k];
+		double xx = r[4], xy = r[5], xz = r[6], yy = r[7], yz = r[8], zz = r[9];
 		double* C = &nav->h_mc[(size_t) c * 9];
 		C[0] = xx; C[1] = xy; C[2] = xz; C[3] = xy; C[4] = yy; C[5] = yz; C[6] = xz; C[7] = yz; C[8] = zz;
 	}
@@ -454,14 +460,15 @@ int fetch_map(phd_navigator* nav, int bankidx, int particle, int* ncomp, int mix
 	return PHD_OK;
 }
 
-// host arrays -> the 10 planes of one particle (covariance: upper triangle of the given 3x3)
-void pack_planes(const double* w, const double* mean3, const double* cov9, int n, int stride, double* planes)
+// host arrays -> the component records of one particle (covariance: upper triangle of the given 3x3)
+void pack_records(const double* w, const double* mean3, const double* cov9, int n, double* recs)
 {
 	static const int tri[6] = {0, 1, 2, 4, 5, 8};
 	for (int c = 0; c < n; c++) {
-		planes[c] = w[c];
-		for (int k = 0; k < 3; k++) planes[(size_t) (1 + k) * stride + c] = mean3[c * 3 + k];
-		for (int k = 0; k < 6; k++) planes[(size_t) (4 + k) * stride + c] = cov9[c * 9 + tri[k]];
+		double* r = recs + (size_t) c * MIX_REC;
+		r[0] = w[c];
+		for (int k = 0; k < 3; k++) r[1 + k] = mean3[c * 3 + k];
+		for (int k = 0; k < 6; k++) r[4 + k] = cov9[c * 9 + tri[k]];
 	}
 }
 
@@ -469,12 +476,10 @@ int upload_particle(phd_navigator* nav, int bankidx, int particle, const double*
                     const double* cov9, int n)
 {
 	if (n < 0 || n > nav->cap) return nav->fail(PHD_ERR_CAPACITY, "map larger than max_components");
-	size_t plane = (size_t) nav->Pcap * nav->cap;
 	if (n > 0) {
-		std::vector<double> planes((size_t) 10 * n);
-		pack_planes(w, mean3, cov9, n, n, planes.data());
-		HC(hipMemcpy2D(nav->bank[bankidx].mix + (size_t) particle * nav->cap, plane * 8, planes.data(), (size_t) n * 8,
-		               (size_t) n * 8, 10, hipMemcpyHostToDevice));
+		std::vector<double> recs((size_t) MIX_REC * n);
+		pack_records(w, mean3, cov9, n, recs.data());
+		HC(hipMemcpy(nav->bank[bankidx].mix + (size_t) particle * nav->cap * MIX_REC, recs.data(), (size_t) n * MIX_REC * 8, hipMemcpyHostToDevice));
 	}
 	HC(hipMemcpy(nav->bank[bankidx].count + particle, &n, sizeof(int), hipMemcpyHostToDevice));
 	return PHD_OK;
@@ -632,7 +637,7 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	if (const char* e = getenv("PHD_CHAIN_MAX")) nav->chain_max = std::max(0, atoi(e));
 	size_t plane = (size_t) nav->Pcap * nav->cap;
 	for (int i = 0; i < 3 && ok; i++) {
-		ok = ok && dalloc((void**) &nav->bank[i].mix, plane * 10 * 8);
+		ok = ok && dalloc((void**) &nav->bank[i].mix, plane * MIX_REC * 8);
 		ok = ok && dalloc((void**) &nav->bank[i].count, (size_t) nav->Pcap * 4);
 		ok = ok && dalloc((void**) &nav->bank[i].poses, (size_t) nav->Pcap * 7 * 8);
 		ok = ok && dalloc((void**) &nav->bank[i].weights, (size_t) nav->Pcap * 8);
@@ -650,7 +655,7 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	ok = ok && hipHostMalloc((void**) &nav->h_status, (2 * SEL_STRIDE + 4) * 4, hipHostMallocDefault) == hipSuccess;
 	ok = ok && dalloc((void**) &nav->d_z, (size_t) nav->Mcap * 3 * 8);
 	ok = ok && dalloc((void**) &nav->d_emit_w, E * 8) && dalloc((void**) &nav->d_emit_idx, E * 4);
-	ok = ok && dalloc((void**) &nav->d_emit_rec, E * 9 * 8) && dalloc((void**) &nav->d_emit_count, (size_t) nav->Pcap * 4);
+	ok = ok && dalloc((void**) &nav->d_emit_rec, E * MIX_REC * 8) && dalloc((void**) &nav->d_emit_count, (size_t) nav->Pcap * 4);
 	ok = ok && dalloc((void**) &nav->d_born_count, (size_t) nav->Pcap * 4);
 	ok = ok && dalloc((void**) &nav->d_born_k, (size_t) nav->Pcap * nav->Mcap * 4);
 	ok = ok && dalloc((void**) &nav->d_born_mean, (size_t) nav->Pcap * nav->Mcap * 3 * 8);
@@ -667,7 +672,8 @@ phd_navigator* phd_create(const phd_params* params, int device)
 #ifdef PHD_STAMPS
 	ok = ok && dalloc((void**) &nav->d_stamps, (size_t) nav->Pcap * 16 * 8);
 #endif
-	ok = ok && dalloc((void**) &nav->d_srec, (size_t) nav->Pcap * 11 * nav->cutcap * 8);
+	ok = ok && dalloc((void**) &nav->d_srec, (size_t) nav->Pcap * PRUNE_ROW * nav->cutcap * 8);
+	ok = ok && dalloc((void**) &nav->d_outw, plane * 8);
 	ok = ok && dalloc((void**) &nav->d_wcopy, (size_t) nav->Pcap * (nav->cap + nav->Mcap) * 8) && dalloc((void**) &nav->d_cover, (size_t) nav->Pcap * nav->cap * 4);
 	ok = ok && dalloc((void**) &nav->d_alm, (size_t) nav->Pcap * 3 * nav->Jcap * 8);
 	ok = ok && dalloc((void**) &nav->d_aJ, (size_t) nav->Pcap * 4) && dalloc((void**) &nav->d_account, (size_t) nav->Pcap * 8);
@@ -768,9 +774,11 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_sel); hipFree(nav->d_inslot); hipFree(nav->d_mslot); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_src);
-	hipFree(nav->d_murty); hipFree(nav->d_bigws); hipFree(nav->d_bigws_used); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_wcopy); hipFree(nav->d_cover); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
+	hipFree(nav->d_murty); hipFree(nav->d_bigws); hipFree(nav->d_bigws_used); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_outw); hipFree(nav->d_wcopy); hipFree(nav->d_cover); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
 	hipFree(nav->d_lw); hipFree(nav->d_dst_tab); hipFree(nav->d_recv_tab); hipFree(nav->plan.code); hipFree(nav->plan.fslot); hipFree(nav->plan.sendlist); hipFree(nav->plan.senddst); hipFree(nav->plan.counts);
 	if (nav->h_counts) hipHostFree(nav->h_counts);
+	for (void* q : nav->ipc_opened) hipIpcCloseMemHandle(q);
+	hipFree(nav->d_graw);
 	if (nav->h_quasi) hipHostFree(nav->h_quasi);
 	if (nav->h_status) hipHostFree(nav->h_status);
 	for (Timer& t : nav->timers) { hipEventDestroy(t.t0); hipEventDestroy(t.t1); }
@@ -1040,10 +1048,24 @@ static int upload_impl(phd_navigator* nav, int nparticles, int stride, const dou
 	rc = reset_indirection(nav);
 	if (rc) return rc;
 	int I = cur_bank(nav);
-	size_t plane = (size_t) nav->Pcap * nav->cap;
-	for (int f = 0; f < 10 && stride > 0; f++) {
-		HC(hipMemcpy2D(nav->bank[I].mix + f * plane, (size_t) nav->cap * 8, planes + (size_t) f * plane_stride,
-		               (size_t) stride * 8, (size_t) stride * 8, nparticles, hipMemcpyHostToDevice));
+	if (stride > 0) {
+		// the ABI's host layout is plane per field ([10][particles][stride], the round-1 device layout); the banks hold one
+		// record per component: converted here, at the edge, in pieces of a few thousand particles
+		const int chunk = std::max(1, (int) std::min<size_t>((size_t) nparticles, ((size_t) 64 << 20) / ((size_t) stride * MIX_REC * 8) + 1));
+		std::vector<double> recs((size_t) chunk * stride * MIX_REC);
+		for (int p0 = 0; p0 < nparticles; p0 += chunk) {
+			const int np_ = std::min(chunk, nparticles - p0);
+			for (int i = 0; i < np_; i++) {
+				const int nc = std::min(std::max(counts[p0 + i], 0), stride);
+				double* r = recs.data() + (size_t) i * stride * MIX_REC;
+				for (int f = 0; f < MIX_REC; f++) {
+					const double* src = planes + (size_t) f * plane_stride + (size_t) (p0 + i) * stride;
+					for (int c = 0; c < nc; c++) r[(size_t) c * MIX_REC + f] = src[c];
+				}
+			}
+			HC(hipMemcpy2D(nav->bank[I].mix + (size_t) p0 * nav->cap * MIX_REC, (size_t) nav->cap * MIX_REC * 8, recs.data(),
+			               (size_t) stride * MIX_REC * 8, (size_t) stride * MIX_REC * 8, np_, hipMemcpyHostToDevice));
+		}
 	}
 	HC(hipMemcpy(nav->bank[I].count, counts, (size_t) nparticles * 4, hipMemcpyHostToDevice));
 	HC(hipMemcpy(nav->bank[I].poses, poses7, (size_t) nparticles * 7 * 8, hipMemcpyHostToDevice));
@@ -1078,12 +1100,24 @@ static int download_impl(phd_navigator* nav, int stride, double* planes, size_t 
 	rc = materialise(nav);
 	if (rc) return rc;
 	int I = cur_bank(nav);
-	size_t plane = (size_t) nav->Pcap * nav->cap;
-	for (int f = 0; f < 10 && stride > 0; f++) {
-		HC(hipMemcpy2D(planes + (size_t) f * plane_stride, (size_t) stride * 8, nav->bank[I].mix + f * plane,
-		               (size_t) nav->cap * 8, (size_t) stride * 8, nav->P, hipMemcpyDeviceToHost));
-	}
 	HC(hipMemcpy(counts, nav->bank[I].count, (size_t) nav->P * 4, hipMemcpyDeviceToHost));
+	if (stride > 0) {   // records -> the ABI's planes (see upload_impl); slots behind a particle's count are left as they are
+		const int chunk = std::max(1, (int) std::min<size_t>((size_t) nav->P, ((size_t) 64 << 20) / ((size_t) stride * MIX_REC * 8) + 1));
+		std::vector<double> recs((size_t) chunk * stride * MIX_REC);
+		for (int p0 = 0; p0 < nav->P; p0 += chunk) {
+			const int np_ = std::min(chunk, nav->P - p0);
+			HC(hipMemcpy2D(recs.data(), (size_t) stride * MIX_REC * 8, nav->bank[I].mix + (size_t) p0 * nav->cap * MIX_REC,
+			               (size_t) nav->cap * MIX_REC * 8, (size_t) stride * MIX_REC * 8, np_, hipMemcpyDeviceToHost));
+			for (int i = 0; i < np_; i++) {
+				const int nc = std::min(std::max(counts[p0 + i], 0), stride);
+				const double* r = recs.data() + (size_t) i * stride * MIX_REC;
+				for (int f = 0; f < MIX_REC; f++) {
+					double* dst = planes + (size_t) f * plane_stride + (size_t) (p0 + i) * stride;
+					for (int c = 0; c < nc; c++) dst[c] = r[(size_t) c * MIX_REC + f];
+				}
+			}
+		}
+	}
 	if (poses7) HC(hipMemcpy(poses7, nav->bank[I].poses, (size_t) nav->P * 7 * 8, hipMemcpyDeviceToHost));
 	if (weights) HC(hipMemcpy(weights, nav->bank[I].weights, (size_t) nav->P * 8, hipMemcpyDeviceToHost));
 	return PHD_OK;
@@ -1190,6 +1224,15 @@ int phd_sync(phd_navigator* nav)
 	rc = check_flags(nav);
 	if (nav->h_flags) {
 		hipMemset(nav->d_flags, 0, 4);
+	}
+	if (!rc && nav->plan_on_device && nav->sharded_used) {
+		// the host never saw the plan of the last sharded step: what it said (a flag on another rank drops the step here too)
+		int st[2] = {MIG_OK, 0};
+		HC(hipMemcpy(st, nav->plan.counts + 2 * nav->world + 2, 8, hipMemcpyDeviceToHost));
+		nav->h_info[1] = st[1];
+		if (st[0] == MIG_DROPPED) rc = nav->fail(PHD_ERR_GENERIC, "the step was dropped: another rank raised a flag (its phd_sync says which); the state is the one before the step");
+		else if (st[0] == MIG_BAD) rc = nav->fail(PHD_ERR_GENERIC, "the gathered source vector was not a resampling result (were the weights of all ranks gathered?)");
+		else if (st[0] == MIG_OVERFLOW) rc = nav->fail(PHD_ERR_CAPACITY, "more migrating particles than the send list holds");
 	}
 	return rc;
 }
@@ -1323,14 +1366,14 @@ int phd_stage_map(phd_navigator* nav, int stage, int particle, int* ncomp, const
 		int ne = 0;
 		HC(hipMemcpy(&ne, nav->d_emit_count + particle, 4, hipMemcpyDeviceToHost));
 		size_t eb = (size_t) particle * nav->ecap;
-		std::vector<double> rec((size_t) std::max(ne, 1) * 9);
+		std::vector<double> rec((size_t) std::max(ne, 1) * MIX_REC);
 		nav->h_mw.resize(std::max(ne, 1)); nav->h_mm.resize((size_t) std::max(ne, 1) * 3); nav->h_mc.resize((size_t) std::max(ne, 1) * 9);
 		if (ne > 0) {
 			HC(hipMemcpy(nav->h_mw.data(), nav->d_emit_w + eb, (size_t) ne * 8, hipMemcpyDeviceToHost));
-			HC(hipMemcpy(rec.data(), nav->d_emit_rec + eb * 9, (size_t) ne * 9 * 8, hipMemcpyDeviceToHost));
+			HC(hipMemcpy(rec.data(), nav->d_emit_rec + eb * MIX_REC, (size_t) ne * MIX_REC * 8, hipMemcpyDeviceToHost));
 		}
 		for (int c = 0; c < ne; c++) {
-			const double* r = &rec[(size_t) c * 9];
+			const double* r = &rec[(size_t) c * MIX_REC + 1];   // (mean and covariance behind the record's weight)
 			for (int k = 0; k < 3; k++) nav->h_mm[(size_t) c * 3 + k] = r[k];
 			double* C = &nav->h_mc[(size_t) c * 9];
 			C[0] = r[3]; C[1] = r[4]; C[2] = r[5]; C[3] = r[4]; C[4] = r[6]; C[5] = r[7]; C[6] = r[5]; C[7] = r[7]; C[8] = r[8];
@@ -1369,7 +1412,7 @@ const double* phd_stage_setloglik(phd_navigator* nav, int* length)
 static int ensure_gw(phd_navigator* nav, int n)
 {
 	if (n <= nav->gwcap) return PHD_OK;
-	if (nav->d_recv_tab) return nav->fail(PHD_ERR_GENERIC, "the gathered-weight vector of a shard cannot grow (other shards hold its address)");
+	if (nav->gw_shared) return nav->fail(PHD_ERR_GENERIC, "the gathered-weight vector of a shard cannot grow (other shards hold its address)");
 	HC(hipStreamSynchronize(nav->stream));
 	hipFree(nav->d_gw);
 	nav->d_gw = nullptr;
@@ -1510,28 +1553,74 @@ int phd_last_timing_counts(phd_navigator* nav, const int** counts)
 // counts, send / receive buffers. With non-decreasing sources a rank receives at most one record per slot and sends at
 // most Pcap + world - 1 (a source particle goes to every rank its run of slots meets; runs of successive sources share at
 // most one rank).
+static void free_sharded(phd_navigator* nav)
+{
+	hipFree(nav->d_lw); nav->d_lw = nullptr;
+	hipFree(nav->d_dst_tab); nav->d_dst_tab = nullptr;
+	hipFree(nav->plan.code); hipFree(nav->plan.fslot); hipFree(nav->plan.sendlist); hipFree(nav->plan.senddst); hipFree(nav->plan.counts);
+	nav->plan = MigPlan{nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+	if (nav->h_counts) hipHostFree(nav->h_counts);
+	nav->h_counts = nullptr;
+	hipFree(nav->d_mslot); nav->d_mslot = nullptr;
+	hipFree(nav->d_send); nav->d_send = nullptr;
+	hipFree(nav->d_recv); nav->d_recv = nullptr;
+	hipFree(nav->d_recv_tab); nav->d_recv_tab = nullptr;
+	nav->sharded_ready = false;
+}
+
 static int ensure_sharded(phd_navigator* nav, bool need_send = true)
 {
-	if (nav->plan.code) return PHD_OK;
+	if (nav->sharded_ready) {
+		if (need_send && !nav->d_send) {   // (a handle first used without a send buffer: push-only hosts never need one)
+			const size_t rec = (size_t) 8 + (size_t) MIX_REC * nav->cap;
+			hipSetDevice(nav->device);
+			HC(hipMalloc((void**) &nav->d_send, (size_t) nav->sendrecs * rec * 8));
+		}
+		return PHD_OK;
+	}
 	hipSetDevice(nav->device);
-	const size_t rec = (size_t) 8 + (size_t) 10 * nav->cap;
+	const size_t rec = (size_t) 8 + (size_t) MIX_REC * nav->cap;
 	nav->plan.sendcap = nav->Pcap + PHD_MAX_DEVICES;
 	nav->recvrecs = nav->Pcap;
 	nav->sendrecs = nav->plan.sendcap;
-	HC(hipMalloc((void**) &nav->d_lw, (size_t) (nav->Pcap + 1) * 8));
-	HC(hipMalloc((void**) &nav->d_dst_tab, PHD_MAX_DEVICES * sizeof(double*)));
-	HC(hipMemcpy(nav->d_dst_tab, &nav->d_lw, sizeof(double*), hipMemcpyHostToDevice));
-	HC(hipMalloc((void**) &nav->plan.code, (size_t) nav->Pcap * 4));
-	HC(hipMalloc((void**) &nav->plan.fslot, (size_t) nav->Pcap * 4));
-	HC(hipMalloc((void**) &nav->plan.sendlist, (size_t) nav->plan.sendcap * 4));
-	HC(hipMalloc((void**) &nav->plan.senddst, (size_t) nav->plan.sendcap * 8));
-	HC(hipMalloc((void**) &nav->plan.counts, (2 * PHD_MAX_DEVICES + 8) * 4));
-	HC(hipMemset(nav->plan.counts, 0, (2 * PHD_MAX_DEVICES + 8) * 4));
-	HC(hipHostMalloc((void**) &nav->h_counts, (2 * PHD_MAX_DEVICES + 8) * 4, hipHostMallocMapped));
-	std::memset(nav->h_counts, 0, (2 * PHD_MAX_DEVICES + 8) * 4);
-	HC(hipMalloc((void**) &nav->d_mslot, (size_t) nav->Pcap * 4));
-	if (need_send) HC(hipMalloc((void**) &nav->d_send, (size_t) nav->sendrecs * rec * 8));   // (a shard of a multi-device handle packs straight into its peers' receive buffers)
-	HC(hipMalloc((void**) &nav->d_recv, (size_t) nav->recvrecs * rec * 8));
+	// (all or nothing: a failure frees what was made, so that the call can be repeated and nothing downstream ever sees a
+	// half-made set — the flag below is what every user of these buffers asks)
+	hipError_t e = hipSuccess;
+	auto want = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+	want(hipMalloc((void**) &nav->d_lw, (size_t) (nav->Pcap + 1) * 8));
+	want(hipMalloc((void**) &nav->d_dst_tab, PHD_MAX_DEVICES * sizeof(double*)));
+	if (e == hipSuccess) want(hipMemcpy(nav->d_dst_tab, &nav->d_lw, sizeof(double*), hipMemcpyHostToDevice));
+	want(hipMalloc((void**) &nav->d_recv_tab, PHD_MAX_DEVICES * sizeof(double*)));
+	want(hipMalloc((void**) &nav->plan.code, (size_t) nav->Pcap * 4));
+	want(hipMalloc((void**) &nav->plan.fslot, (size_t) nav->Pcap * 4));
+	want(hipMalloc((void**) &nav->plan.sendlist, (size_t) nav->plan.sendcap * 4));
+	want(hipMalloc((void**) &nav->plan.senddst, (size_t) nav->plan.sendcap * 8));
+	want(hipMalloc((void**) &nav->plan.counts, (2 * PHD_MAX_DEVICES + 8) * 4));
+	if (e == hipSuccess) want(hipMemset(nav->plan.counts, 0, (2 * PHD_MAX_DEVICES + 8) * 4));
+	// (coherent: the plan kernel's system-scope stores must reach the polling host while the kernel runs, whatever the
+	// runtime's default for mapped host memory is)
+	want(hipHostMalloc((void**) &nav->h_counts, (2 * PHD_MAX_DEVICES + 8) * 4, hipHostMallocMapped | hipHostMallocCoherent));
+	if (e == hipSuccess) std::memset(nav->h_counts, 0, (2 * PHD_MAX_DEVICES + 8) * 4);
+	want(hipMalloc((void**) &nav->d_mslot, (size_t) nav->Pcap * 4));
+	if (need_send) want(hipMalloc((void**) &nav->d_send, (size_t) nav->sendrecs * rec * 8));   // (a shard of a multi-device handle packs straight into its peers' receive buffers)
+	// The receive buffer is written by OTHER devices (peer stores of a multi-device handle's shards, or of other ranks'
+	// processes through IPC) and read here: fine-grained device memory, coherent between agents without cache maintenance —
+	// what RCCL allocates for its own peer-to-peer buffers. (See the head of phd_multi.inc for the visibility argument.)
+	if (e == hipSuccess) {
+		nav->recv_finegrained = getenv("PHD_COARSE_RECV") == nullptr &&
+		                        hipExtMallocWithFlags((void**) &nav->d_recv, (size_t) nav->recvrecs * rec * 8, hipDeviceMallocFinegrained) == hipSuccess;
+		if (!nav->recv_finegrained) {
+			(void) hipGetLastError();
+			nav->d_recv = nullptr;
+			want(hipMalloc((void**) &nav->d_recv, (size_t) nav->recvrecs * rec * 8));
+		}
+	}
+	if (e != hipSuccess) {
+		(void) hipGetLastError();
+		free_sharded(nav);
+		return nav->fail(PHD_ERR_DEVICE, std::string("buffers of the sharded step: ") + hipGetErrorString(e));
+	}
+	nav->sharded_ready = true;
 	return PHD_OK;
 }
 
@@ -1549,8 +1638,9 @@ static int step_local(phd_navigator* nav, uint8_t onlymapping)
 	rc = launch_map(nav, b, !onlymapping);
 	if (rc) return rc;
 	timer_begin(nav, T_PW);
+	// (per-rank host: the export buffer holds P + 1 doubles, the step's status word behind the weights)
 	hipLaunchKernelGGL(k_push_weights, dim3((nav->P + 255) / 256), dim3(256), 0, nav->stream, b, (double* const*) nav->d_dst_tab, nav->ndst,
-	                   nav->push_first, nav->push_flagslot);
+	                   nav->push_first, nav->gw_shared ? nav->push_flagslot : nav->P);
 	timer_end(nav, T_PW);
 	HC(hipGetLastError());
 	return PHD_OK;
@@ -1581,16 +1671,24 @@ void* phd_device_global_weights(phd_navigator* nav, int world_particles)
 // the global part: the resampling kernel on the gathered vector, this rank's weights back into its bank, the plan.
 // onlymapping: OnlyMapping keeps the weights and never resamples (PHDNavigator.cs:330-336) — the same kernel with the
 // weights taken as they are and resampling off. hostcounts: the plan also writes its counts to pinned host memory.
-static int step_global(phd_navigator* nav, int rank, int world_size, double u, uint8_t onlymapping, bool hostcounts)
+static int step_global(phd_navigator* nav, int rank, int world_size, double u, uint8_t onlymapping, bool hostcounts, bool from_graw = false)
 {
 	hipSetDevice(nav->device);
 	const int Pg = nav->P * world_size;
 	nav->last_world_particles = Pg;
 	nav->world = world_size; nav->rank = rank;
-	int rc = ensure_sharded(nav);
+	int rc = ensure_sharded(nav, hostcounts);
 	if (!rc) rc = ensure_gw(nav, Pg);
 	if (rc) return rc;
+	nav->plan_on_device = !hostcounts;
 	StepBufs b = make_bufs(nav);
+	if (from_graw) {
+		// the all-gather landed as [rank][P + 1] (weights | status word): the weights into the contiguous vector the global
+		// kernel takes, the status words behind it — a flag raised on ANY rank then drops the step on every rank alike
+		hipLaunchKernelGGL(k_ungather, dim3((Pg + world_size + 255) / 256), dim3(256), 0, nav->stream, (const double*) nav->d_graw, nav->d_gw, nav->P, world_size);
+		nav->d_gflags = nav->d_gw + Pg;
+	}
+	else if (!nav->gw_shared) nav->d_gflags = nullptr;   // (the host-plan path gathers the weights only: every rank answers for its own flags)
 	timer_begin(nav, T_NR);
 	rc = launch_normalise(nav, b, nav->d_gw, Pg, u, onlymapping ? -1 : 0, onlymapping ? 1 : 0, nav->d_plan, nav->d_info);
 	timer_end(nav, T_NR);
@@ -1616,6 +1714,132 @@ int phd_step_global_async(phd_navigator* nav, int rank, int world_size, double u
 	MULTI_UNSUPPORTED(nav, "phd_step_global_async");
 	if (world_size < 1 || world_size > PHD_MAX_DEVICES || rank < 0 || rank >= world_size) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step_global: bad rank/world (at most 64 ranks)");
 	return step_global(nav, rank, world_size, u_resample, 0, true);
+}
+
+// ---- the same step with NOTHING for the host to wait for (round 4): the migrating particles are pushed by the senders,
+// straight into their places in the receivers' buffers, from the plan the device made. The host of rank r
+//   once:      exchanges the ranks' phd_migration_ipc_export handles and opens them (phd_migration_ipc_open), or — shards in
+//              one process — hands in the raw pointers (phd_migration_set_peers)
+//   per step:  phd_step_local_async            local kernels; weights | status word into phd_device_local_weights [P + 1]
+//              <all-gather of those P + 1 doubles into phd_device_gather_buffer, RCCL>
+//              phd_step_global_device_async    un-gather, global resampling, plan — all on the device
+//              phd_migration_push_async        k_pack_particles with the peers' buffers as destinations
+//              <a one-word all-reduce on the stream: every rank's records have landed>
+//              phd_migration_unpack_async      k_finish_sharded
+// and never learns whether the step resampled, how many particles moved, or whether a flag dropped it, before phd_sync.
+void* phd_device_gather_buffer(phd_navigator* nav, int world_size)
+{
+	if (!nav || nav->multi || world_size < 1 || world_size > PHD_MAX_DEVICES) return nullptr;
+	hipSetDevice(nav->device);
+	const int need = world_size * (nav->Pcap + 1);
+	if (need > nav->grawcap) {
+		if (hipStreamSynchronize(nav->stream) != hipSuccess) return nullptr;
+		hipFree(nav->d_graw);
+		nav->d_graw = nullptr; nav->grawcap = 0;
+		if (hipMalloc((void**) &nav->d_graw, (size_t) need * 8) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+		hipMemset(nav->d_graw, 0, (size_t) need * 8);
+		nav->grawcap = need;
+	}
+	return nav->d_graw;
+}
+
+int phd_step_global_device_async(phd_navigator* nav, int rank, int world_size, double u_resample, uint8_t onlymapping)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	MULTI_UNSUPPORTED(nav, "phd_step_global_device_async");
+	if (world_size < 1 || world_size > PHD_MAX_DEVICES || rank < 0 || rank >= world_size) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step_global_device: bad rank/world (at most 64 ranks)");
+	if (!nav->d_graw || nav->grawcap < world_size * (nav->P + 1)) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step_global_device: no gather buffer (phd_device_gather_buffer(world_size) first)");
+	if (!nav->peers_set && world_size > 1) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step_global_device: the peers' receive buffers are not known (phd_migration_ipc_open / phd_migration_set_peers first)");
+	return step_global(nav, rank, world_size, u_resample, onlymapping, false, true);
+}
+
+// the 64-byte hipIpcMemHandle_t of this rank's receive buffer, for the other ranks' processes to open
+int phd_migration_ipc_export(phd_navigator* nav, void* handle64, int64_t* buffer_bytes)
+{
+	if (!nav || !handle64) return PHD_ERR_BAD_ARGUMENT;
+	MULTI_UNSUPPORTED(nav, "phd_migration_ipc_export");
+	int rc = ensure_sharded(nav, false);
+	if (rc) return rc;
+	static_assert(sizeof(hipIpcMemHandle_t) == 64, "the ABI hands out 64 bytes");
+	hipIpcMemHandle_t h;
+	HC(hipIpcGetMemHandle(&h, nav->d_recv));
+	std::memcpy(handle64, &h, 64);
+	if (buffer_bytes) *buffer_bytes = (int64_t) ((size_t) nav->recvrecs * ((size_t) 8 + (size_t) MIX_REC * nav->cap) * 8);
+	return PHD_OK;
+}
+
+// recv_buffers[world_size]: where every rank's receive buffer is, as THIS device addresses it (entry `rank` may be NULL:
+// the handle's own). Shards in one process pass each other's phd_migration_recv_buffer (with peer access enabled).
+int phd_migration_set_peers(phd_navigator* nav, void* const* recv_buffers, int rank, int world_size)
+{
+	if (!nav || !recv_buffers) return PHD_ERR_BAD_ARGUMENT;
+	MULTI_UNSUPPORTED(nav, "phd_migration_set_peers");
+	if (world_size < 1 || world_size > PHD_MAX_DEVICES || rank < 0 || rank >= world_size) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_set_peers: bad rank/world (at most 64 ranks)");
+	int rc = ensure_sharded(nav, false);
+	if (rc) return rc;
+	std::vector<double*> tab(world_size);
+	for (int t = 0; t < world_size; t++) {
+		tab[t] = (t == rank) ? nav->d_recv : (double*) recv_buffers[t];
+		if (!tab[t]) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_set_peers: the receive buffer of rank " + std::to_string(t) + " is NULL");
+	}
+	hipSetDevice(nav->device);
+	HC(hipStreamSynchronize(nav->stream));
+	HC(hipMemcpy(nav->d_recv_tab, tab.data(), world_size * sizeof(double*), hipMemcpyHostToDevice));
+	nav->peers_set = true;
+	nav->world = world_size; nav->rank = rank;
+	return PHD_OK;
+}
+
+// handles[world_size][64]: every rank's phd_migration_ipc_export, in rank order (the entry of `rank` itself is not opened)
+int phd_migration_ipc_open(phd_navigator* nav, const void* handles, int rank, int world_size)
+{
+	if (!nav || !handles) return PHD_ERR_BAD_ARGUMENT;
+	MULTI_UNSUPPORTED(nav, "phd_migration_ipc_open");
+	if (world_size < 1 || world_size > PHD_MAX_DEVICES || rank < 0 || rank >= world_size) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_ipc_open: bad rank/world (at most 64 ranks)");
+	hipSetDevice(nav->device);
+	for (void* q : nav->ipc_opened) hipIpcCloseMemHandle(q);
+	nav->ipc_opened.clear();
+	std::vector<void*> ptrs(world_size, nullptr);
+	for (int t = 0; t < world_size; t++) {
+		if (t == rank) continue;
+		hipIpcMemHandle_t h;
+		std::memcpy(&h, (const char*) handles + (size_t) t * 64, 64);
+		void* q = nullptr;
+		const hipError_t e = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
+		if (e != hipSuccess) {
+			(void) hipGetLastError();
+			return nav->fail(PHD_ERR_DEVICE, "phd_migration_ipc_open: the receive buffer of rank " + std::to_string(t) + " cannot be opened: " + hipGetErrorString(e) +
+			                 " (the ranks' GPUs must reach each other peer to peer; HSA_ENABLE_IPC_MODE_LEGACY=0 on this pool)");
+		}
+		nav->ipc_opened.push_back(q);
+		ptrs[t] = q;
+	}
+	return phd_migration_set_peers(nav, ptrs.data(), rank, world_size);
+}
+
+// 1: the receive buffer is fine-grained device memory (coherent for the peers storing into it); 0: an ordinary allocation
+int phd_migration_recv_is_finegrained(phd_navigator* nav)
+{
+	if (!nav || nav->multi) return -1;
+	if (ensure_sharded(nav, false)) return -1;
+	return nav->recv_finegrained ? 1 : 0;
+}
+
+// pack, with every record stored straight into its place in its destination's receive buffer (the count and the places are
+// the device plan's: a fixed grid strides over the records; nothing runs when the step did not resample or was dropped)
+int phd_migration_push_async(phd_navigator* nav)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	MULTI_UNSUPPORTED(nav, "phd_migration_push_async");
+	if (!nav->sharded_ready || !nav->peers_set) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_push_async: no peers (phd_migration_ipc_open / phd_migration_set_peers, then phd_step_global_device_async)");
+	hipSetDevice(nav->device);
+	StepBufs b = make_bufs(nav);
+	timer_begin(nav, T_PK);
+	hipLaunchKernelGGL(k_pack_particles, dim3(std::min(nav->plan.sendcap, 256)), dim3(256), 0, nav->stream, b, nav->plan, nav->world, (double*) nullptr,
+	                   (double* const*) nav->d_recv_tab);
+	timer_end(nav, T_PK);
+	HC(hipGetLastError());
+	return PHD_OK;
 }
 
 // Pure host logic (no handle, no device): from the global source vector of a resampling step, which of
@@ -1787,7 +2011,7 @@ int phd_migration_pack_async(phd_navigator* nav)
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	MULTI_UNSUPPORTED(nav, "phd_migration_pack_async");
 	hipSetDevice(nav->device);
-	if (!nav->plan.code) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_pack_async: no plan (phd_step_global_async, phd_migration_plan first)");
+	if (!nav->sharded_ready || nav->plan_on_device) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_pack_async: no plan known to the host (phd_step_global_async, phd_migration_plan first)");
 	if (nav->nsend == 0) return PHD_OK;   // (the per-rank host knows the counts)
 	StepBufs b = make_bufs(nav);
 	timer_begin(nav, T_PK);
@@ -1820,7 +2044,7 @@ int phd_migration_unpack_async(phd_navigator* nav)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	MULTI_UNSUPPORTED(nav, "phd_migration_unpack_async");
-	if (!nav->plan.code) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_unpack_async: no plan (phd_step_global_async first)");
+	if (!nav->sharded_ready) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_unpack_async: no plan (phd_step_global_async first)");
 	return step_finish(nav);
 }
 

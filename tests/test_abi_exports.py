@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported():
 
 def test_params_struct_matches_c_defaults():
     lib = _lib.load()
-    assert lib.phd_api_version() == 3
+    assert lib.phd_api_version() == 4
     c = PhdParams()
     lib.phd_default_params(C.byref(c), 7, 640, 33)
     py = prm3d_defaults(7, 640, 33)

@@ -23,7 +23,7 @@ def setup(cfg, profile):
     return nav, p, f
 
 
-@pytest.mark.parametrize("cfg,profile", [("B", "steady"), ("B", "survey"), ("S", "steady")])
+@pytest.mark.parametrize("cfg,profile", [("B", "steady"), ("B", "survey"), ("S", "steady"), ("S", "survey")])
 def test_full_size_properties_and_sample(cfg, profile):
     nav, p, f = setup(cfg, profile)
     nav.run_stages(f.z, with_alpha=True)
