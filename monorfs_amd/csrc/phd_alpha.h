@@ -830,93 +830,64 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 	// read (the pick below takes at most J of them), so when J <= no the J heaviest are selected (radix select on
 	// the weight's bit pattern, ties by map index) and only those are ordered.
 	if (J >= 1 && J <= no) {
-		int* hist   = (int*) red;                                   // [256]
-		int* selidx = (int*) (smem + lay.p1_selidx);                // [J] selected components, unordered
-		__shared__ int s_bin, s_need, s_binc, s_nsel, s_wc[4];
-		__shared__ unsigned long long s_T;
-		unsigned long long prefix = 0;
-		int need = J, binc = 0, shift = 56;
-		for (; shift >= 0; shift -= 8) {
-			hist[tid] = 0;
-			__syncthreads();
-			for (int c0 = 0; c0 < no; c0 += 256) {
-				const int c = c0 + tid;
-				const unsigned long long key = (c < no) ? prune_key(keyw[c]) : 0ull;
-				const bool in = c < no && (shift == 56 || (key >> (shift + 8)) == (prefix >> (shift + 8)));
-				const int digit = (int) ((key >> shift) & 255);
-				// equal weights are common (components never detected since birth): the lanes that share the first
-				// candidate's digit add once, together
-				const unsigned long long cand = ballot64(in);
-				if (cand) {
-					const int lead = __ffsll((long long) cand) - 1;
-					const int d0 = __shfl(digit, lead, 64);
-					const unsigned long long same = ballot64(in && digit == d0);
-					if (lane == lead) atomicAdd(&hist[d0], __popcll(same));
-					else if (in && digit != d0) atomicAdd(&hist[digit], 1);
-				}
-			}
-			__syncthreads();
-			if (wv == 0) {   // the bin holding the need-th largest: lane l looks at bins 255 - 4l .. 252 - 4l
-				const int b0 = 255 - 4 * lane;
-				const int c0 = hist[b0], c1 = hist[b0 - 1], c2 = hist[b0 - 2], c3 = hist[b0 - 3];
-				const int tot = c0 + c1 + c2 + c3;
-				int incl = tot;
-#pragma unroll
-				for (int o = 1; o < 64; o <<= 1) {
-					int y = __shfl_up(incl, o, 64);
-					if (lane >= o) incl += y;
-				}
-				const int excl = incl - tot;
-				if (excl < need && need <= incl) {
-					int r = need - excl, b = b0, cb = c0;
-					if (r > c0) {
-						r -= c0; b = b0 - 1; cb = c1;
-						if (r > c1) {
-							r -= c1; b = b0 - 2; cb = c2;
-							if (r > c2) { r -= c2; b = b0 - 3; cb = c3; }
-						}
-					}
-					s_bin = b; s_need = r; s_binc = cb;
-				}
-			}
-			__syncthreads();
-			prefix |= (unsigned long long) s_bin << shift;
-			need = s_need;
-			binc = s_binc;
-			if (binc == 1) break;   // one weight carries this prefix: it is the J-th largest
-		}
-		if (binc == 1 && shift > 0) {
-			for (int c = tid; c < no; c += 256) {
-				const unsigned long long key = prune_key(keyw[c]);
-				if ((key >> shift) == (prefix >> shift)) s_T = key;
-			}
-			__syncthreads();
-			prefix = s_T;
-		}
-		const unsigned long long T = prefix;   // key of the J-th largest weight; `need` of the `binc` equal ones are taken
-		if (tid == 0) s_nsel = 0;
+		// The J heaviest, by ONE histogram over the weights' leading bits (exponent and four mantissa bits from MinWeight up,
+		// 500 bins: thirty-one octaves, the last bin takes what lies beyond): the bins above the one the J-th heaviest lies in
+		// are taken whole, the entries of that bin are ranked among themselves by (weight, map index) and the first `need` of
+		// them taken. (Eight passes of an 8-bit radix select before: three barriers each, 22 k of this kernel's 74 k cycles on
+		// config B.)
+		constexpr int HB = 500;
+		int* const hist   = (int*) red;                                   // [HB + 4] (`red` is idle between the block sums above and the exp table below)
+		int* const selidx = (int*) (smem + lay.p1_selidx);                // [J] selected components, unordered
+		int* const tl     = sortsrc;                                      // the threshold bin's entries (sortsrc is written only by the ordering below)
+		int& s_T = hist[HB];
+		int& s_above = hist[HB + 1];
+		int& s_nt = hist[HB + 2];
+		int& s_ntaken = hist[HB + 3];
+		const unsigned int hbase = (unsigned int) (((unsigned long long) __double_as_longlong(prm.minw) << 1) >> 49);
+		auto bin_of = [&](double w) {
+			const unsigned int k = (unsigned int) (((unsigned long long) __double_as_longlong(w) << 1) >> 49);
+			return (int) min(max((int) k - (int) hbase, 0), HB - 1);
+		};
+		for (int t = tid; t < HB + 4; t += 256) hist[t] = 0;
 		__syncthreads();
-		if (need == binc) {
-			for (int c = tid; c < no; c += 256) {
-				if (prune_key(keyw[c]) >= T) selidx[atomicAdd(&s_nsel, 1)] = c;
+		for (int c = tid; c < no; c += 256) atomicAdd(&hist[bin_of(keyw[c])], 1);
+		__syncthreads();
+		if (wv == 0) {   // from the top bin down (lane l: bins 511 - 8 l .. 504 - 8 l): the bin at which J entries are reached
+			int cq[8], mine = 0;
+#pragma unroll
+			for (int q = 0; q < 8; q++) { const int b = 511 - (8 * lane + q); cq[q] = (b < HB) ? hist[b] : 0; mine += cq[q]; }
+			int incl = mine;
+#pragma unroll
+			for (int o = 1; o < 64; o <<= 1) {
+				const int y = __shfl_up(incl, o, 64);
+				if (lane >= o) incl += y;
+			}
+			int run = incl - mine;
+#pragma unroll
+			for (int q = 0; q < 8; q++) {
+				if (run < J && J <= run + cq[q]) { s_T = 511 - (8 * lane + q); s_above = run; }
+				run += cq[q];
 			}
 		}
-		else {
-			// more weights equal to the J-th than fit: the first `need` in map order (stable sort)
-			int eqbase = 0;
-			for (int c0 = 0; c0 < no; c0 += 256) {
-				const int c = c0 + tid;
-				const unsigned long long key = (c < no) ? prune_key(keyw[c]) : 0ull;
-				const bool eq = c < no && key == T;
-				const unsigned long long bal = ballot64(eq);
-				if (lane == 0) s_wc[wv] = __popcll(bal);
-				__syncthreads();
-				int rank = eqbase + __popcll(bal & lanemask_lt());
-				for (int q = 0; q < wv; q++) rank += s_wc[q];
-				if ((c < no && key > T) || (eq && rank < need)) selidx[atomicAdd(&s_nsel, 1)] = c;
-				eqbase += s_wc[0] + s_wc[1] + s_wc[2] + s_wc[3];
-				__syncthreads();
+		__syncthreads();
+		const int T = s_T, above = s_above, need = J - above;   // `need` of the threshold bin's entries are taken (1 <= need <= its count)
+		for (int c = tid; c < no; c += 256) {
+			const int b = bin_of(keyw[c]);
+			if (b > T) selidx[atomicAdd(&s_ntaken, 1)] = c;            // (the bins above: in any order)
+			else if (b == T) tl[atomicAdd(&s_nt, 1)] = c;
+		}
+		__syncthreads();
+		const int nt = s_nt;
+		for (int t = tid; t < nt; t += 256) {
+			const int ct = tl[t];
+			const double wt = keyw[ct];
+			int rank = 0;
+			for (int u = 0; u < nt; u++) {
+				const int cu = tl[u];
+				const double wu = keyw[cu];
+				rank += (wu > wt || (wu == wt && cu < ct)) ? 1 : 0;
 			}
+			if (rank < need) selidx[above + rank] = ct;   // (the bins above filled [0, above); ranks are distinct)
 		}
 		__syncthreads();
 		// order the J selected by (weight desc, map index asc): every entry counts the entries before it
@@ -1550,7 +1521,9 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 			PHD_STAMP(10);
 			// what the replay reads per cluster, brought into LDS in one go when it is little (it usually is: forty clusters, a
 			// few weights each): the replay is one wave walking the clusters in order, every read a dependent trip otherwise
-			if (nroots <= QGRAD_G2_CLUSTERS && s_ebump <= QGRAD_G2_WEIGHTS) {
+			// (the bump counter also counts the clusters that found no room, off + mcount > ecap: only a list that fits the
+			// particle's scratch as a whole is copied — nothing is read behind its end)
+			if (nroots <= QGRAD_G2_CLUSTERS && s_ebump <= min(QGRAD_G2_WEIGHTS, ecap)) {
 				for (int i = tid; i < nroots * QGRAD_HDR; i += 256) s_g2[i] = gj[i];
 				for (int i = tid; i < s_ebump; i += 256) s_g2[QGRAD_G2_CLUSTERS * QGRAD_HDR + i] = elist[i];
 				if (tid == 0) s_g2lds = 1;

@@ -268,11 +268,17 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 			// (up to 2048 emitted entries a thread keeps its weights for the scatter below: one trip to memory instead of two)
 			constexpr int WK = 8;
 			const bool keepw = ne <= 256 * WK;
+			// (their canonical indices — which decide between equal weights: components never detected since birth, dozens of
+			// them — are kept beside the slots when the pool has the room, and fetched HERE, with the weights, in one trip: read
+			// one by one inside the scatter below they were a dependent trip to memory per entry, five in a row per thread)
+			const bool haveki = xsize >= NS + 516 + capN + 2;
 			double wk[WK];
+			int    ik[WK];
 #pragma unroll
 			for (int q = 0; q < WK; q++) {
 				const int e = tid + 256 * q;
 				wk[q] = (keepw && e < ne) ? a.emit_w[eb + e] : 0.0;
+				ik[q] = (keepw && haveki && e < ne) ? a.emit_idx[eb + e] : 0;
 			}
 			if (keepw) {
 #pragma unroll
@@ -281,7 +287,15 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 				}
 			}
 			else {
-				for (int e = tid; e < ne; e += 256) atomicAdd(&hist[bin_of(a.emit_w[eb + e])], 1);
+				for (int e0 = tid; e0 < ne; e0 += 256 * WK) {
+					double wr[WK];
+#pragma unroll
+					for (int q = 0; q < WK; q++) wr[q] = (e0 + 256 * q < ne) ? a.emit_w[eb + e0 + 256 * q] : 0.0;
+#pragma unroll
+					for (int q = 0; q < WK; q++) {
+						if (e0 + 256 * q < ne) atomicAdd(&hist[bin_of(wr[q])], 1);
+					}
+				}
 			}
 			__syncthreads();
 			if (wv == 0) {
@@ -316,27 +330,36 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 			if (cnt <= capN && s_maxb <= 512) {
 				unsigned long long* const kw = (unsigned long long*) (smem + lay.x);   // [capN] full keys, bin after bin
 				unsigned int* const ks = (unsigned int*) (kw + capN);                  // [capN] their slots
-				// their canonical indices, which decide between equal weights (components never detected since birth: dozens of
-				// them), beside the slots when the pool has the room; read from memory pair by pair otherwise
-				const bool haveki = xsize >= NS + 516 + capN + 2;
-				unsigned int* const ki = out + capN;
-				auto place = [&](double w, int e) {
+				unsigned int* const ki = out + capN;                                   // [capN] their canonical indices (haveki; read from memory pair by pair otherwise)
+				auto place = [&](double w, int e, int idx) {
 					const int bq = bin_of(w);
 					if (bq >= T) {
 						const int pos = atomicAdd(&hist[bq], 1);   // (the start becomes the end)
 						kw[pos] = prune_key(w);
 						ks[pos] = (unsigned int) e;
-						if (haveki) ki[pos] = (unsigned int) a.emit_idx[eb + e];
+						if (haveki) ki[pos] = (unsigned int) idx;
 					}
 				};
 				if (keepw) {
 #pragma unroll
 					for (int q = 0; q < WK; q++) {
-						if (tid + 256 * q < ne) place(wk[q], tid + 256 * q);
+						if (tid + 256 * q < ne) place(wk[q], tid + 256 * q, ik[q]);
 					}
 				}
 				else {
-					for (int e = tid; e < ne; e += 256) place(a.emit_w[eb + e], e);
+					// more than 2048 emitted entries: the same in rounds of WK entries per thread, a round's loads issued together
+					for (int e0 = tid; e0 < ne; e0 += 256 * WK) {
+#pragma unroll
+						for (int q = 0; q < WK; q++) {
+							const int e = e0 + 256 * q;
+							wk[q] = (e < ne) ? a.emit_w[eb + e] : 0.0;
+							ik[q] = (haveki && e < ne) ? a.emit_idx[eb + e] : 0;
+						}
+#pragma unroll
+						for (int q = 0; q < WK; q++) {
+							if (e0 + 256 * q < ne) place(wk[q], e0 + 256 * q, ik[q]);
+						}
+					}
 				}
 				__syncthreads();
 				PHD_STAMP(6);
@@ -457,69 +480,86 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 	double birthP[6];
 #pragma unroll
 	for (int t = 0; t < 6; t++) birthP[t] = prm.birthP[t];   // (a local copy, as merge_thr2: the lambdas below must not capture `prm`)
+	// The gather is written WITHOUT control flow between a thread's loads: behind a divergent branch the compiler waits for
+	// every outstanding memory operation (s_waitcnt vmcnt(0) at the join — it cannot count them across the branch), which made
+	// a thread's rows one full trip to memory each, one after the other. Rows beyond the cut are clamped to the last kept row
+	// (their loads hit lines the wave reads anyway, their stores are predicated off); a birth's copy reads its (unwritten)
+	// emit record like an update and is patched afterwards (rare: the one branch, behind all loads).
 	struct RowSrc { const double* rec; double w; int cidx; };
-	auto resolve = [&](int r) {
+	auto resolve_ranked = [&](int r) {
 		RowSrc o;
-		int slt;
-		if (rk_kw) {
-			const unsigned int pos = order[r];
-			slt = (int) rk_ks[pos];
-			o.w = __longlong_as_double((long long) (rk_kw[pos] & 0x7fffffffffffffffull));   // prune_key of a positive weight, undone
-			o.cidx = rk_ki ? (int) rk_ki[pos] : a.emit_idx[eb + slt];
-		}
-		else {
-			slt = (int) (order[r] & smask);
-			o.w = a.emit_w[eb + slt];
-			o.cidx = a.emit_idx[eb + slt];
-		}
+		const unsigned int pos = order[r];
+		const int slt = (int) rk_ks[pos];
+		o.w = __longlong_as_double((long long) (rk_kw[pos] & 0x7fffffffffffffffull));   // prune_key of a positive weight, undone
+		o.cidx = (int) rk_ki[pos];
 		o.rec = (o.cidx < nprior) ? prior + (size_t) o.cidx * MIX_REC : a.emit_rec + (eb + slt) * MIX_REC;
 		return o;
 	};
-	// the record of a resolved row into the slab; its bound into LDS; the box and the largest radius; its mean handed back
-	auto stage = [&](int r, const RowSrc& o, double mo[3]) {
-		double w_, m[3], P[6];
-		if (o.cidx >= nprior && o.cidx < npredicted) {   // the copy of a birth: mean from the sweep, BirthCovariance
-			const double* bm = a.born_mean + ((size_t) p * a.Mcap + (o.cidx - nprior)) * 3;
-			m[0] = bm[0]; m[1] = bm[1]; m[2] = bm[2];
-#pragma unroll
-			for (int t = 0; t < 6; t++) P[t] = birthP[t];
-		}
-		else load_comp(o.rec, w_, m, P);
-		double2* row = (double2*) (srec + (size_t) r * PRUNE_ROW);
-		row[0] = make_double2(o.w, m[0]); row[1] = make_double2(m[1], m[2]);
-		row[2] = make_double2(P[0], P[1]); row[3] = make_double2(P[2], P[3]); row[4] = make_double2(P[4], P[5]);
-		row[5] = make_double2((double) o.cidx, 0.0);
-		const double P0 = P[0], P1 = P[1], P2 = P[2], P3 = P[3], P4 = P[4], P5 = P[5];
-		double det = P0 * (P3 * P5 - P4 * P4) - P1 * (P1 * P5 - P4 * P2) + P2 * (P1 * P4 - P3 * P2);
-		bool pd = P0 > 0 && (P0 * P3 - P1 * P1) > 0 && det > 0;   // Sylvester
-		double rad = pd ? sqrt(merge_thr2 * (P0 + P3 + P5)) : INFINITY;
-		rad2[r] = rad * rad * (1.0 + 1e-6);
-		if (pd) rmx = fmax(rmx, rad);
-		lo0 = fmin(lo0, m[0]); lo1 = fmin(lo1, m[1]); lo2 = fmin(lo2, m[2]);
-		hi0 = fmax(hi0, m[0]); hi1 = fmax(hi1, m[1]); hi2 = fmax(hi2, m[2]);
-		mo[0] = m[0]; mo[1] = m[1]; mo[2] = m[2];
+	auto resolve_listed = [&](int slt, double w, int cidx) {
+		RowSrc o;
+		o.w = w; o.cidx = cidx;
+		o.rec = (cidx < nprior) ? prior + (size_t) cidx * MIX_REC : a.emit_rec + (eb + slt) * MIX_REC;
+		return o;
 	};
-	// (the means of a thread's first four rows — all of them up to 1024 kept entries — stay in registers for the grid below:
-	// it reads nothing back)
+	struct RowRec { double m0, m1, m2, P0, P1, P2, P3, P4, P5; };
+	auto fetch = [&](const RowSrc& o) {   // (five 16-byte loads; the weight in front of the mean is the entry's own, o.w)
+		const double2* q = (const double2*) o.rec;
+		const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4];
+		return RowRec{a0.y, a1.x, a1.y, a2.x, a2.y, a3.x, a3.y, a4.x, a4.y};
+	};
+	// the copy of a birth (canonical index in [nprior, npredicted)): mean from the sweep, BirthCovariance — selects, no branch
+	auto patch_birth = [&](const RowSrc& o, RowRec v) {
+		const bool birth = o.cidx >= nprior && o.cidx < npredicted;
+		const double* bm = a.born_mean + ((size_t) p * a.Mcap + (birth ? o.cidx - nprior : 0)) * 3;
+		const double b0 = bm[0], b1 = bm[1], b2 = bm[2];
+		v.m0 = birth ? b0 : v.m0; v.m1 = birth ? b1 : v.m1; v.m2 = birth ? b2 : v.m2;
+		v.P0 = birth ? birthP[0] : v.P0; v.P1 = birth ? birthP[1] : v.P1; v.P2 = birth ? birthP[2] : v.P2;
+		v.P3 = birth ? birthP[3] : v.P3; v.P4 = birth ? birthP[4] : v.P4; v.P5 = birth ? birthP[5] : v.P5;
+		return v;
+	};
+	// ... its record into the slab; its bound into LDS; the box and the largest radius
+	auto stage = [&](int r, const RowSrc& o, const RowRec& v) {
+		double2* row = (double2*) (srec + (size_t) r * PRUNE_ROW);
+		row[0] = make_double2(o.w, v.m0); row[1] = make_double2(v.m1, v.m2);
+		row[2] = make_double2(v.P0, v.P1); row[3] = make_double2(v.P2, v.P3); row[4] = make_double2(v.P4, v.P5);
+		row[5] = make_double2((double) o.cidx, 0.0);
+		const double det = v.P0 * (v.P3 * v.P5 - v.P4 * v.P4) - v.P1 * (v.P1 * v.P5 - v.P4 * v.P2) + v.P2 * (v.P1 * v.P4 - v.P3 * v.P2);
+		const bool pd = v.P0 > 0 && (v.P0 * v.P3 - v.P1 * v.P1) > 0 && det > 0;   // Sylvester
+		const double rad = pd ? sqrt(merge_thr2 * (v.P0 + v.P3 + v.P5)) : INFINITY;
+		rad2[r] = rad * rad * (1.0 + 1e-6);
+		rmx = pd ? fmax(rmx, rad) : rmx;
+		lo0 = fmin(lo0, v.m0); lo1 = fmin(lo1, v.m1); lo2 = fmin(lo2, v.m2);
+		hi0 = fmax(hi0, v.m0); hi1 = fmax(hi1, v.m1); hi2 = fmax(hi2, v.m2);
+	};
+	// Two rows of this thread per batch (ra, ra + 256): both descriptions, then both records, then the stores — vector memory
+	// operations retire in issue order (vmcnt counts loads and stores together), so no load is issued behind a store of its
+	// own batch. (Four rows per batch: the kernel spilled 192 bytes per lane at its 128 registers.)
 	double kmean[4][3];
 #pragma unroll
 	for (int q = 0; q < 4; q++) { kmean[q][0] = 0; kmean[q][1] = 0; kmean[q][2] = 0; }
-#pragma unroll
-	for (int q = 0; q < 4; q += 2) {
-		const int ra = tid + 256 * q, rb = ra + 256;
-		if (ra < cut) {   // (two rows per trip)
-			const RowSrc oa = resolve(ra);
-			if (rb < cut) {
-				const RowSrc ob = resolve(rb);
-				stage(ra, oa, kmean[q]);
-				stage(rb, ob, kmean[q + 1]);
-			}
-			else stage(ra, oa, kmean[q]);
+	const bool anybirth = npredicted > nprior;
+	auto gather2 = [&](int ra, double* ka, double* kb) {
+		const int rb = ra + 256;
+		const int ca = min(ra, cut - 1), cb = min(rb, cut - 1);
+		RowSrc oa, ob;
+		if (rk_kw && rk_ki) {   // (workgroup-uniform)
+			oa = resolve_ranked(ca); ob = resolve_ranked(cb);
 		}
-	}
-	for (int r = tid + 1024; r < cut; r += 256) {
-		double mdummy[3];
-		stage(r, resolve(r), mdummy);
+		else {
+			const int sa = rk_kw ? (int) rk_ks[order[ca]] : (int) (order[ca] & smask), sb = rk_kw ? (int) rk_ks[order[cb]] : (int) (order[cb] & smask);
+			const double wa = a.emit_w[eb + sa], wb = a.emit_w[eb + sb];
+			const int ia = a.emit_idx[eb + sa], ib = a.emit_idx[eb + sb];
+			oa = resolve_listed(sa, wa, ia); ob = resolve_listed(sb, wb, ib);
+		}
+		RowRec va = fetch(oa), vb = fetch(ob);
+		if (anybirth) { va = patch_birth(oa, va); vb = patch_birth(ob, vb); }   // (workgroup-uniform)
+		if (ra < cut) { stage(ra, oa, va); if (ka) { ka[0] = va.m0; ka[1] = va.m1; ka[2] = va.m2; } }
+		if (rb < cut) { stage(rb, ob, vb); if (kb) { kb[0] = vb.m0; kb[1] = vb.m1; kb[2] = vb.m2; } }
+	};
+	if (cut > 0) {
+		gather2(tid, kmean[0], kmean[1]);          // (the means of the first four rows — all rows, up to 1024 kept entries —
+		if (cut > 512) gather2(tid + 512, kmean[2], kmean[3]);   //  stay in registers for the grid below)
+		for (int ra = tid + 1024; ra < cut; ra += 512) gather2(ra, nullptr, nullptr);
 	}
 	// the mean of slab row r: the 32 bytes at its head, one sector
 	auto slab_mean = [&](int r, double& x0, double& x1, double& x2) {
@@ -735,12 +775,41 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 				const float thr = (float) (rr * rr * (1.0 + 1e-5));
 				unsigned long long pend0 = 0, pend1 = 0;   // up to 8 queued rows as 16-bit fields
 				int npend = 0;
+				// the queued rows' exact tests, four at a time: their means are fetched together (one trip to the slab for the
+				// four, not one each, one after the other)
 				auto drain = [&]() {
-					for (; npend > 0; npend--) {
-						const int f = npend - 1;
-						test((int) (((f < 4) ? (pend0 >> (16 * f)) : (pend1 >> (16 * (f - 4)))) & 0xffff));
+					if (npend > 0 && !have) {
+						double P[6], mm[3], wi, det;
+						load_comp(srec + (size_t) i * PRUNE_ROW, wi, mm, P);
+						inv_sym3(P, Pi, det);
+						m0 = mm[0]; m1 = mm[1]; m2 = mm[2];
+						have = true;
 					}
-					pend0 = 0; pend1 = 0;
+					for (int b0 = 0; b0 < npend; b0 += 4) {
+						int kk[4];
+						double kx[4], ky[4], kz[4];
+#pragma unroll
+						for (int u = 0; u < 4; u++) {
+							const int f = b0 + u;
+							kk[u] = (f < npend) ? (int) (((f < 4) ? (pend0 >> (16 * f)) : (pend1 >> (16 * (f - 4)))) & 0xffff) : i;
+							slab_mean(kk[u], kx[u], ky[u], kz[u]);   // (an idle slot reads the row's own mean: a line it has)
+						}
+#pragma unroll
+						for (int u = 0; u < 4; u++) {
+							const double d0 = m0 - kx[u], d1 = m1 - ky[u], d2 = m2 - kz[u];
+							const double sq = d0 * d0 + d1 * d1 + d2 * d2;
+							if (b0 + u < npend && sq <= bound && quad_sym(Pi, d0, d1, d2) < merge_thr2) {
+								unsigned int v = (unsigned int) kk[u];
+#pragma unroll
+								for (int q = 0; q < PRUNE_NBR; q++) {
+									unsigned int lo_ = min(e[q], v), hi_ = max(e[q], v);
+									e[q] = lo_; v = hi_;
+								}
+								cnt++;
+							}
+						}
+					}
+					npend = 0; pend0 = 0; pend1 = 0;
 				};
 				unsigned int qb[8];
 				const int n = ranges(me, qb);
@@ -767,6 +836,8 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 #endif
 				unsigned int cur = 0, left = 0;
 				int c = 0;
+				// (four candidates per trip, their four LDS reads in flight together, was measured: the walk took 37 k cycles
+				// against 19 k — the bookkeeping of four cursors with their divergent range changes costs more than the latency)
 				for (int f = 0; f < n; f++) {
 #ifdef PHD_STAMP_COUNTERS
 					if (a.stamps && a.stamp_kernel == 2 && (int) (__ffsll((long long) ballot64(1)) - 1) == lane) atomicAdd(&a.stamps[(size_t) p * 16 + 15], 1.0);   // wave-level trips
@@ -980,28 +1051,48 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 	double* wcopy = a.wcopy + (size_t) p * (a.cap + a.Mcap);
 	for (int c = tid; c < npred; c += 256) wcopy[c] = 0.0;
 	__syncthreads();
+	// positions first, for all rows at once (one barrier): the survivors of every chunk of 256 rows and wave are counted into
+	// scan[chunk][wave]; a survivor's position is the survivors of the chunks before its own, of the waves before its own in
+	// the chunk, and of the lanes before its own in the wave
+	const int nchunks = (cut + 255) >> 8;   // (at most 14: MaxQuantity is bounded by the LDS, phd_create)
+	auto survives = [&](int i) { return i < cut && !(((unsigned int) absb[i & 63] >> (i >> 6)) & 1u); };
+	for (int q = 0; q < nchunks; q++) {
+		const unsigned long long bal = ballot64(survives(q * 256 + tid));
+		if (lane == 0) scan[q * 4 + wv] = __popcll(bal);
+	}
+	__syncthreads();
 	int nsurv_before = 0;
-	for (int r0 = 0; r0 < cut; r0 += 256) {
-		const int  i = r0 + tid;
-		const bool surv = i < cut && !(((unsigned int) absb[i & 63] >> (i >> 6)) & 1u);
-		unsigned long long bal = ballot64(surv);
-		if (lane == 0) scan[wv] = __popcll(bal);
-		__syncthreads();
+	// A thread's rows are tid + 256 q, one after the other; the slab record of the NEXT one is requested before the results of
+	// this one are stored (memory operations retire in issue order: behind the stores the next row's loads would wait for the
+	// stores' acknowledgements as well).
+	double nw = 0, nm[3] = {0, 0, 0}, nP[6] = {0, 0, 0, 0, 0, 0}, ncidxd = 0;
+	auto request = [&](int q) {   // (no branch: a row beyond the cut, or an absorbed one, reads a line its wave reads anyway)
+		const int i = min(q * 256 + tid, max(cut - 1, 0));
+		const double2* row = (const double2*) (srec + (size_t) i * PRUNE_ROW);
+		const double2 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3], r4 = row[4], r5 = row[5];
+		nw = r0.x; nm[0] = r0.y; nm[1] = r1.x; nm[2] = r1.y;
+		nP[0] = r2.x; nP[1] = r2.y; nP[2] = r3.x; nP[3] = r3.y; nP[4] = r4.x; nP[5] = r4.y;
+		ncidxd = r5.x;
+	};
+	if (cut > 0) request(0);
+	for (int q = 0; q < nchunks; q++) {
+		const int  i = q * 256 + tid;
+		const bool surv = survives(i);
+		const unsigned long long bal = ballot64(surv);
 		int base = nsurv_before;
-		for (int q = 0; q < wv; q++) base += scan[q];
-		const int total = scan[0] + scan[1] + scan[2] + scan[3];
-		__syncthreads();
+		for (int u = 0; u < wv; u++) base += scan[q * 4 + u];
+		const int total = scan[q * 4] + scan[q * 4 + 1] + scan[q * 4 + 2] + scan[q * 4 + 3];
+		// (this row's slab record: the component record and, in the sixth 16 bytes, its canonical index)
+		const double w = nw, Pr[6] = {nP[0], nP[1], nP[2], nP[3], nP[4], nP[5]};
+		const double m0 = nm[0], m1 = nm[1], m2 = nm[2];
+		const int cidx = (int) ncidxd;
+		if (q + 1 < nchunks) request(q + 1);   // (uniform)
 		if (surv) {
 			// the reference runs on the CLR (no fused multiply-add): Merge's raw moments must round as there, or a scene far
 			// from the origin loses digits of the covariance to the difference (tests: test_reweight_far_from_the_origin)
 PHD_REF_ARITH
 			const int pos = base + __popcll(bal & lanemask_lt());
-			// (this row's slab record: the component record and, in the sixth 16 bytes, its canonical index)
-			double w, mi[3], Pr[6];
-			load_comp(srec + (size_t) i * PRUNE_ROW, w, mi, Pr);
-			const int cidx = (int) srec[(size_t) i * PRUNE_ROW + 10];
 			// Gaussian.Merge (Gaussian.cs:329-346): raw moments, the candidate first, then its set in list order
-			const double m0 = mi[0], m1 = mi[1], m2 = mi[2];
 			double W = 0.0 + w;
 			double M0 = 0.0 + w * m0, M1 = 0.0 + w * m1, M2 = 0.0 + w * m2;
 			double C0 = 0.0 + w * (Pr[0] + m0 * m0), C1 = 0.0 + w * (Pr[1] + m0 * m1), C2 = 0.0 + w * (Pr[2] + m0 * m2);

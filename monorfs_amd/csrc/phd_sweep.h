@@ -63,6 +63,12 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 
 	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int M = a.M;
+#ifdef PHD_STAMPS
+	// diagnostic build (PHD_STAMP_KERNEL=6): the clock the chip holds under this kernel — shader cycles (s_memtime) against
+	// the constant 100 MHz counter (s_memrealtime) over the workgroup's lifetime, and over its pair loops alone
+	const long long st_c0 = clock64(), st_r0 = wall_clock64();
+	long long st_pairc = 0, st_pairr = 0;
+#endif
 	const int klane = HALF ? (lane & 31) : lane;          // this lane's measurement (within its block of 64)
 	const int hoff  = HALF ? 4 * (lane >> 5) : 0;         // ... and how far behind the wave's component its own is
 	const bool owner = !HALF || lane < 32;                // the lane that speaks for the measurement in the reductions
@@ -260,6 +266,9 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 			}
 		};
 		int cc = wv;
+#ifdef PHD_STAMPS
+		const long long st_pc = clock64(), st_pr = wall_clock64();
+#endif
 		if (HALF) {
 			for (; cc < cend; cc += 8) visit(cc);   // components cc and cc + 4 at once
 		}
@@ -267,6 +276,9 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 			for (; cc + 4 < cend; cc += 8) { visit(cc); visit(cc + 4); }
 			if (cc < cend) visit(cc);
 		}
+#ifdef PHD_STAMPS
+		st_pairc += clock64() - st_pc; st_pairr += wall_clock64() - st_pr;
+#endif
 		if (!compact) {
 #pragma unroll
 			for (int b = 0; b < ZB; b++) part2[wv * MP + b * 64 + lane] = dens[b];
@@ -403,6 +415,12 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 		if (ne > a.ecap) { atomicOr(a.flags, PHD_FLAG_EMIT_OVERFLOW); ne = a.ecap; }
 		a.emit_count[p] = ne;
 	}
+#ifdef PHD_STAMPS
+	if (tid == 0 && a.stamps && a.stamp_kernel == 6) {
+		double* o = a.stamps + (size_t) p * 16;
+		o[0] = 0; o[1] = (double) (clock64() - st_c0); o[2] = (double) (wall_clock64() - st_r0); o[3] = (double) st_pairc; o[4] = (double) st_pairr;
+	}
+#endif
 }
 
 #ifndef PHD_SWEEP_WAVES

@@ -1409,7 +1409,7 @@ const double* phd_stage_setloglik(phd_navigator* nav, int* length)
 }
 
 // the gathered weight vector of all ranks (+ room for their status words behind it) and the global source vector
-static int ensure_gw(phd_navigator* nav, int n)
+static int ensure_gw(phd_navigator* nav, int n, bool shared = false)
 {
 	if (n <= nav->gwcap) return PHD_OK;
 	if (nav->gw_shared) return nav->fail(PHD_ERR_GENERIC, "the gathered-weight vector of a shard cannot grow (other shards hold its address)");
@@ -1418,7 +1418,12 @@ static int ensure_gw(phd_navigator* nav, int n)
 	nav->d_gw = nullptr;
 	hipFree(nav->d_plan);
 	nav->d_plan = nullptr;
-	HC(hipMalloc((void**) &nav->d_gw, ((size_t) n + PHD_MAX_DEVICES) * 8));
+	// (a multi-device handle's shards store their weights into each other's vectors: fine-grained, as the receive buffers)
+	if (!shared || getenv("PHD_COARSE_RECV") || hipExtMallocWithFlags((void**) &nav->d_gw, ((size_t) n + PHD_MAX_DEVICES) * 8, hipDeviceMallocFinegrained) != hipSuccess) {
+		(void) hipGetLastError();
+		nav->d_gw = nullptr;
+		HC(hipMalloc((void**) &nav->d_gw, ((size_t) n + PHD_MAX_DEVICES) * 8));
+	}
 	HC(hipMalloc((void**) &nav->d_plan, (size_t) n * 4));
 	nav->gwcap = n;
 	return PHD_OK;

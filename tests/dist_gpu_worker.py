@@ -1,8 +1,11 @@
 """Worker of tests/test_gpu_multiproc.py: one rank of a sharded SlamUpdate sequence on a real device. All ranks share
-cuda:0 (RCCL refuses two ranks on one GPU), so the two collectives of the step — the all-gather of the particle weights
-and the all-to-all of the migrating particles — run on gloo through host copies of the library's device buffers, with
-exactly the call sequence and split-size conventions bench.py uses over RCCL. Rank 0 also runs the whole particle set in
-one handle and compares."""
+cuda:0 (RCCL refuses two ranks on one GPU), so the collectives of the step run on gloo through host copies of the library's
+device buffers, with exactly the call sequence bench.py uses over RCCL. Rank 0 also runs the whole particle set in one handle
+and compares.
+  mode "device" (argv[1], the default; what bench.py --gpus N runs): no host wait — the weights (+ status words) are
+      all-gathered, the plan stays on the device, every rank's kernels store the migrating particles straight into the other
+      PROCESSES' receive buffers (opened through hipIpcMemHandle), a barrier stands in for the one-word all-reduce;
+  mode "host": round 3's sequence — the host waits for the plan's split sizes and moves the records with all_to_all_single."""
 import ctypes as C
 import os
 import sys
@@ -50,9 +53,43 @@ def main():
         one = navigator.PHDNavigator(p1, particlecount=Pg)
         one.upload_state(planes, f.counts, f.poses, f.weights)
     nresampled = 0
+    mode = sys.argv[1] if len(sys.argv) > 1 else "device"
+    if mode == "device":
+        graw = dev(lib.phd_device_gather_buffer(h, world), world * (Pl + 1))
+        hbuf = C.create_string_buffer(64)
+        nav._check(lib.phd_migration_ipc_export(h, hbuf, None))
+        handles = [None] * world
+        dist.all_gather_object(handles, bytes(hbuf.raw))
+        nav._check(lib.phd_migration_ipc_open(h, b"".join(handles), rank, world))
     for step in range(steps):
         u = 0.3 + 0.2 * step
         nav._check(lib.phd_step_local_async(h, 0))
+        if mode == "device":
+            lw = dev(lib.phd_device_local_weights(h), Pl + 1).cpu()
+            g_host = torch.empty(world * (Pl + 1), dtype=torch.float64)
+            dist.all_gather_into_tensor(g_host, lw)
+            graw.copy_(g_host)
+            nav._check(lib.phd_step_global_device_async(h, rank, world, C.c_double(u), 0))
+            nav._check(lib.phd_migration_push_async(h))
+            torch.cuda.synchronize()
+            dist.barrier()                      # every rank's records have landed (bench.py: a one-word all-reduce on the stream)
+            nav._check(lib.phd_migration_unpack_async(h))
+            nav.sync()
+            ns = nr = 0
+            w_all = [None] * world
+            dist.gather_object((nav.VehicleWeights, nav.poses(), [nav.MapModel(i) for i in (0, Pl // 2, Pl - 1)], 0, 0),
+                               w_all if rank == 0 else None, dst=0)
+            if rank == 0:
+                one.SlamUpdate(None, f.z, u_resample=u)
+                nresampled += bool(one.resample_sources()[1])
+                assert np.array_equal(one.VehicleWeights, np.concatenate([x[0] for x in w_all])), "step %d: weights differ" % step
+                assert np.array_equal(one.poses(), np.concatenate([x[1] for x in w_all])), "step %d: poses differ" % step
+                for r in range(world):
+                    for j, i in enumerate((0, Pl // 2, Pl - 1)):
+                        a_, b_ = one.MapModel(r * Pl + i), w_all[r][2][j]
+                        assert all(np.array_equal(x, y) for x, y in zip(a_, b_)), "step %d rank %d particle %d" % (step, r, i)
+                print("step %d ok (device plan, IPC push)" % step, flush=True)
+            continue
         lw = dev(lib.phd_device_local_weights(h), Pl).cpu()
         gw_host = torch.empty(Pg, dtype=torch.float64)
         dist.all_gather_into_tensor(gw_host, lw)

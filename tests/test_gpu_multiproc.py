@@ -1,5 +1,7 @@
-"""Two real processes, one rank each, sharing the GPU: the sharded SlamUpdate with its two collectives (gloo, staged
-through host memory because RCCL refuses two ranks on one device) against a single handle holding all particles."""
+"""Two / three real processes, one rank each, sharing the GPU: the sharded SlamUpdate (collectives on gloo, staged through
+host memory because RCCL refuses two ranks on one device) against a single handle holding all particles — in the sequence
+bench.py runs (plan on the device, migrating particles stored into the other processes' IPC-opened buffers, no host wait) and
+in round 3's (host-side split sizes, all_to_all_single)."""
 import os
 import subprocess
 import sys
@@ -11,10 +13,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_sequence_in_real_processes(world):
+@pytest.mark.parametrize("world,mode", [(2, "device"), (3, "device"), (2, "host"), (3, "host")])
+def test_sharded_sequence_in_real_processes(world, mode):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29530 + world))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                         "--master-addr", "127.0.0.1", "--master-port", str(29530 + world),
-                        os.path.join(ROOT, "tests", "dist_gpu_worker.py")], capture_output=True, text=True, env=env, timeout=300)
+                        os.path.join(ROOT, "tests", "dist_gpu_worker.py"), mode], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "multiproc ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
