@@ -677,6 +677,7 @@ __global__ __launch_bounds__(64) void k_test_pairing(MurtyNodes* nodes, char* bi
 // Arrays indexed by landmark live in LDS while the map estimate has at most ALPHA_JL landmarks; a larger
 // estimate (up to Jcap) moves them to a per-particle slab in HBM, reached through the same (flat) pointers.
 #define ALPHA_JL 256
+#define ALPHA_DEFER_ROWS 10   // a particle with an association cluster of more rows than this is left to the big-cluster workers (DEFER, below)
 
 struct AlphaLds {
 	int zs, red, lm, pick, scr;                 // persistent, offsets in doubles
@@ -747,8 +748,14 @@ __host__ __device__ inline size_t alpha_jscratch_doubles(int Jcap)
 #define QGRAD_G2_CLUSTERS 64                                  // headers / weights of the first pass kept in LDS for the ordered replay
 #define QGRAD_G2_WEIGHTS 384
 #define QGRAD_HDR 10                                         // doubles per cluster in the particle's scratch: pairings, G[6], list offset, finite
-template <int ZB, bool QUASI, bool GRAD = false, int TAG = 0>
-__device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const StepBufs& a, int ncap, double* smem, double* gws = nullptr)
+// DEFER (the step's k_alpha_assoc; 0: everything here): the ordered replay of the clusters of more than 5 rows — best-first
+//                enumeration by ONE wave, up to 200 assignment problems per cluster — is rare per particle and enormous when
+//                it happens (config S: 5 % of the particles, 15 times the median workgroup's lifetime: the launch waited for
+//                them). 1: a particle that needs it is put on the launch's list (StepBufs::biglist) and gets no set
+//                log-likelihood here; 2: k_alpha_big, one workgroup per listed particle (pin >= 0), runs the body again WITH the
+//                replay — on a stream of its own, beside k_alpha_density, which does not need the value (k_alpha_combine does).
+template <int ZB, bool QUASI, bool GRAD = false, int TAG = 0, int DEFER = 0>
+__device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const StepBufs& a, int ncap, double* smem, double* gws = nullptr, int pin = -1)
 {
 	constexpr int MP = ZB * 64;
 	constexpr int MW = ZB;   // 64-bit adjacency words per landmark
@@ -757,18 +764,19 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 	double* zs   = smem + lay.zs;          // [MP][3] measurements
 	double* red  = smem + lay.red;         // [256] reduction scratch
 	double* etab = red;                    // [256] exp table (filled before the cluster sums, once `red` is idle)
-	__shared__ int s_J, s_changed, s_nroots, s_big;
+	__shared__ int s_J, s_changed, s_nroots, s_big, s_huge;
 	__shared__ double s_ccount, s_total;
 	__shared__ int s_ebump, s_g2lds;                                                    // gradient mode (see the first pass below)
 	__shared__ double s_g2[GRAD ? QGRAD_G2_CLUSTERS * QGRAD_HDR + QGRAD_G2_WEIGHTS : 2];
 	if (GRAD && threadIdx.x == 0) s_g2lds = 0;
 
-	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int p = (pin >= 0) ? pin : a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int M = a.M, cap = a.cap;
 	const MixView vin = bank_view(a, SEL_IN), vout = bank_view(a, SEL_OUT);
 	const Bank bin = bank_of(a, SEL_IN);
 	const Bank bout = bank_of(a, SEL_OUT);
 	const int no = QUASI ? 0 : vout.count[p];
+	bool deferred = false;   // (workgroup-uniform) DEFER == 1: this particle is left to k_alpha_big
 	const size_t sbo = (size_t) p * cap;
 	const PoseD pose = load_pose(QUASI ? a.qposes + (size_t) p * 7 : bin.poses + (size_t) p * 7);
 
@@ -1032,7 +1040,7 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 		}
 		for (int k = tid; k < M; k += 256) labz[k] = J + k;
 		for (int t = tid; t < MP * JW; t += 256) adjT[t] = 0;
-		if (tid == 0) { s_nroots = 0; s_big = 0; }
+		if (tid == 0) { s_nroots = 0; s_big = 0; s_huge = 0; }
 		__threadfence_block();
 		__syncthreads();
 		// detection block: defined iff Mahalanobis(z_k; h(m_j), R) < 5 (:433-442). Measurement per lane, wave w takes the
@@ -1161,6 +1169,7 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 				if (nl + nz > 5) {
 					res[ri] = NAN;   // solved below by the Murty path
 					s_big = 1;
+					if (nl + nz > ALPHA_DEFER_ROWS) s_huge = 1;
 					continue;
 				}
 				const unsigned long long Lp = pk_sort5(memL[root], nl), Zp = pk_sort5(memZ[root], nz);   // members, ascending
@@ -1248,6 +1257,7 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 					if (nrow > 5) {
 						res[ri] = NAN;   // solved below by the Murty path
 						s_big = 1;
+						if (nrow > ALPHA_DEFER_ROWS) s_huge = 1;
 					}
 					else {
 						double* mat = mats + lane;   // entry e at mat[e * 4] (fewer than 5 landmarks: at most 4 clusters)
@@ -1531,7 +1541,11 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 			__syncthreads();
 		}
 		PHD_STAMP(8);
-		if (s_big) {
+		if (DEFER == 1 && s_huge) {
+			deferred = true;
+			if (tid == 0) a.biglist[1 + atomicAdd(a.biglist, 1)] = p;   // ([0]: entries; emptied by k_normalise_resample)
+		}
+		else if (s_big) {
 			// Some cluster has more than 5 rows: it is enumerated best-first (MurtyPairing) under the
 			// early-exit test of PHDNavigator.cs:503, which reads logcomp[m] as left behind by the clusters
 			// before it. So wave 0 replays the clusters in order up to the last such cluster, keeping the
@@ -1653,12 +1667,16 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 						}
 					}
 					else {
-						mcount = wave_murty_any<TAG>(ws, nd, nrow, lane, [&](int m, bool unsolved, auto colof) {
+						auto hook = [&](int m, bool unsolved, auto colof) {
 							if (!GRAD) return;
 							double g = 0;
 							if (!unsolved) g = pairing_gradient(colof);
 							if (lane < 6) dvec[m][lane] = g;
-						});
+						};
+						// (the step's main kernel replays clusters of at most ALPHA_DEFER_ROWS rows only: the one-row-per-lane
+						// solver, none of the frames of the two- and four-row ones)
+						if (DEFER == 1) mcount = wave_murty<1, TAG>(ws, nd, nrow, lane, hook);
+						else mcount = wave_murty_any<TAG>(ws, nd, nrow, lane, hook);
 					}
 					if (mcount >= 0) {
 						// LogSumExp(logcomp, 0, m), MatrixExtensions.cs:361-389
@@ -1834,6 +1852,73 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 						}
 					}
 				}
+				else if (!GRAD && J >= 5) {
+					// Only what the clusters of up to 5 rows LEAVE in logcomp matters to a big one (its values are known from the
+					// permanent path): entry i is pairing number i of the last cluster before it that has more than i pairings
+					// (a cluster of n rows writes its n! values into [0, n!), in LexicographicalPairing's order — `modelsize` = J >=
+					// 5 >= n: every permutation once). So the clusters between two big ones are not replayed one after the other
+					// (one lane per cluster, a hundred clusters, 1.5 M cycles for the particles that had a big cluster at all —
+					// the launch waited for them): the lanes take the ENTRIES — the last cluster per row count by a wave maximum,
+					// the pairing unranked, its value summed over the rows in order (AssignmentValue), as the literal walk does.
+					auto small_value = [&](int ri, int idx) {
+						const int root = roots[ri];
+						const int cn = cnt[root];
+						const int nl = cn & 0xffff, nz = cn >> 16, nrow = nl + nz;
+						const unsigned long long Lp = pk_sort5(memL[root], nl), Zp = pk_sort5(memZ[root], nz);   // members, ascending
+						const unsigned int perm = pk_unrank(idx, nrow);
+						double v = 0;
+						for (int x = 0; x < nrow; x++) {
+							const int y = pk_get(perm, x);
+							double e = -INFINITY;
+							if (x < nl) {
+								const int j = (int) ((Lp >> (12 * x)) & 4095);
+								if (y < nz) {
+									const int k = (int) ((Zp >> (12 * y)) & 4095);
+									if ((adj[(size_t) j * MW + (k >> 6)] >> (k & 63)) & 1ull) {
+										const double dist = sqrt(quad_gen(prm.Rinv, zh[j] - zs[k * 3], zh[JS + j] - zs[k * 3 + 1],
+										                                  zh[2 * JS + j] - zs[k * 3 + 2]));
+										e = lpd[j] + logmult - 0.5 * dist * dist;
+									}
+								}
+								else if (y - nz == x) e = lmd[j];
+							}
+							else {
+								if (y < nz) { if (y == x - nl) e = prm.logkappa; }
+								else e = 0;
+							}
+							v += e;   // AssignmentValue: the rows in order
+						}
+						return v;
+					};
+					auto apply_small = [&](int lo, int hi) {   // the clusters [lo, hi), all of at most 5 rows, as logcomp sees them
+						int l2 = -1, l3 = -1, l4 = -1, l5 = -1;
+						for (int ri = lo + lane; ri < hi; ri += 64) {
+							const int cn = cnt[roots[ri]];
+							const int nrow = (cn & 0xffff) + (cn >> 16);
+							l2 = (nrow == 2) ? ri : l2; l3 = (nrow == 3) ? ri : l3; l4 = (nrow == 4) ? ri : l4; l5 = (nrow == 5) ? ri : l5;
+						}
+#pragma unroll
+						for (int o = 32; o > 0; o >>= 1) {
+							l2 = max(l2, __shfl_xor(l2, o, 64)); l3 = max(l3, __shfl_xor(l3, o, 64));
+							l4 = max(l4, __shfl_xor(l4, o, 64)); l5 = max(l5, __shfl_xor(l5, o, 64));
+						}
+						for (int idx = lane; idx < 120; idx += 64) {
+							int best = l5;                        // 120 pairings
+							if (idx < 24) best = max(best, l4);
+							if (idx < 6) best = max(best, l3);
+							if (idx < 2) best = max(best, l2);
+							if (best >= 0) ws.logcomp[idx] = small_value(best, idx);
+						}
+						lds_fence();
+					};
+					int done = 0;
+					for (int ri = 0; ri <= lastbig; ri++) {
+						if (!isnan(res[ri])) continue;   // (uniform: res is in LDS)
+						apply_small(done, ri);
+						replay_one(ri);
+						done = ri + 1;
+					}
+				}
 				else {
 					for (int ri = 0; ri <= lastbig; ri++) replay_one(ri);
 				}
@@ -1845,7 +1930,7 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 		// total over the components: clusters holding detections, the lone landmarks (misdetection only,
 		// log(1 - PD_j)) and the lone measurements (clutter, log kappa). The reference adds them in that order one
 		// by one; here every thread adds its share and the shares are summed in a fixed tree.
-		{
+		if (!deferred) {
 			double tpart = 0;
 			for (int r = tid; r < nroots; r += 256) tpart += res[r];
 			for (int j = tid; j < J; j += 256) {
@@ -1869,7 +1954,7 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 #endif
 	PHD_STAMP_FLUSH(3, 12);
 	if (tid == 0) {
-		a.setll[p] = s_total;
+		if (!deferred) a.setll[p] = s_total;
 		if (!QUASI) {
 			a.aJ[p]      = J;
 			a.account[p] = s_ccount;
@@ -1885,6 +1970,25 @@ __global__ __launch_bounds__(256, PHD_ASSOC_WAVES) void k_alpha_assoc(const DevP
 {
 	extern __shared__ __align__(16) double smem[];
 	alpha_assoc_body<ZB, false>(prm, a, ncap, smem);
+}
+
+// the same with the particles that need the ordered replay (a cluster of more than 5 rows) left to k_alpha_big
+template <int ZB>
+__global__ __launch_bounds__(256, PHD_ASSOC_WAVES) void k_alpha_assoc_main(const DevParams prm, const StepBufs a, int ncap)
+{
+	extern __shared__ __align__(16) double smem[];
+	alpha_assoc_body<ZB, false, false, 2, 1>(prm, a, ncap, smem);
+}
+
+// WeightAlpha's last line for every particle (PHDNavigator.cs:390-392, :335), when k_alpha_density left it open (a.defer):
+// alpha = exp(set log-likelihood + density ratio), weight *= alpha
+__global__ __launch_bounds__(256) void k_alpha_combine(const StepBufs a)
+{
+	const int p = blockIdx.x * 256 + threadIdx.x;
+	if (p >= a.P) return;
+	const double alpha = exp(a.setll[p] + a.ratio[p]);   // :392
+	a.alpha[p] = alpha;
+	bank_of(a, SEL_OUT).weights[p] = bank_of(a, SEL_IN).weights[p] * alpha;   // :335
 }
 
 // one workgroup per candidate pose (the smoother's pose x landmark x measurement batches)
@@ -1916,7 +2020,7 @@ __global__ __launch_bounds__(256, 4) void k_quasi_setll(const DevParams prm, con
 #define DENS_REC 12   // gauss_record + the weight ratio of the component's surviving misdetection copy (+ 1: records stay 16-byte aligned)
 
 #define DENS_LDS_DOUBLES (TILE * DENS_REC + 2 * (DENS_JL / 64) * 256 + EXPTAB_N + 2)
-__device__ __forceinline__ void alpha_density_body(const DevParams& prm, const StepBufs& a, double* pool)
+__device__ __forceinline__ void alpha_density_body(const DevParams& prm, const StepBufs& a, double* pool, int pin = -1)
 {
 	constexpr int JL = DENS_JL;
 	double* const tile = pool;                                        // [TILE][12]
@@ -1926,7 +2030,7 @@ __device__ __forceinline__ void alpha_density_body(const DevParams& prm, const S
 	int* const s_wc = (int*) (etab + EXPTAB_N);                       // [4]
 	double* red = tile;                          // reduction scratch once the sweeps are over
 
-	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int p = (pin >= 0) ? pin : a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int cap = a.cap;
 	const MixView vin = bank_view(a, SEL_IN), vout = bank_view(a, SEL_OUT);
 	const Bank bin = bank_of(a, SEL_IN);
@@ -2081,9 +2185,12 @@ __device__ __forceinline__ void alpha_density_body(const DevParams& prm, const S
 	if (tid == 0) {
 		const double ccount = a.account[p];
 		double ratio = (plog - pcount) - (clog - ccount);   // :390
-		double alpha = exp(a.setll[p] + ratio);             // :392
-		a.alpha[p] = alpha;
-		bout.weights[p] = bin.weights[p] * alpha;           // :335
+		if (a.defer) a.ratio[p] = ratio;                    // (k_alpha_combine: the set log-likelihood may still be in the making)
+		else {
+			double alpha = exp(a.setll[p] + ratio);         // :392
+			a.alpha[p] = alpha;
+			bout.weights[p] = bin.weights[p] * alpha;       // :335
+		}
 	}
 }
 
@@ -2091,4 +2198,24 @@ __global__ __launch_bounds__(256) void k_alpha_density(const DevParams prm, cons
 {
 	__shared__ __align__(16) double pool[DENS_LDS_DOUBLES];
 	alpha_density_body(prm, a, pool);
+}
+
+// ... and those particles, INSIDE the launch of the densities: the first `nbig` workgroups of k_alpha_density_big stride over the
+// list (how many there are is known on the device only) and run the association body again with the replay; the others are
+// k_alpha_density's. A replay is one wave deep in the solver for hundreds of microseconds: started first, beside a launch
+// that fills the machine for as long, it costs the step nothing. (On a stream of its own it did not overlap: HIP's streams
+// share four hardware queues, and with more of those the whole step ran a fifth slower.)
+template <int ZB>
+__global__ __launch_bounds__(256, 4) void k_alpha_density_big(const DevParams prm, const StepBufs a, int ncap, int nbig)
+{
+	extern __shared__ __align__(16) double smem[];
+	if ((int) blockIdx.x < nbig) {
+		const int n = a.biglist[0];
+		for (int w = blockIdx.x; w < n; w += nbig) {
+			alpha_assoc_body<ZB, false, false, 0, 2>(prm, a, ncap, smem, nullptr, a.biglist[1 + w]);
+			__syncthreads();   // (the next particle reuses the LDS arrays)
+		}
+		return;
+	}
+	alpha_density_body(prm, a, smem, a.p0 + (int) blockIdx.x - nbig);
 }

@@ -125,6 +125,10 @@ struct StepBufs {
 	double* wcopy;       // [P][cap + Mcap] weight of the surviving misdetection copy of predicted component c (0: none), k_prune_merge -> k_alpha_density
 	int*    cover;       // [P][cap] 1: this pruned component is such a copy
 	double* stamps;      // [P][16] phase stamps of the diagnostic build (NULL otherwise)
+	int*    biglist;     // k_alpha_assoc_main -> k_alpha_big: [0] entries, [1 ..] the particles of this launch whose association needs the ordered replay
+	int     bigstride;   // ints between the lists of two sub-ranges
+	double* ratio;       // [P] k_alpha_density -> k_alpha_combine: the density part of log alpha
+	int     defer;       // 1: the step runs k_alpha_assoc_main / k_alpha_big / k_alpha_combine (k_alpha_density leaves alpha open)
 	int     all_pairs;   // 1: k_sweep evaluates every (component, measurement) pair, the radius gate only masks (SURVEY §8d's benchmark
 	                     // mode: the unit count P C M is exact); 0: a visit whose 64 pairs all lie outside the gate is skipped
 	int     stamp_kernel; // which kernel writes them (env PHD_STAMP_KERNEL): 2 prune, 3 assoc, 4 density, 1 correct, 5 the one-launch chain
@@ -350,8 +354,13 @@ __global__ __launch_bounds__(256) void k_replicate(const StepBufs a, double weig
 __global__ __launch_bounds__(256) void k_push_weights(const StepBufs a, double* const* dst, int ndst, int first, int flagslot)
 {
 	const int i = blockIdx.x * 256 + threadIdx.x;
-	const double* w = bank_of(a, SEL_OUT).weights;
+	double* w = bank_of(a, SEL_OUT).weights;
 	if (i < a.P) {
+		if (a.defer) {   // WeightAlpha's last line, left open by k_alpha_density (see k_normalise_resample)
+			const double alpha = exp(a.setll[i] + a.ratio[i]);
+			a.alpha[i] = alpha;
+			w[i] = bank_of(a, SEL_IN).weights[i] * alpha;
+		}
 		const double v = w[i];
 		for (int t = 0; t < ndst; t++) dst[t][first + i] = v;
 	}

@@ -173,6 +173,7 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 	PHD_STAMP_DECL;
 	PHD_STAMP(0);
 	if (tid == 0 && a.bigws_used && *a.bigws_used) *a.bigws_used = 0;   // the association slab is free again (every k_alpha_assoc of the step is over)
+	if (tid < 4 && a.biglist) a.biglist[(size_t) tid * a.bigstride] = 0;   // ... and the sub-ranges' lists of deferred particles are empty again
 	// A kernel of this step raised a flag (emit capacity, landmark scratch): what it wrote into the OUT bank is not a
 	// valid state. The step is dropped as a whole — the roles stay, nothing of the current state was touched — and the host
 	// finds the flag at its next phd_sync. (Every thread reads the same word, written by earlier launches.)
@@ -181,6 +182,17 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 		return;
 	}
 	double* gwp = gw ? gw : bank_of(a, SEL_OUT).weights;
+	if (a.defer && !gw) {
+		// WeightAlpha's last line (PHDNavigator.cs:390-392, :335), left open by k_alpha_density while the set log-likelihoods of
+		// the particles with big association clusters were still in the making: alpha = exp(L + density ratio), weight *= alpha
+		const double* win = bank_of(a, SEL_IN).weights;
+		for (int i = tid; i < P; i += nt) {
+			const double alpha = exp(a.setll[i] + a.ratio[i]);
+			a.alpha[i] = alpha;
+			gwp[i] = win[i] * alpha;
+		}
+		__syncthreads();   // (a workgroup's own stores: visible to its loads behind the barrier)
+	}
 	const int CH = (P + nt - 1) / nt;              // contiguous chunk of every thread
 	const int c0 = min(P, tid * CH), c1 = min(P, c0 + CH), cn = c1 - c0;
 	// The vector is staged in LDS chunk-transposed: element j of chunk t at lw[j * LS + t], LS = nt + 1. Every loop below has

@@ -47,6 +47,18 @@ struct phd_navigator {
 	int         chain_max = 512;       // up to this many particles a step's per-particle kernels run as one launch (k_particle_chain; env PHD_CHAIN_MAX)
 	bool        chain_ok[3] = {false, false, false};   // ... where the bodies' LDS arrays fit one workgroup (per measurement-block count 1, 2, 4)
 	hipStream_t aux[MAXSPLIT - 1] = {nullptr, nullptr, nullptr};   // streams of the sub-ranges after the first
+	// Option (environment PHD_DEFER_BIG=1; off by default): the particles with an association cluster of more than
+	// ALPHA_DEFER_ROWS rows are listed by k_alpha_assoc_main and their ordered replay runs inside the launch of the densities
+	// (the first workgroups of k_alpha_density_big), k_normalise_resample / k_push_weights finish alpha. Built when the replay
+	// was what config S's association kernel waited for (5 % of the particles, 15 times the median workgroup's lifetime); since
+	// the clusters of up to 5 rows are no longer replayed one by one (phd_alpha.h, apply_small) the replay is short and the
+	// option costs more than it hides (config S 3.80 against 3.62 ms: the fused launch needs the association's LDS, three
+	// workgroups per CU for the densities instead of four). Kept for scenes whose clusters are large; bit-identical results.
+	int         defer_big = 0;
+	int         nbig = 256;            // workgroups of k_alpha_density_big that work the list off (environment PHD_NBIG)
+	int         last_defer = 0;        // the last launch_map left alpha open (k_normalise_resample / k_push_weights / k_alpha_combine finish it)
+	int*        d_biglist = nullptr;   // [MAXSPLIT][Pcap + 2]
+	double*     d_ratio = nullptr;     // [Pcap]
 	hipEvent_t  ev_fork = nullptr, ev_join[MAXSPLIT - 1] = {nullptr, nullptr, nullptr};
 	bool sel_host_valid = false;       // h_sel mirrors the device-side bank roles without a round trip
 	int Pcap = 0, cap = 0, Mcap = 0, ecap = 0, Jcap = 0, cutcap = 0;
@@ -227,7 +239,7 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.bigws = nav->d_bigws; b.bigws_bytes = nav->bigws_bytes; b.bigws_used = nav->d_bigws_used;
 	b.cand_count = nav->d_cand_count; b.denom = nav->d_denom;
 	b.cand = nav->d_cand; b.candcap = nav->candcap;
-	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account; b.srec = nav->d_srec; b.outw = nav->d_outw; b.wcopy = nav->d_wcopy; b.cover = nav->d_cover; b.stamps = nav->d_stamps; b.all_pairs = nav->all_pairs ? 1 : 0; b.stamp_kernel = getenv("PHD_STAMP_KERNEL") ? atoi(getenv("PHD_STAMP_KERNEL")) : 2;
+	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account; b.srec = nav->d_srec; b.outw = nav->d_outw; b.wcopy = nav->d_wcopy; b.cover = nav->d_cover; b.stamps = nav->d_stamps; b.biglist = nav->d_biglist; b.bigstride = nav->Pcap + 2; b.ratio = nav->d_ratio; b.defer = 0; b.all_pairs = nav->all_pairs ? 1 : 0; b.stamp_kernel = getenv("PHD_STAMP_KERNEL") ? atoi(getenv("PHD_STAMP_KERNEL")) : 2;
 	return b;
 }
 
@@ -299,6 +311,7 @@ const char* T_EF = "k_emit_finish";
 const char* T_PM = "k_prune_merge";
 const char* T_WA = "k_alpha_assoc";
 const char* T_WD = "k_alpha_density";
+const char* T_WC = "k_alpha_combine";
 const char* T_NR = "k_normalise_resample";
 const char* T_GR = "k_finish_sharded";
 const char* T_PL = "k_plan_migration";
@@ -327,14 +340,20 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha)
 		else hipLaunchKernelGGL(k_particle_chain<ZB>, dim3(P), dim3(256), (size_t) chain_lds_bytes<ZB>(nav->cutcap), nav->stream, nav->dp, b0, nav->cutcap, with_alpha ? 1 : 0);
 		timer_end(nav, T_CH);
 		HC(hipGetLastError());
+		nav->last_defer = 0;
 		return PHD_OK;
 	}
 	if (S > 1) {
 		HC(hipEventRecord(nav->ev_fork, nav->stream));
 		for (int s = 1; s < S; s++) HC(hipStreamWaitEvent(nav->aux[s - 1], nav->ev_fork, 0));
 	}
+	const bool defer = with_alpha && nav->defer_big != 0;
+	nav->last_defer = defer ? 1 : 0;
+	const size_t ldb = std::max((size_t) lay.bytes, (size_t) DENS_LDS_DOUBLES * 8);   // k_alpha_density_big: the larger of the two bodies' pools
 	for (int s = 0; s < S; s++) {
 		StepBufs b = b0;
+		b.defer = defer ? 1 : 0;
+		b.biglist = nav->d_biglist + (size_t) s * b0.bigstride;
 		b.p0 = (int) ((long long) P * s / S);
 		const int n = (int) ((long long) P * (s + 1) / S) - b.p0;
 		if (n <= 0) continue;
@@ -349,11 +368,21 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha)
 		timer_begin(nav, T_PM, st, true);
 		hipLaunchKernelGGL(k_prune_merge, dim3(n), dim3(256), lp, st, nav->dp, b, nav->cutcap);
 		timer_end(nav, T_PM, st);
-		if (with_alpha) {
+		if (with_alpha && defer) {
+			timer_begin(nav, T_WA, st, true);
+			hipLaunchKernelGGL(k_alpha_assoc_main<ZB>, dim3(n), dim3(256), lay.bytes, st, nav->dp, b, nav->cutcap);
+			timer_end(nav, T_WA, st);
+			// the particles it listed are worked off by the first workgroups of the densities' launch
+			const int nbig = std::max(1, std::min(nav->nbig, n));
+			timer_begin(nav, T_WD, st, true);
+			hipLaunchKernelGGL(k_alpha_density_big<ZB>, dim3(n + nbig), dim3(256), ldb, st, nav->dp, b, nav->cutcap, nbig);
+			timer_end(nav, T_WD, st);
+		}
+		else if (with_alpha) {
 			timer_begin(nav, T_WA, st, true);
 			hipLaunchKernelGGL(k_alpha_assoc<ZB>, dim3(n), dim3(256), lay.bytes, st, nav->dp, b, nav->cutcap);
 			timer_end(nav, T_WA, st);
-				timer_begin(nav, T_WD, st, true);
+			timer_begin(nav, T_WD, st, true);
 			hipLaunchKernelGGL(k_alpha_density, dim3(n), dim3(256), 0, st, nav->dp, b);
 			timer_end(nav, T_WD, st);
 		}
@@ -633,6 +662,8 @@ phd_navigator* phd_create(const phd_params* params, int device)
 		ok = ok && hipEventCreateWithFlags(&nav->ev_join[i], hipEventDisableTiming) == hipSuccess;
 	}
 	ok = ok && hipEventCreateWithFlags(&nav->ev_fork, hipEventDisableTiming) == hipSuccess;
+	if (const char* e = getenv("PHD_DEFER_BIG")) nav->defer_big = atoi(e) != 0;
+	if (const char* e = getenv("PHD_NBIG")) nav->nbig = std::max(1, atoi(e));
 	if (const char* e = getenv("PHD_SPLIT")) nav->nsplit = std::max(0, atoi(e));
 	if (const char* e = getenv("PHD_CHAIN_MAX")) nav->chain_max = std::max(0, atoi(e));
 	size_t plane = (size_t) nav->Pcap * nav->cap;
@@ -674,6 +705,8 @@ phd_navigator* phd_create(const phd_params* params, int device)
 #endif
 	ok = ok && dalloc((void**) &nav->d_srec, (size_t) nav->Pcap * PRUNE_ROW * nav->cutcap * 8);
 	ok = ok && dalloc((void**) &nav->d_outw, plane * 8);
+	ok = ok && dalloc((void**) &nav->d_biglist, (size_t) phd_navigator::MAXSPLIT * (nav->Pcap + 2) * 4) && dalloc((void**) &nav->d_ratio, (size_t) nav->Pcap * 8);
+	if (ok) hipMemset(nav->d_biglist, 0, (size_t) phd_navigator::MAXSPLIT * (nav->Pcap + 2) * 4);
 	ok = ok && dalloc((void**) &nav->d_wcopy, (size_t) nav->Pcap * (nav->cap + nav->Mcap) * 8) && dalloc((void**) &nav->d_cover, (size_t) nav->Pcap * nav->cap * 4);
 	ok = ok && dalloc((void**) &nav->d_alm, (size_t) nav->Pcap * 3 * nav->Jcap * 8);
 	ok = ok && dalloc((void**) &nav->d_aJ, (size_t) nav->Pcap * 4) && dalloc((void**) &nav->d_account, (size_t) nav->Pcap * 8);
@@ -698,18 +731,24 @@ phd_navigator* phd_create(const phd_params* params, int device)
 		const int la[3] = {alpha_lds(64, nav->cutcap).bytes, alpha_lds(128, nav->cutcap).bytes, alpha_lds(256, nav->cutcap).bytes};
 		if (la[0] > lim.alpha[0]) {
 			ok = ok && hipFuncSetAttribute((const void*) k_alpha_assoc<1>, hipFuncAttributeMaxDynamicSharedMemorySize, la[0]) == hipSuccess;
+			ok = ok && hipFuncSetAttribute((const void*) k_alpha_assoc_main<1>, hipFuncAttributeMaxDynamicSharedMemorySize, la[0]) == hipSuccess;
+			ok = ok && hipFuncSetAttribute((const void*) k_alpha_density_big<1>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(la[0], (int) (DENS_LDS_DOUBLES * 8))) == hipSuccess;
 			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll<1>, hipFuncAttributeMaxDynamicSharedMemorySize, la[0]) == hipSuccess;
 			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll_grad<1>, hipFuncAttributeMaxDynamicSharedMemorySize, la[0]) == hipSuccess;
 			lim.alpha[0] = la[0];
 		}
 		if (la[1] > lim.alpha[1]) {
 			ok = ok && hipFuncSetAttribute((const void*) k_alpha_assoc<2>, hipFuncAttributeMaxDynamicSharedMemorySize, la[1]) == hipSuccess;
+			ok = ok && hipFuncSetAttribute((const void*) k_alpha_assoc_main<2>, hipFuncAttributeMaxDynamicSharedMemorySize, la[1]) == hipSuccess;
+			ok = ok && hipFuncSetAttribute((const void*) k_alpha_density_big<2>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(la[1], (int) (DENS_LDS_DOUBLES * 8))) == hipSuccess;
 			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll<2>, hipFuncAttributeMaxDynamicSharedMemorySize, la[1]) == hipSuccess;
 			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll_grad<2>, hipFuncAttributeMaxDynamicSharedMemorySize, la[1]) == hipSuccess;
 			lim.alpha[1] = la[1];
 		}
 		if (la[2] > lim.alpha[2]) {
 			ok = ok && hipFuncSetAttribute((const void*) k_alpha_assoc<4>, hipFuncAttributeMaxDynamicSharedMemorySize, la[2]) == hipSuccess;
+			ok = ok && hipFuncSetAttribute((const void*) k_alpha_assoc_main<4>, hipFuncAttributeMaxDynamicSharedMemorySize, la[2]) == hipSuccess;
+			ok = ok && hipFuncSetAttribute((const void*) k_alpha_density_big<4>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(la[2], (int) (DENS_LDS_DOUBLES * 8))) == hipSuccess;
 			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll<4>, hipFuncAttributeMaxDynamicSharedMemorySize, la[2]) == hipSuccess;
 			ok = ok && hipFuncSetAttribute((const void*) k_quasi_setll_grad<4>, hipFuncAttributeMaxDynamicSharedMemorySize, la[2]) == hipSuccess;
 			lim.alpha[2] = la[2];
@@ -793,6 +832,7 @@ void phd_destroy(phd_navigator* nav)
 		if (nav->ev_join[i]) hipEventDestroy(nav->ev_join[i]);
 	}
 	if (nav->ev_fork) hipEventDestroy(nav->ev_fork);
+	hipFree(nav->d_biglist); hipFree(nav->d_ratio);
 	delete nav;
 }
 
@@ -1201,6 +1241,7 @@ int phd_step_async(phd_navigator* nav, uint8_t onlymapping, double u_resample)
 	StepBufs b = make_bufs(nav);
 	int rc = launch_map(nav, b, !onlymapping);
 	if (rc) return rc;
+	b.defer = nav->last_defer;
 	timer_begin(nav, T_NR);
 	nav->d_res_slots = nav->d_src;
 	// the same launch hands the resampled particles their small arrays and rotates the bank roles (rotate_roles)
@@ -1323,9 +1364,14 @@ int phd_stage_run(phd_navigator* nav, const double* z3, int nmeasurements, uint8
 	HC(hipMemsetAsync(nav->d_bigws_used, 0, 8, nav->stream));
 	rc = launch_map(nav, b, with_alpha != 0);
 	if (rc) return rc;
+	if (nav->last_defer) {   // (no k_normalise_resample follows a stage run: alpha is finished here)
+		b.defer = 1;
+		hipLaunchKernelGGL(k_alpha_combine, dim3((nav->P + 255) / 256), dim3(256), 0, nav->stream, b);
+	}
 	hipLaunchKernelGGL(k_expand_emit, dim3(nav->P), dim3(256), 0, nav->stream, nav->dp, b);   // PHD_STAGE_CORRECTED reads whole records
 	HC(hipGetLastError());
 	HC(hipMemsetAsync(nav->d_bigws_used, 0, 8, nav->stream));   // (as behind a quasi batch: no k_normalise_resample follows a stage run)
+	for (int s_ = 0; s_ < phd_navigator::MAXSPLIT; s_++) HC(hipMemsetAsync(nav->d_biglist + (size_t) s_ * (nav->Pcap + 2), 0, 4, nav->stream));
 	rc = sync_state(nav);
 	if (rc) return rc;
 	nav->stage_valid = true;
@@ -1642,6 +1688,7 @@ static int step_local(phd_navigator* nav, uint8_t onlymapping)
 	StepBufs b = make_bufs(nav);
 	rc = launch_map(nav, b, !onlymapping);
 	if (rc) return rc;
+	b.defer = nav->last_defer;
 	timer_begin(nav, T_PW);
 	// (per-rank host: the export buffer holds P + 1 doubles, the step's status word behind the weights)
 	hipLaunchKernelGGL(k_push_weights, dim3((nav->P + 255) / 256), dim3(256), 0, nav->stream, b, (double* const*) nav->d_dst_tab, nav->ndst,

@@ -326,3 +326,32 @@ def test_device_path_a_flag_on_one_rank_drops_the_step_on_all(nav_mod):
     _device_path_step(navs, Pl, 0.4)
     for nv in navs:
         nv.close()
+
+
+def test_deferred_replay_of_big_clusters_is_the_same_step(nav_mod, monkeypatch):
+    """PHD_DEFER_BIG=1 (read when a handle is created): the particles whose association has a cluster of more than ten rows
+    are listed, their ordered replay runs inside the launch of the densities, alpha is finished by the resampling kernel —
+    weights, sources and maps bit for bit those of the default path, on a frame with clusters of more than ten rows."""
+    from test_gpu_parity import clustered_frame
+    from test_gpu_round2 import make_nav
+    f = clustered_frame(91, 3, 8, 7, spread_px=4.0)        # three groups of 8 landmarks and 7 measurements a few pixels apart: clusters of up to 15 rows
+    results = []
+    for defer in ("0", "1"):
+        monkeypatch.setenv("PHD_DEFER_BIG", defer)
+        monkeypatch.setenv("PHD_CHAIN_MAX", "0")      # (the separate kernels, not the one-launch chain of small particle sets)
+        nav, p = make_nav(nav_mod, f, merge_threshold=1e-3, emit_capacity=12000)
+        out = []
+        for u in (0.3, 0.8):
+            nav.SlamUpdate(None, f.z, u_resample=u)
+            out.append((nav.VehicleWeights, nav.resample_sources(), nav.BestParticle, [nav.MapModel(i) for i in (0, f.P - 1)]))
+        nav.run_stages(f.z, with_alpha=True)
+        out.append((nav.WeightAlpha(), nav.SetLogLikelihood()))
+        results.append(out)
+        nav.close()
+    a, b = results
+    for (wa, sa, ba, ma), (wb, sb, bb, mb) in zip(a[:2], b[:2]):
+        assert np.array_equal(wa, wb) and sa[1] == sb[1] and np.array_equal(sa[0], sb[0]) and ba == bb
+        for x, y in zip(ma, mb):
+            assert all(np.array_equal(u, v) for u, v in zip(x, y))
+    assert np.array_equal(a[2][0], b[2][0]) and np.array_equal(a[2][1], b[2][1])
+    assert np.all(np.isfinite(a[2][1]))
