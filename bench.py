@@ -25,7 +25,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_SUSTAINED_TFLOPS = 53.0   # v_fma_f64 over the whole chip, measured (profiles/r01_mfma_f64_probe.txt)
+FP64_SUSTAINED_TFLOPS = 59.6   # v_fma_f64 over the whole chip at four waves per SIMD, the occupancy of the dense kernels: measured with the
+                               # in-kernel clock beside it (2.14 GHz under that loop; scripts/probes/fp64_clock.hip, profiles/r04_fp64_clock.txt;
+                               # 62.3 at eight waves per SIMD; round 1's 53 came from a colder, shorter run)
 FP64_SPEC_TFLOPS = 78.6        # the datasheet FP64 vector rate (4 cycles per wave instruction, 1024 SIMDs, 2.4 GHz)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 # SURVEY §8d's protocol is ">= 20 warm + >= 100 timed steps": the first ~20 steps behind the creation of a handle run about
@@ -199,6 +201,7 @@ def cpu_baseline(frame, params, sample, threads):
         stages += stt
     steps = len(times)
     med = float(np.median(times))
+    p10, p90 = float(np.percentile(times, 10)), float(np.percentile(times, 90))
     # the same step on 1 thread and on 8 (the reference's Parallel.For runs on NParallel = 8 threads, Config.cs:46), on
     # proportionally smaller particle samples (about a second each)
     by_threads = {}
@@ -211,8 +214,15 @@ def cpu_baseline(frame, params, sample, threads):
         orc.slam_update(params, st, frame.z, u=0.5, threads=t)
         by_threads[str(t)] = n * frame.C * frame.M / (time.perf_counter() - t0)
     by_threads[str(threads)] = P * frame.C * frame.M / med
+    import shutil
+    runtimes = {name: shutil.which(name) for name in ("mono", "dotnet", "mcs", "csc", "msbuild", "xbuild")}
     return {"value": P * frame.C * frame.M / med, "unit": "PHD updates/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port",
             "by_threads": by_threads, "steps": steps, "statistic": "median step time", "mean_value": steps * P * frame.C * frame.M / elapsed,
+            "step_ms": {"median": med * 1e3, "p10": p10 * 1e3, "p90": p90 * 1e3},
+            "value_p10_p90": [P * frame.C * frame.M / p90, P * frame.C * frame.M / p10],
+            # SURVEY 8d / BASELINE.md 2.2: the reference's own C# path can only be timed where a C# runtime exists
+            "csharp_runtime": ("absent (no mono / dotnet / mcs / csc / msbuild / xbuild on this box's PATH): the reference's mono-rfs.exe cannot be run here"
+                               if not any(runtimes.values()) else {k: v for k, v in runtimes.items() if v}),
             "sample": "%d steps of %d of the %d particles (C=%d, M=%d), oracle/phd_oracle.cpp with OpenMP over particles on %d threads, %.1f s; "
                       "a restatement of the C# algorithm in C++, not the C# runtime"
                       % (steps, P, frame.P, frame.C, frame.M, threads, elapsed),
@@ -585,6 +595,11 @@ def main():
                "unit": "PHD updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preroll_steps": PREROLL_STEPS,
                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f64", "data": "synthetic",
+               "frame_to_quote": ("`value` is measured on SURVEY 8d's LITERAL frame ('survey': every prior weight U(0.05, 1.2)): quote it as the metric of record, "
+                                  "knowing what that frame is — the map's expected size is five times the measurements, every WeightAlpha underflows, all "
+                                  "particle weights end at 0 (PHDNavigator.cs:344's guard) and the step never resamples. other_modes.weights_steady is the same "
+                                  "configuration on a map consistent with the frame (finite weights, depletion, resampling and the particle copy in EVERY step): "
+                                  "quote that one for what a converged filter does per frame."),
                "config": {"workload": "RB-PHD-SLAM SlamUpdate, BASELINE config %s: %d particles/GPU x %d components x %d measurements, "
                                       "PRM3D pixel-range model, prior weights '%s', state resident in HBM"
                                       % (args.config, P, Cc, M, args.weights),
@@ -606,7 +621,7 @@ def main():
             alg_bytes = 160.0 * particles_per_launch * Cc   # 80 B/component read + 80 B written, per particle
             achieved = alg_bytes / (src[dom] * 1e-3) / 1e9
             traffic = None
-            for tname in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+            for tname in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
                 tfile = os.path.join(ROOT, "profiles", tname)
                 if os.path.exists(tfile):
                     try:
@@ -634,8 +649,8 @@ def main():
             out["kernel_ms_sampling"] = "HIP events on every %d-th step of the timed region (%d of %d steps)" % (max(1, min(args.events_every, 255)), timed_steps, args.steps)
             # The step is bound by vector-ALU issue, not by HBM: the wave-level VALU instructions of one
             # step (SQ_INSTS_VALU of the committed profile, per particle) against the rate at which the chip sustains
-            # FP64 FMAs (scripts/probes/mfma_f64_rate.hip: 53 TFLOP/s = 4.14e11 wave instructions/s).
-            for vname in ("r03_valu_insts.json", "r02_valu_insts.json", "r01_valu_insts.json"):
+            # FP64 FMAs (scripts/probes/fp64_clock.hip: 59.6 TFLOP/s = 4.66e11 wave instructions/s at four waves per SIMD).
+            for vname in ("r04_valu_insts.json", "r03_valu_insts.json", "r02_valu_insts.json", "r01_valu_insts.json"):
                 vfile = os.path.join(ROOT, "profiles", vname)
                 if not os.path.exists(vfile):
                     continue
@@ -650,7 +665,9 @@ def main():
                                              "spec_wave_instructions_per_s": spec, "bound_ms_at_spec": insts / spec * 1e3, "frac_at_spec": insts / spec * 1e3 / ms,
                                              "flop_model": {"flop_per_update": 60, "tflops_delivered": 60.0 * P * Cc * M / (ms * 1e-3) / 1e12,
                                                             "frac_of_fp64_vector_peak": 60.0 * P * Cc * M / (ms * 1e-3) / 1e12 / FP64_SPEC_TFLOPS},
-                                             "source": "profiles/%s (rocprofv3 SQ_INSTS_VALU), profiles/r01_mfma_f64_probe.txt" % vname}
+                                             "in_kernel_clock_mhz": {"k_sweep": 2375, "v_fma_f64 loop at 4 waves per SIMD": 2144,
+                                                                     "source": "profiles/r04_sweep_clock.txt, profiles/r04_fp64_clock.txt (s_memtime / s_memrealtime)"},
+                                             "source": "profiles/%s (rocprofv3 SQ_INSTS_VALU), profiles/r04_fp64_clock.txt" % vname}
                         break
                 except Exception:
                     pass

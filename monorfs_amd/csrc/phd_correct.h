@@ -30,15 +30,13 @@ __device__ __forceinline__ void load_predicted(const DevParams& prm, const StepB
 
 // =================================================================================================
 #define EMIT_LIST 512   // four per-wave lists of 128 pairs waiting for the Kalman path
-#define EMIT_LDS_DOUBLES (EXPTAB_N + 256 + (EMIT_LIST + 4) / 2 + 4 * 256)   // etab, ldenom[256] | ints: list[4][128], npair | denominators, measurements [256][3]
+#define EMIT_LDS_DOUBLES (EXPTAB_N + 256 + (EMIT_LIST + 4) / 2)   // etab, ldenom[256] | ints: list[4][128], npair
 __device__ __forceinline__ void emit_finish_body(const DevParams& prm, const StepBufs& a, double* pool)
 {
 	double* const etab = pool;
 	double* const ldenom = pool + EXPTAB_N;
 	int* const list = (int*) (pool + EXPTAB_N + 256);
 	int& s_npair = list[EMIT_LIST];
-	double* const sdenom = pool + EXPTAB_N + 256 + (EMIT_LIST + 4) / 2;   // [256] kappa + weightsum[z] (a trip to memory per pair otherwise)
-	double* const sz = sdenom + 256;                                      // [256][3] the measurements
 	const int p = a.p0 + blockIdx.x, tid = threadIdx.x;
 	const int M = a.M;
 	const MixView vin = bank_view(a, SEL_IN);
@@ -67,10 +65,10 @@ __device__ __forceinline__ void emit_finish_body(const DevParams& prm, const Ste
 		load_predicted(prm, a, vin, p, n, c, w, m, P);
 		CompMeas q;
 		comp_measure(prm, pose, rq, m, P, q);
-		const double n0 = sz[k * 3] - q.zh[0], n1 = sz[k * 3 + 1] - q.zh[1], n2 = sz[k * 3 + 2] - q.zh[2];
+		const double n0 = a.z[k * 3] - q.zh[0], n1 = a.z[k * 3 + 1] - q.zh[1], n2 = a.z[k * 3 + 2] - q.zh[2];
 		const double d2  = quad_gen(q.Sinv, n0, n1, n2);
 		const double qz  = q.qmult * exp_neg(-0.5 * d2, etab);   // mc.Evaluate(z)
-		const double wgt = (q.pd * w) * qz / sdenom[k];          // :899
+		const double wgt = (q.pd * w) * qz / denom[k];           // :899
 		if (wgt < prm.minw) return;
 		const int slot = nmis + atomicAdd(&s_npair, 1);
 		if (slot >= a.ecap) return;
@@ -84,10 +82,6 @@ __device__ __forceinline__ void emit_finish_body(const DevParams& prm, const Ste
 		a.emit_idx[e] = np + k * np + c;   // position in the reference's `corrected` list: after the np copies, z-major
 		store_comp(a.emit_rec + e * MIX_REC, wgt, mn, Pn);   // the update as a component record, as the banks hold them
 	};
-	for (int k = tid; k < M; k += 256) {
-		sdenom[k] = denom[k];
-		sz[k * 3] = a.z[k * 3]; sz[k * 3 + 1] = a.z[k * 3 + 1]; sz[k * 3 + 2] = a.z[k * 3 + 2];
-	}
 	if (!overflow) {
 		// Most queued pairs fail once the real denominator is known. Their exponent x = log(PD w q) travels with
 		// them as a float32: x - log(denom) < log(MinWeight) by more than the float32 rounding settles it; the
@@ -96,29 +90,20 @@ __device__ __forceinline__ void emit_finish_body(const DevParams& prm, const Ste
 		const int wv = tid >> 6, lane = tid & 63;
 		int* const wlist = list + wv * 128;   // up to 63 waiting + 64 new entries
 		for (int k = tid; k < M; k += 256) ldenom[k] = log(denom[k]);
-		__syncthreads();   // (also: sdenom and sz are complete)
+		__syncthreads();
 		const double lminw = log(prm.minw);
 		const int ncw = (wv == 0) ? nc0 : ((wv == 1) ? nc1 : ((wv == 2) ? nc2 : nc3));
 		const int2* seg = cands + (size_t) wv * segcap;
 		int nl = 0;   // wave-uniform: entries waiting in the list
-		// (the queue is read four groups of 64 entries ahead, without a branch between the four loads: a group's load issued
-		// behind the stores of the Kalman path would wait for their acknowledgements as well, and behind a divergent branch
-		// for everything outstanding — one dependent trip to memory per group, a dozen per wave)
-		int2 ahead[4];
 		for (int j0 = 0; j0 < ncw; j0 += 64) {
-			const int u4 = (j0 >> 6) & 3;
-			if (u4 == 0) {
-#pragma unroll
-				for (int u = 0; u < 4; u++) ahead[u] = seg[min(j0 + 64 * u + lane, max(ncw - 1, 0))];
-			}
 			const int j = j0 + lane;
 			bool keep = false;
 			int  code = 0;
-			{
-				const int2 cd = (u4 == 0) ? ahead[0] : ((u4 == 1) ? ahead[1] : ((u4 == 2) ? ahead[2] : ahead[3]));
+			if (j < ncw) {
+				const int2 cd = seg[j];
 				code = cd.x;
 				const double x = (double) __int_as_float(cd.y);
-				keep = j < ncw && !(x - ldenom[code & 255] < lminw - 1e-3 - 1e-6 * fabs(x));
+				keep = !(x - ldenom[code & 255] < lminw - 1e-3 - 1e-6 * fabs(x));
 			}
 			const unsigned long long bal = ballot64(keep);
 			if (keep) wlist[nl + __popcll(bal & lanemask_lt())] = code;
@@ -144,7 +129,6 @@ __device__ __forceinline__ void emit_finish_body(const DevParams& prm, const Ste
 	}
 	else {
 		// a segment of the queue overflowed (more than a quarter of a wave's pairs are candidates): every pair, gate included
-		__syncthreads();   // (sdenom and sz are complete)
 		for (int j = tid; j < np * M; j += 256) {
 			const int c = j / M, k = j - c * M;
 			double w, m[3], P[6], x[3];

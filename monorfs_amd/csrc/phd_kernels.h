@@ -220,6 +220,21 @@ __global__ __launch_bounds__(256, 1) void k_particle_chain(const DevParams prm, 
 	PHD_STAMP_FLUSH(5, 6);   // (diagnostic build, PHD_STAMP_KERNEL=5: the bodies' shares of the chain)
 }
 
+// k_sweep, k_emit_finish and k_prune_merge as ONE launch on a full machine (environment PHD_FUSE_SEP=1): the first three bodies
+// of the chain above at k_sweep's own register budget (four workgroups per CU), k_alpha_assoc and k_alpha_density behind it as
+// launches of their own (compiled into one kernel with the others they cost occupancy: 245 registers). The workgroups of a CU
+// drift apart — some in the dense pair loops, some in the latency-bound prune — and two launch boundaries go.
+template <int ZB, bool HALF = false>
+__global__ __launch_bounds__(256, 4) void k_sweep_emit_prune(const DevParams prm, const StepBufs a, int cutcap)
+{
+	extern __shared__ __align__(16) double smem[];
+	sweep_body<ZB, HALF>(prm, a, smem);
+	__syncthreads();
+	emit_finish_body(prm, a, smem);
+	__syncthreads();
+	prune_merge_body(prm, a, cutcap, smem);
+}
+
 // Test surface (phd_stage_map, PHD_STAGE_CORRECTED): the emitted list carries no mean / covariance for the misdetection
 // copies (k_sweep writes their weight and index only); this fills them in from the predicted components.
 __global__ __launch_bounds__(256) void k_expand_emit(const DevParams prm, const StepBufs a)

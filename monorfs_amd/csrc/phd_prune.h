@@ -1163,3 +1163,14 @@ __global__ __launch_bounds__(256, PHD_PRUNE_WAVES) void k_prune_merge(const DevP
 	extern __shared__ __align__(16) double smem[];
 	prune_merge_body(prm, a, cutcap, smem);
 }
+
+// k_emit_finish and k_prune_merge as ONE launch (environment PHD_FUSE_EP=1): a particle's corrected list goes from the one
+// body to the other behind a workgroup barrier, the launch boundary between two latency-bound kernels — a tail in which the
+// machine drains and a ramp in which it fills — is paid once. Registers: the Kalman path compiled at this kernel's 128.
+__global__ __launch_bounds__(256, PHD_PRUNE_WAVES) void k_emit_prune(const DevParams prm, const StepBufs a, int cutcap)
+{
+	extern __shared__ __align__(16) double smem[];
+	emit_finish_body(prm, a, smem);
+	__syncthreads();   // (workgroup scope: what this workgroup's waves stored is visible to its loads behind the barrier)
+	prune_merge_body(prm, a, cutcap, smem);
+}

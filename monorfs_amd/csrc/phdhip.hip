@@ -56,6 +56,10 @@ struct phd_navigator {
 	// workgroups per CU for the densities instead of four). Kept for scenes whose clusters are large; bit-identical results.
 	int         defer_big = 0;
 	int         nbig = 256;            // workgroups of k_alpha_density_big that work the list off (environment PHD_NBIG)
+	int         fuse_ep = -1;          // k_emit_finish and k_prune_merge as one launch (k_emit_prune): -1 = for frames of up to 64 measurements (measured on
+	                                   // two streams: config B 0.677 -> 0.667 ms survey, 0.634 -> 0.615 steady; config S, 128 measurements, 3.67 -> 3.85:
+	                                   // its Kalman path is long and pays for the 128 registers); environment PHD_FUSE_EP = 0 / 1 forces
+	int         fuse_sep = 0;          // environment PHD_FUSE_SEP=1: k_sweep, k_emit_finish and k_prune_merge as one launch
 	int         last_defer = 0;        // the last launch_map left alpha open (k_normalise_resample / k_push_weights / k_alpha_combine finish it)
 	int*        d_biglist = nullptr;   // [MAXSPLIT][Pcap + 2]
 	double*     d_ratio = nullptr;     // [Pcap]
@@ -309,6 +313,8 @@ void timer_end(phd_navigator* nav, const char* name, hipStream_t st = nullptr)
 const char* T_SW = "k_sweep";
 const char* T_EF = "k_emit_finish";
 const char* T_PM = "k_prune_merge";
+const char* T_EP = "k_emit_prune";
+const char* T_SEP = "k_sweep_emit_prune";
 const char* T_WA = "k_alpha_assoc";
 const char* T_WD = "k_alpha_density";
 const char* T_WC = "k_alpha_combine";
@@ -358,16 +364,32 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha)
 		const int n = (int) ((long long) P * (s + 1) / S) - b.p0;
 		if (n <= 0) continue;
 		hipStream_t st = s == 0 ? nav->stream : nav->aux[s - 1];
+		if (nav->fuse_sep) {
+			const size_t ld3 = std::max(std::max(lp, (size_t) EMIT_LDS_DOUBLES * 8), (size_t) SweepLds<ZB>::doubles * 8);
+			timer_begin(nav, T_SEP, st);
+			if (ZB == 1 && nav->M <= 32) hipLaunchKernelGGL((k_sweep_emit_prune<1, true>), dim3(n), dim3(256), ld3, st, nav->dp, b, nav->cutcap);
+			else hipLaunchKernelGGL(k_sweep_emit_prune<ZB>, dim3(n), dim3(256), ld3, st, nav->dp, b, nav->cutcap);
+			timer_end(nav, T_SEP, st);
+		}
+		else {
 		timer_begin(nav, T_SW, st);
 		if (ZB == 1 && nav->M <= 32) hipLaunchKernelGGL((k_sweep<1, true>), dim3(n), dim3(256), 0, st, nav->dp, b);
 		else hipLaunchKernelGGL(k_sweep<ZB>, dim3(n), dim3(256), 0, st, nav->dp, b);
 		timer_end(nav, T_SW, st);
-		timer_begin(nav, T_EF, st, true);
-		hipLaunchKernelGGL(k_emit_finish, dim3(n), dim3(256), 0, st, nav->dp, b);
-		timer_end(nav, T_EF, st);
-		timer_begin(nav, T_PM, st, true);
-		hipLaunchKernelGGL(k_prune_merge, dim3(n), dim3(256), lp, st, nav->dp, b, nav->cutcap);
-		timer_end(nav, T_PM, st);
+		if (nav->fuse_ep < 0 ? ZB == 1 : nav->fuse_ep != 0) {
+			timer_begin(nav, T_EP, st, true);
+			hipLaunchKernelGGL(k_emit_prune, dim3(n), dim3(256), std::max(lp, (size_t) EMIT_LDS_DOUBLES * 8), st, nav->dp, b, nav->cutcap);
+			timer_end(nav, T_EP, st);
+		}
+		else {
+			timer_begin(nav, T_EF, st, true);
+			hipLaunchKernelGGL(k_emit_finish, dim3(n), dim3(256), 0, st, nav->dp, b);
+			timer_end(nav, T_EF, st);
+			timer_begin(nav, T_PM, st, true);
+			hipLaunchKernelGGL(k_prune_merge, dim3(n), dim3(256), lp, st, nav->dp, b, nav->cutcap);
+			timer_end(nav, T_PM, st);
+		}
+		}
 		if (with_alpha && defer) {
 			timer_begin(nav, T_WA, st, true);
 			hipLaunchKernelGGL(k_alpha_assoc_main<ZB>, dim3(n), dim3(256), lay.bytes, st, nav->dp, b, nav->cutcap);
@@ -663,6 +685,8 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	}
 	ok = ok && hipEventCreateWithFlags(&nav->ev_fork, hipEventDisableTiming) == hipSuccess;
 	if (const char* e = getenv("PHD_DEFER_BIG")) nav->defer_big = atoi(e) != 0;
+	if (const char* e = getenv("PHD_FUSE_EP")) nav->fuse_ep = atoi(e) != 0 ? 1 : 0;
+	if (const char* e = getenv("PHD_FUSE_SEP")) nav->fuse_sep = atoi(e) != 0 ? 1 : 0;
 	if (const char* e = getenv("PHD_NBIG")) nav->nbig = std::max(1, atoi(e));
 	if (const char* e = getenv("PHD_SPLIT")) nav->nsplit = std::max(0, atoi(e));
 	if (const char* e = getenv("PHD_CHAIN_MAX")) nav->chain_max = std::max(0, atoi(e));
@@ -727,7 +751,16 @@ phd_navigator* phd_create(const phd_params* params, int device)
 		std::lock_guard<std::mutex> limits_guard(limits_mu);
 		DevLimits& lim = limits[device];
 		const int lp = prune_lds(nav->cutcap).bytes;
-		if (lp > lim.prune) { ok = ok && hipFuncSetAttribute((const void*) k_prune_merge, hipFuncAttributeMaxDynamicSharedMemorySize, lp) == hipSuccess; lim.prune = lp; }
+		if (lp > lim.prune) {
+			ok = ok && hipFuncSetAttribute((const void*) k_prune_merge, hipFuncAttributeMaxDynamicSharedMemorySize, lp) == hipSuccess;
+			ok = ok && hipFuncSetAttribute((const void*) k_emit_prune, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lp, (int) (EMIT_LDS_DOUBLES * 8))) == hipSuccess;
+			const int l3[3] = {std::max(lp, (int) (SweepLds<1>::doubles * 8)), std::max(lp, (int) (SweepLds<2>::doubles * 8)), std::max(lp, (int) (SweepLds<4>::doubles * 8))};
+			ok = ok && hipFuncSetAttribute((const void*) k_sweep_emit_prune<1>, hipFuncAttributeMaxDynamicSharedMemorySize, l3[0]) == hipSuccess;
+			ok = ok && hipFuncSetAttribute((const void*) k_sweep_emit_prune<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l3[0]) == hipSuccess;
+			ok = ok && hipFuncSetAttribute((const void*) k_sweep_emit_prune<2>, hipFuncAttributeMaxDynamicSharedMemorySize, l3[1]) == hipSuccess;
+			ok = ok && hipFuncSetAttribute((const void*) k_sweep_emit_prune<4>, hipFuncAttributeMaxDynamicSharedMemorySize, l3[2]) == hipSuccess;
+			lim.prune = lp;
+		}
 		const int la[3] = {alpha_lds(64, nav->cutcap).bytes, alpha_lds(128, nav->cutcap).bytes, alpha_lds(256, nav->cutcap).bytes};
 		if (la[0] > lim.alpha[0]) {
 			ok = ok && hipFuncSetAttribute((const void*) k_alpha_assoc<1>, hipFuncAttributeMaxDynamicSharedMemorySize, la[0]) == hipSuccess;
