@@ -287,6 +287,45 @@ def main():
         nav._check(lib.phd_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream), 1))
         Pg = P * world
         lw_ptr = lib.phd_device_local_weights(h)          # fixed addresses: the export buffer and the migration buffers
+        if not args.host_plan:
+            # every rank's receive buffer, opened by every other rank (hipIpcMemHandle): the senders' kernels store the
+            # migrating particles straight into them. If ANY rank cannot export or open (a runtime that refuses IPC on
+            # fine-grained memory: retried with an ordinary allocation), every rank takes round 3's host-plan sequence instead —
+            # a number from the slower path is better than none, and the line says which path ran.
+            ipc_note = None
+            for attempt in ("finegrained", "coarse"):
+                ok = 1
+                hbuf = C.create_string_buffer(64)
+                try:
+                    nav._check(lib.phd_migration_ipc_export(h, hbuf, None))
+                except Exception as e:
+                    ok, ipc_note = 0, "export (%s): %s" % (attempt, e)
+                handles = [None] * world
+                dist.all_gather_object(handles, bytes(hbuf.raw))
+                if ok:
+                    try:
+                        nav._check(lib.phd_migration_ipc_open(h, b"".join(handles), rank, world))
+                    except Exception as e:
+                        ok, ipc_note = 0, "open (%s): %s" % (attempt, e)
+                agreed = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+                if int(agreed.item()) == 1:
+                    break
+                if attempt == "finegrained":
+                    # a fresh handle with ordinary receive buffers (the allocation class is fixed when the buffers are made)
+                    os.environ["PHD_COARSE_RECV"] = "1"
+                    nav.close()
+                    nav = navigator.PHDNavigator(params, particlecount=P, device=local_rank)
+                    nav.upload_state(frame.planes(), frame.counts, frame.poses, frame.weights)
+                    nav.set_measurements(frame.z)
+                    nav.set_frozen(True)
+                    nav.set_all_pairs(True)
+                    lib, h = nav._lib, nav._h
+                    nav._check(lib.phd_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream), 1))
+                    lw_ptr = lib.phd_device_local_weights(h)
+                else:
+                    args.host_plan = True
+                    print("bench.py rank %d: the IPC path is not available (%s): host-plan sequence" % (rank, ipc_note), file=sys.stderr)
         if args.host_plan:
             gw = torch.as_tensor(DevArray(lib.phd_device_global_weights(h, Pg), Pg), device="cuda")
             scounts = np.zeros(world, np.int32)
@@ -298,15 +337,8 @@ def main():
             mig_rec = bpp.value // 8
             sharded_info = {"plan": "device, its split sizes waited for by the host", "migration": "all_to_all_single", "collective": "allgather"}
         else:
-            # every rank's receive buffer, opened by every other rank (hipIpcMemHandle): the senders' kernels store the
-            # migrating particles straight into them
             graw = torch.as_tensor(DevArray(lib.phd_device_gather_buffer(h, world), world * (P + 1)), device="cuda")
             lw1 = torch.as_tensor(DevArray(lw_ptr, P + 1), device="cuda")
-            hbuf = C.create_string_buffer(64)
-            nav._check(lib.phd_migration_ipc_export(h, hbuf, None))
-            handles = [None] * world
-            dist.all_gather_object(handles, bytes(hbuf.raw))
-            nav._check(lib.phd_migration_ipc_open(h, b"".join(handles), rank, world))
             token = torch.zeros(1, dtype=torch.float32, device="cuda")
             sharded_info = {"plan": "device", "migration": "peer stores into IPC-opened receive buffers, one-word all-reduce as the landing barrier",
                             "collective": args.collective, "recv_buffer_finegrained": bool(lib.phd_migration_recv_is_finegrained(h) == 1),
@@ -632,8 +664,13 @@ def main():
                         if not iso and per_step[dom] > 1 and not tname.startswith("r01"):
                             traffic = traffic / per_step[dom]   # r02 figures are per whole-range launch
                         break
+            # (every kernel by the same rule, for the reader who wants another one than the dominant: the step's algorithmic
+            # bytes over that kernel's launch duration — k_sweep was the dominant kernel until k_emit_finish and k_prune_merge
+            # became one launch)
+            per_kernel = {k: {"kernel_ms": src[k], "frac": 160.0 * per_launch_particles[k] * Cc / (src[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                          for k in src if k.startswith("k_") and src[k] > 0}
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "per_kernel": per_kernel,
                                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": src[dom],
                                "particles_per_launch": particles_per_launch,
                                "launches_per_step": 1 if iso else per_step[dom],
