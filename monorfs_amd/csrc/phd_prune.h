@@ -31,7 +31,9 @@
 #include "phd_device.h"
 
 #define PRUNE_NBR 7
-#define PRUNE_NB 4096   // buckets of the spatial hash (16-bit counters, two per LDS word)
+#ifndef PRUNE_NB
+#define PRUNE_NB 2048   // buckets of the spatial hash (16-bit counters, two per LDS word; 4096 until round 4: half of them, and the bounds below as
+#endif                  // float32, take MaxQuantity 1024's working set from 58.7 to 50.5 KB — three workgroups per CU instead of two on config S)
 #define PRUNE_HEAVY 32  // a row with more candidates than this is searched by a whole wave
 #define PRUNE_ROW 12    // doubles per row of the sorted slab: w, m[3], P[6] (a component record), canonical index, spare
 
@@ -49,10 +51,13 @@ __host__ __device__ inline PruneLds prune_lds(int cutcap)
 	while (NS < 2 * cutcap) NS <<= 1;
 	l.NS    = NS;
 	l.rad2  = 0;
-	l.x     = l.rad2 + cc;                   // sort words u64[NS]  |  the lists of the pair search (see `rest`)
+	l.x     = l.rad2 + ((cc / 2 + 1) & ~1);   // (rad2: cc float32) sort words u64[NS]  |  the lists of the pair search (see `rest`)
 	// nbr u64[2*cc], cand float4[cc], owner int[cc], cstart u16[NB+2], absb int[64], ord u16[cc], rowpos u16[cc]
 	int rest  = 2 * cc + 2 * cc + cc / 2 + (PRUNE_NB + 2) / 4 + 1 + 32 + 2 * (cc / 4 + 1) + 4;
-	l.scan  = l.x + (NS > rest ? NS : rest);
+	int need  = NS > rest ? NS : rest;
+	const int ranked = NS + 516 + (NS * 2) / 3 + 2;   // what the ranked ordering takes with its canonical indices in LDS (prune_merge_body, haveki)
+	if (ranked > need) need = ranked;
+	l.scan  = l.x + need;
 	l.bytes = (l.scan + 136) * 8;            // int[264] | double[28], + spare
 	return l;
 }
@@ -198,7 +203,7 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 {
 	const PruneLds lay = prune_lds(cutcap);
 	const int cc = (cutcap + 1) & ~1, NS = lay.NS;
-	double* rad2  = smem + lay.rad2;                       // [cut] squared Euclidean bound of row i (inf: none)
+	float*  rad2  = (float*) (smem + lay.rad2);            // [cut] squared Euclidean bound of row i (inf: none), float32 rounded UP: a sound bound stays one
 	unsigned int* sw = (unsigned int*) (smem + lay.x);                 // [NS] sort words (prune_pack32)
 	unsigned int* w2 = sw + NS;                                        // [NS] the 32 weight bits behind the key of slot e < NS
 	unsigned long long* nbr = (unsigned long long*) (smem + lay.x);    // [cut][2]: count + up to 7 close later rows
@@ -526,7 +531,12 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 		const double det = v.P0 * (v.P3 * v.P5 - v.P4 * v.P4) - v.P1 * (v.P1 * v.P5 - v.P4 * v.P2) + v.P2 * (v.P1 * v.P4 - v.P3 * v.P2);
 		const bool pd = v.P0 > 0 && (v.P0 * v.P3 - v.P1 * v.P1) > 0 && det > 0;   // Sylvester
 		const double rad = pd ? sqrt(merge_thr2 * (v.P0 + v.P3 + v.P5)) : INFINITY;
-		rad2[r] = rad * rad * (1.0 + 1e-6);
+		{
+			const double b2 = rad * rad * (1.0 + 1e-6);
+			float bf = (float) b2;
+			if ((double) bf < b2) bf = __int_as_float(__float_as_int(bf) + 1);   // (positive, finite: the next float32 up; +inf converts to +inf)
+			rad2[r] = bf;
+		}
 		rmx = pd ? fmax(rmx, rad) : rmx;
 		lo0 = fmin(lo0, v.m0); lo1 = fmin(lo1, v.m1); lo2 = fmin(lo2, v.m2);
 		hi0 = fmax(hi0, v.m0); hi1 = fmax(hi1, v.m1); hi2 = fmax(hi2, v.m2);
@@ -701,7 +711,7 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 		__syncthreads();
 		for (int i = tid; i < cut; i += 256) {
 			int key = 63;
-			if (rad2[i] <= rcap * rcap) {
+			if ((double) rad2[i] <= rcap * rcap) {
 				unsigned int qb[8];
 				key = min(ranges(cand[rowpos[i]], qb), 62);
 			}
@@ -738,7 +748,7 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 		for (int t = tid; t < hstart; t += 256) {
 			const int i = ord[t];
 			const float4 me = cand[rowpos[i]];
-			const double bound = rad2[i];
+			const double bound = (double) rad2[i];
 			int cnt = 0;
 			unsigned int e[PRUNE_NBR];   // close rows found (statically indexed only)
 #pragma unroll
@@ -897,7 +907,7 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 		for (int h = hstart + wv; h < cut; h += 4) {   // (wave-uniform) one crowded row per wave at a time, candidate per lane
 			const int i = ord[h];
 			const float4 me = cand[rowpos[i]];
-			const double bound = rad2[i];
+			const double bound = (double) rad2[i];
 			int cnt = 0;
 			unsigned int e[PRUNE_NBR];   // the same in every lane
 #pragma unroll
