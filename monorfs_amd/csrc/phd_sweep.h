@@ -428,7 +428,10 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 #endif
 // (four measurement blocks per lane need 220 registers: two waves per SIMD is what that kernel gets, and what it asks for)
 template <int ZB, bool HALF = false>
-__global__ __launch_bounds__(256, (ZB == 4 ? 2 : PHD_SWEEP_WAVES)) void k_sweep(const DevParams prm, const StepBufs a)
+#ifndef PHD_SWEEP2_WAVES
+#define PHD_SWEEP2_WAVES PHD_SWEEP_WAVES   // ... of the two-block kernel (65 - 128 measurements)
+#endif
+__global__ __launch_bounds__(256, (ZB == 4 ? 2 : (ZB == 2 ? PHD_SWEEP2_WAVES : PHD_SWEEP_WAVES))) void k_sweep(const DevParams prm, const StepBufs a)
 {
 	__shared__ __align__(16) double pool[SweepLds<ZB>::doubles];
 	sweep_body<ZB, HALF>(prm, a, pool);
