@@ -668,7 +668,7 @@ def main():
             # bytes over that kernel's launch duration — k_sweep was the dominant kernel until k_emit_finish and k_prune_merge
             # became one launch)
             per_kernel = {k: {"kernel_ms": src[k], "frac": 160.0 * per_launch_particles[k] * Cc / (src[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                          for k in src if k.startswith("k_") and src[k] > 0}
+                          for k in src if k.startswith("k_") and src[k] > 0 and k != "k_normalise_resample"}   # (one workgroup for all particles: no per-particle stream)
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "per_kernel": per_kernel,
                                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": src[dom],
