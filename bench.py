@@ -30,11 +30,12 @@ FP64_SUSTAINED_TFLOPS = 59.6   # v_fma_f64 over the whole chip at four waves per
                                # 62.3 at eight waves per SIMD; round 1's 53 came from a colder, shorter run)
 FP64_SPEC_TFLOPS = 78.6        # the datasheet FP64 vector rate (4 cycles per wave instruction, 1024 SIMDs, 2.4 GHz)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-# SURVEY §8d's protocol is ">= 20 warm + >= 100 timed steps": the first ~20 steps behind the creation of a handle run about
-# 5 % slower than the steady state (the device comes out of idle: 0.72 ms per step timed behind 3 warm-up steps, 0.68 behind
-# 20, 0.67 behind 60). The state is therefore rolled this many untimed steps BEFORE the --warmup steps (reported as
-# "preroll_steps"); the timed region is still exactly --steps steps between two barriers.
-PREROLL_STEPS = 20
+# SURVEY §8d's protocol is ">= 20 warm + >= 100 timed steps": the first steps behind the creation of a handle run slower than
+# the steady state (the device comes out of idle). Round 4, 20 timed steps behind 5 warm-up steps: 0.669 ms per step with 20 steps
+# rolled first, 0.653 with 60, 0.653 with 150, 0.656 with 400 (200 timed steps: 0.647 either way; scripts/r4_preroll.sh). The state
+# is therefore rolled this many untimed steps BEFORE the --warmup steps (reported as "preroll_steps"; 40 ms of device time); the
+# timed region is still exactly --steps steps between two barriers.
+PREROLL_STEPS = int(os.environ.get("PHD_BENCH_PREROLL", "60"))
 
 
 def parse():

@@ -1969,7 +1969,10 @@ template <int ZB>
 __global__ __launch_bounds__(256, PHD_ASSOC_WAVES) void k_alpha_assoc(const DevParams prm, const StepBufs a, int ncap)
 {
 	extern __shared__ __align__(16) double smem[];
+	PHD_TL_BEGIN;
+	PHD_SET_PRIO(PHD_LAT_PRIO);
 	alpha_assoc_body<ZB, false>(prm, a, ncap, smem);
+	PHD_TL_END(3);
 }
 
 // the same with the particles that need the ordered replay (a cluster of more than 5 rows) left to k_alpha_big
@@ -2197,7 +2200,10 @@ __device__ __forceinline__ void alpha_density_body(const DevParams& prm, const S
 __global__ __launch_bounds__(256) void k_alpha_density(const DevParams prm, const StepBufs a)
 {
 	__shared__ __align__(16) double pool[DENS_LDS_DOUBLES];
+	PHD_TL_BEGIN;
+	PHD_SET_PRIO(PHD_DENSE_PRIO);
 	alpha_density_body(prm, a, pool);
+	PHD_TL_END(4);
 }
 
 // ... and those particles, INSIDE the launch of the densities: the first `nbig` workgroups of k_alpha_density_big stride over the

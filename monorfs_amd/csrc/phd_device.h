@@ -21,11 +21,27 @@
 #define PHD_STAMP_DECL long long stamp_[12]; for (int s_ = 0; s_ < 12; s_++) stamp_[s_] = 0
 #define PHD_STAMP(i) stamp_[i] = clock64()
 #define PHD_STAMP_FLUSH(id, n) if (threadIdx.x == 0 && a.stamps && a.stamp_kernel == (id)) { for (int s_ = 0; s_ < (n); s_++) a.stamps[(size_t) (a.p0 + blockIdx.x) * 16 + s_] = (double) (stamp_[s_] - stamp_[0]); }
+// ... and the launch's TIMELINE (PHD_STAMP_KERNEL = 100 + id): every workgroup's start and end on the constant 100 MHz counter and the
+// place it ran at (HW_ID: SIMD / CU / SE; XCC_ID), for scripts/timeline.py: ramp, rounds and tail of a launch.
+#define PHD_TL_BEGIN const long long tl0_ = wall_clock64()
+#define PHD_TL_END(id) if (threadIdx.x == 0 && a.stamps && a.stamp_kernel == 100 + (id)) { double* o_ = a.stamps + (size_t) (a.p0 + blockIdx.x) * 16; \
+	o_[0] = (double) tl0_; o_[1] = (double) wall_clock64(); o_[2] = (double) __builtin_amdgcn_s_getreg((31 << 11) | 4); o_[3] = (double) __builtin_amdgcn_s_getreg((31 << 11) | 20); }
 #else
 #define PHD_STAMP_DECL
 #define PHD_STAMP(i)
 #define PHD_STAMP_FLUSH(id, n)
+#define PHD_TL_BEGIN
+#define PHD_TL_END(id)
 #endif
+
+// Wave priority of the latency-bound kernels / the dense ones (s_setprio 0..3; experiment switches, 0 = leave it alone)
+#ifndef PHD_LAT_PRIO
+#define PHD_LAT_PRIO 0
+#endif
+#ifndef PHD_DENSE_PRIO
+#define PHD_DENSE_PRIO 0
+#endif
+#define PHD_SET_PRIO(x) do { if ((x) > 0) __builtin_amdgcn_s_setprio(x); } while (0)
 
 // Parameters as the kernels consume them (built once on the host from phd_params).
 struct DevParams {

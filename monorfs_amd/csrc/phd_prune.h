@@ -1180,7 +1180,10 @@ __global__ __launch_bounds__(256, PHD_PRUNE_WAVES) void k_prune_merge(const DevP
 __global__ __launch_bounds__(256, PHD_PRUNE_WAVES) void k_emit_prune(const DevParams prm, const StepBufs a, int cutcap)
 {
 	extern __shared__ __align__(16) double smem[];
+	PHD_TL_BEGIN;
+	PHD_SET_PRIO(PHD_LAT_PRIO);
 	emit_finish_body(prm, a, smem);
 	__syncthreads();   // (workgroup scope: what this workgroup's waves stored is visible to its loads behind the barrier)
 	prune_merge_body(prm, a, cutcap, smem);
+	PHD_TL_END(2);
 }

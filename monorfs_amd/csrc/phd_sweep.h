@@ -434,5 +434,8 @@ template <int ZB, bool HALF = false>
 __global__ __launch_bounds__(256, (ZB == 4 ? 2 : (ZB == 2 ? PHD_SWEEP2_WAVES : PHD_SWEEP_WAVES))) void k_sweep(const DevParams prm, const StepBufs a)
 {
 	__shared__ __align__(16) double pool[SweepLds<ZB>::doubles];
+	PHD_TL_BEGIN;
+	PHD_SET_PRIO(PHD_DENSE_PRIO);
 	sweep_body<ZB, HALF>(prm, a, pool);
+	PHD_TL_END(6);
 }
