@@ -2022,12 +2022,18 @@ __global__ __launch_bounds__(256, 4) void k_quasi_setll(const DevParams prm, con
 #define DENS_JL 128   // landmarks whose partial sums stay in LDS
 #define DENS_REC 12   // gauss_record + the weight ratio of the component's surviving misdetection copy (+ 1: records stay 16-byte aligned)
 
-#define DENS_LDS_DOUBLES (TILE * DENS_REC + 2 * (DENS_JL / 64) * 256 + EXPTAB_N + 2)
+#ifndef DENS_TILE
+#define DENS_TILE TILE   // components staged per tile of THIS kernel (threads beyond it sit the staging out)
+#endif
+#ifndef PHD_DENS_WAVES
+#define PHD_DENS_WAVES 4
+#endif
+#define DENS_LDS_DOUBLES (DENS_TILE * DENS_REC + 2 * (DENS_JL / 64) * 256 + EXPTAB_N + 2)
 __device__ __forceinline__ void alpha_density_body(const DevParams& prm, const StepBufs& a, double* pool, int pin = -1)
 {
 	constexpr int JL = DENS_JL;
-	double* const tile = pool;                                        // [TILE][12]
-	double* const partpl = tile + TILE * DENS_REC;                    // [JB][4][64] partial densities of v_pred (HBM slab when J > JL)
+	double* const tile = pool;                                        // [DENS_TILE][12]
+	double* const partpl = tile + DENS_TILE * DENS_REC;                    // [JB][4][64] partial densities of v_pred (HBM slab when J > JL)
 	double* const partcl = partpl + (JL / 64) * 256;                  // the same for v_corr
 	double* const etab = partcl + (JL / 64) * 256;
 	int* const s_wc = (int*) (etab + EXPTAB_N);                       // [4]
@@ -2070,8 +2076,8 @@ __device__ __forceinline__ void alpha_density_body(const DevParams& prm, const S
 		for (int i = tid; i < JB * 256; i += 256) { partp[i] = 0; partc[i] = 0; }
 		for (int src = 0; src < 2; src++) {
 			const int total = (src == 0) ? np : no;
-			for (int c0 = 0; c0 < total; c0 += TILE) {
-				int c = c0 + tid;
+			for (int c0 = 0; c0 < total; c0 += DENS_TILE) {
+				int c = (DENS_TILE < 256 && tid >= DENS_TILE) ? total : c0 + tid;
 				int cend;
 				if (src == 0) {
 					if (c < total) {
@@ -2091,7 +2097,7 @@ __device__ __forceinline__ void alpha_density_body(const DevParams& prm, const S
 						gauss_record(w, m, Pi, PHD_INV_2PI / sqrt(fabs(det)), tile + tid * DENS_REC);
 						tile[tid * DENS_REC + 10] = (w > 0) ? wcopy[c] / w : 0.0;
 					}
-					cend = min(TILE, total - c0);
+					cend = min(DENS_TILE, total - c0);
 				}
 				else {
 					// the corrected components not accounted for by the first sweep, compacted in map order
@@ -2197,7 +2203,7 @@ __device__ __forceinline__ void alpha_density_body(const DevParams& prm, const S
 	}
 }
 
-__global__ __launch_bounds__(256) void k_alpha_density(const DevParams prm, const StepBufs a)
+__global__ __launch_bounds__(256, PHD_DENS_WAVES) void k_alpha_density(const DevParams prm, const StepBufs a)
 {
 	__shared__ __align__(16) double pool[DENS_LDS_DOUBLES];
 	PHD_TL_BEGIN;

@@ -25,7 +25,9 @@
 // place it ran at (HW_ID: SIMD / CU / SE; XCC_ID), for scripts/timeline.py: ramp, rounds and tail of a launch.
 #define PHD_TL_BEGIN const long long tl0_ = wall_clock64()
 #define PHD_TL_END(id) if (threadIdx.x == 0 && a.stamps && a.stamp_kernel == 100 + (id)) { double* o_ = a.stamps + (size_t) (a.p0 + blockIdx.x) * 16; \
-	o_[0] = (double) tl0_; o_[1] = (double) wall_clock64(); o_[2] = (double) __builtin_amdgcn_s_getreg((31 << 11) | 4); o_[3] = (double) __builtin_amdgcn_s_getreg((31 << 11) | 20); }
+	o_[0] = (double) tl0_; o_[1] = (double) wall_clock64(); o_[2] = (double) __builtin_amdgcn_s_getreg((31 << 11) | 4); o_[3] = (double) __builtin_amdgcn_s_getreg((31 << 11) | 20); } \
+	else if (threadIdx.x == 0 && a.stamps && a.stamp_kernel == 199) { double* o_ = a.stamps + (size_t) (a.p0 + blockIdx.x) * 16 + ((id) == 6 ? 0 : ((id) == 2 ? 2 : ((id) == 3 ? 4 : 6))); \
+	o_[0] = (double) tl0_; o_[1] = (double) wall_clock64(); }   /* 199: all four kernels of a step side by side (scripts/timeline_step.py) */
 #else
 #define PHD_STAMP_DECL
 #define PHD_STAMP(i)

@@ -131,6 +131,15 @@ struct StepBufs {
 	int     defer;       // 1: the step runs k_alpha_assoc_main / k_alpha_big / k_alpha_combine (k_alpha_density leaves alpha open)
 	int     all_pairs;   // 1: k_sweep evaluates every (component, measurement) pair, the radius gate only masks (SURVEY §8d's benchmark
 	                     // mode: the unit count P C M is exact); 0: a visit whose 64 pairs all lie outside the gate is skipped
+	// k_normalise_resample folded into the one-launch chain (small particle sets): the workgroup that takes the last ticket runs it
+	int           fold_nr;      // 1: k_particle_chain ends the step itself
+	unsigned int* ticket;       // [1] workgroups of the launch that are through (the last one sets it back to 0)
+	double        nr_u;         // the arguments k_normalise_resample would have got
+	int           nr_force, nr_skip, nr_frozen;
+	int*          nr_src;
+	int*          nr_info;
+	int*          nr_sel_next;
+	int*          nr_inslot;
 	int     stamp_kernel; // which kernel writes them (env PHD_STAMP_KERNEL): 2 prune, 3 assoc, 4 density, 1 correct, 5 the one-launch chain
 };
 
@@ -218,6 +227,28 @@ __global__ __launch_bounds__(256, 1) void k_particle_chain(const DevParams prm, 
 		PHD_STAMP(5);
 	}
 	PHD_STAMP_FLUSH(5, 6);   // (diagnostic build, PHD_STAMP_KERNEL=5: the bodies' shares of the chain)
+	if (a.fold_nr) {
+		// The end of the step without a launch of its own: behind the barrier every wave's stores have left the CU; ONE thread
+		// publishes them (release fence, device scope: the XCD's L2 is written back — by every thread that is 1024 write-backs
+		// per launch and cost more than the launch saved) and takes a ticket; the workgroup that takes the last has every
+		// particle's weight, count and flag before it (acquire fence: L1 and the L2's stale lines invalidated) and runs
+		// k_normalise_resample's body on the launch's LDS pool.
+		__shared__ int s_last;
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores are acknowledged by the L2
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			__threadfence();
+			const int last = (atomicAdd(a.ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+			if (last) *a.ticket = 0;   // for the next launch (stream order)
+			__threadfence();
+			s_last = last;
+		}
+		__syncthreads();
+		if (s_last) {   // (workgroup-uniform)
+			normalise_resample_body(a, nullptr, a.P, prm.min_eff, a.nr_u, a.nr_force, a.nr_skip, 1, a.nr_src, a.nr_info, a.nr_sel_next,
+			                        a.nr_frozen, a.nr_inslot, smem);
+		}
+	}
 }
 
 // k_sweep, k_emit_finish and k_prune_merge as ONE launch on a full machine (environment PHD_FUSE_SEP=1): the first three bodies

@@ -158,12 +158,14 @@ __device__ __forceinline__ void rotate_roles(const StepBufs& a, const int* src, 
 	}
 }
 
-__global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, double* gw, int P, double min_eff, double u,
-                                                             int force_resample, int skip_normalise, int use_lds,
-                                                             int* src, int* info, int* sel_next, int frozen, int* inslot)
+// The body: the kernel's one workgroup, or — for a small particle set — the last workgroup of k_particle_chain to finish
+// (phd_kernels.h; blockDim.x = 256 there as in a launch of its own for up to 512 weights: the same tree of sums, the same bits).
+__device__ __forceinline__ void normalise_resample_body(const StepBufs& a, double* gw, int P, double min_eff, double u,
+                                                        int force_resample, int skip_normalise, int use_lds,
+                                                        int* src, int* info, int* sel_next, int frozen, int* inslot,
+                                                        double* lw /* LDS, [P] chunk-transposed when use_lds */)
 {
 #pragma clang fp contract(off)   // the error-free transformations below must not be fused
-	extern __shared__ __align__(16) double lw[];   // [P] when use_lds
 	__shared__ double s_pchi[1024], s_pclo[1024];  // double-double prefix sum at the start of every thread's chunk
 	__shared__ double s16[16], s16b[16];
 	__shared__ int    s_i16[16];
@@ -497,4 +499,16 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 		__syncthreads();   // src and the weights of every particle are written
 		rotate_roles(a, src, 1, sel_next, frozen, inslot, tid);
 	}
+}
+
+__global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, double* gw, int P, double min_eff, double u,
+                                                             int force_resample, int skip_normalise, int use_lds,
+                                                             int* src, int* info, int* sel_next, int frozen, int* inslot)
+{
+	extern __shared__ __align__(16) double lw_nr[];   // [P] when use_lds
+	PHD_TL_BEGIN;
+	normalise_resample_body(a, gw, P, min_eff, u, force_resample, skip_normalise, use_lds, src, info, sel_next, frozen, inslot, lw_nr);
+#ifdef PHD_STAMPS
+	if (threadIdx.x == 0 && a.stamps && a.stamp_kernel == 199) { a.stamps[8] = (double) tl0_; a.stamps[9] = (double) wall_clock64(); }
+#endif
 }

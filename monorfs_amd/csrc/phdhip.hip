@@ -45,6 +45,7 @@ struct phd_navigator {
 	static const int MAXSPLIT = 4;
 	int         nsplit = 0;            // sub-ranges a step's per-particle kernels are split into (0: chosen from the particle count)
 	int         chain_max = 512;       // up to this many particles a step's per-particle kernels run as one launch (k_particle_chain; env PHD_CHAIN_MAX)
+	int         fold_nr = 0;           // 1 (env PHD_FOLD_NR): the chain ends the step itself — k_normalise_resample's body in its last workgroup; measured slower than the launch
 	bool        chain_ok[3] = {false, false, false};   // ... where the bodies' LDS arrays fit one workgroup (per measurement-block count 1, 2, 4)
 	hipStream_t aux[MAXSPLIT - 1] = {nullptr, nullptr, nullptr};   // streams of the sub-ranges after the first
 	// Option (environment PHD_DEFER_BIG=1; off by default): the particles with an association cluster of more than
@@ -64,6 +65,13 @@ struct phd_navigator {
 	int*        d_biglist = nullptr;   // [MAXSPLIT][Pcap + 2]
 	double*     d_ratio = nullptr;     // [Pcap]
 	hipEvent_t  ev_fork = nullptr, ev_join[MAXSPLIT - 1] = {nullptr, nullptr, nullptr};
+	// Two sub-ranges, steps posted back to back (phd_step_async after phd_step_async): the end of the step runs on the stream
+	// whose chain finishes LAST and no fork precedes the next step ("the step boundary"; env PHD_PIPELINE=0: a fork
+	// before and a join behind every step, as for every other caller)
+	int         pipeline = 1;
+	bool        pipe_ok = false;       // nothing was enqueued on `stream` since the last such step: the aux stream is ordered behind all of it
+	int         lagger = 1;            // which of the two streams (0 `stream`, 1 aux[0]) finishes the coming step last
+	hipEvent_t  ev_res = nullptr;      // k_normalise_resample is through (recorded on the stream that ran it)
 	bool sel_host_valid = false;       // h_sel mirrors the device-side bank roles without a round trip
 	int Pcap = 0, cap = 0, Mcap = 0, ecap = 0, Jcap = 0, cutcap = 0;
 	int P = 0, M = 0;
@@ -241,10 +249,20 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.born_count = nav->d_born_count; b.born_k = nav->d_born_k; b.born_mean = nav->d_born_mean;
 	b.alpha = nav->d_alpha; b.setll = nav->d_setll; b.flags = nav->d_flags; b.murty = nav->d_murty; b.jscratch = nav->d_jscratch;
 	b.bigws = nav->d_bigws; b.bigws_bytes = nav->bigws_bytes; b.bigws_used = nav->d_bigws_used;
+	b.fold_nr = 0; b.ticket = (unsigned int*) (nav->d_bigws_used + 1);
+	b.nr_u = 0; b.nr_force = 0; b.nr_skip = 0; b.nr_frozen = 0; b.nr_src = nullptr; b.nr_info = nullptr; b.nr_sel_next = nullptr; b.nr_inslot = nullptr;
 	b.cand_count = nav->d_cand_count; b.denom = nav->d_denom;
 	b.cand = nav->d_cand; b.candcap = nav->candcap;
 	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account; b.srec = nav->d_srec; b.outw = nav->d_outw; b.wcopy = nav->d_wcopy; b.cover = nav->d_cover; b.stamps = nav->d_stamps; b.biglist = nav->d_biglist; b.bigstride = nav->Pcap + 2; b.ratio = nav->d_ratio; b.defer = 0; b.all_pairs = nav->all_pairs ? 1 : 0; b.stamp_kernel = getenv("PHD_STAMP_KERNEL") ? atoi(getenv("PHD_STAMP_KERNEL")) : 2;
 	return b;
+}
+
+// Every entry point that may enqueue work on the handle's stream comes through here (phd_step_async alone does not): whatever
+// it enqueues, the aux stream is not ordered behind it until the next step forks again.
+static inline void enter(phd_navigator* nav)
+{
+	hipSetDevice(nav->device);
+	nav->pipe_ok = false;
 }
 
 int zb_of(int M) { return M <= 64 ? 1 : (M <= 128 ? 2 : 4); }
@@ -328,8 +346,10 @@ const char* T_CH = "k_particle_chain";
 // The per-particle kernels of a step. With nsplit > 1 the particle range is cut into sub-ranges whose kernel
 // chains run on concurrent streams (forked from and joined back into the handle's stream), so that the
 // latency-bound kernels of one sub-range overlap the arithmetic-bound kernels of another.
+// `pipe` >= 0 (phd_step_async, two sub-ranges): no fork and no join here — the caller has ordered the streams and ends the step on
+// the stream that finishes last, `pipe` (0 `stream`, 1 aux[0]); the other one's chain is enqueued first.
 template <int ZB>
-int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha)
+int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha, int pipe = -1)
 {
 	const int P = nav->P;
 	// two half-ranges measured best at 2048 particles (1.10 -> 1.02 ms); below ~4 workgroups per CU and sub-range it does not pay
@@ -349,14 +369,15 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha)
 		nav->last_defer = 0;
 		return PHD_OK;
 	}
-	if (S > 1) {
+	if (S > 1 && pipe < 0) {
 		HC(hipEventRecord(nav->ev_fork, nav->stream));
 		for (int s = 1; s < S; s++) HC(hipStreamWaitEvent(nav->aux[s - 1], nav->ev_fork, 0));
 	}
 	const bool defer = with_alpha && nav->defer_big != 0;
 	nav->last_defer = defer ? 1 : 0;
 	const size_t ldb = std::max((size_t) lay.bytes, (size_t) DENS_LDS_DOUBLES * 8);   // k_alpha_density_big: the larger of the two bodies' pools
-	for (int s = 0; s < S; s++) {
+	for (int si = 0; si < S; si++) {
+		const int s = (pipe >= 0 && S == 2) ? (si == 0 ? 1 - pipe : pipe) : si;
 		StepBufs b = b0;
 		b.defer = defer ? 1 : 0;
 		b.biglist = nav->d_biglist + (size_t) s * b0.bigstride;
@@ -409,7 +430,7 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha)
 			timer_end(nav, T_WD, st);
 		}
 	}
-	for (int s = 1; s < S; s++) {
+	for (int s = 1; s < S && pipe < 0; s++) {
 		HC(hipEventRecord(nav->ev_join[s - 1], nav->aux[s - 1]));
 		HC(hipStreamWaitEvent(nav->stream, nav->ev_join[s - 1], 0));
 	}
@@ -433,18 +454,19 @@ int launch_quasi(phd_navigator* nav, const StepBufs& b, int nposes, bool gradien
 	return PHD_OK;
 }
 
-int launch_map(phd_navigator* nav, const StepBufs& b, bool with_alpha)
+int launch_map(phd_navigator* nav, const StepBufs& b, bool with_alpha, int pipe = -1)
 {
 	switch (zb_of(nav->M)) {
-	case 1:  return launch_map_kernels<1>(nav, b, with_alpha);
-	case 2:  return launch_map_kernels<2>(nav, b, with_alpha);
-	default: return launch_map_kernels<4>(nav, b, with_alpha);
+	case 1:  return launch_map_kernels<1>(nav, b, with_alpha, pipe);
+	case 2:  return launch_map_kernels<2>(nav, b, with_alpha, pipe);
+	default: return launch_map_kernels<4>(nav, b, with_alpha, pipe);
 	}
 }
 
 int launch_normalise(phd_navigator* nav, const StepBufs& b, double* gw, int P, double u, int force, int skipnorm, int* src, int* info,
-                     int* sel_next = nullptr)
+                     int* sel_next = nullptr, hipStream_t st = nullptr)
 {
+	if (!st) st = nav->stream;
 	// one workgroup; 256 / 512 threads for shorter weight vectors (fewer waves to meet at every barrier), 1024 beyond 4096
 	static const int nr_env = getenv("PHD_NR_THREADS") ? atoi(getenv("PHD_NR_THREADS")) : 0;
 	const int nthreads = (nr_env == 256 || nr_env == 512 || nr_env == 1024) ? nr_env : (P <= 512 ? 256 : (P <= 4096 ? 512 : 1024));
@@ -453,7 +475,7 @@ int launch_normalise(phd_navigator* nav, const StepBufs& b, double* gw, int P, d
 	size_t lds = (size_t) ((P + nthreads - 1) / nthreads) * (nthreads + 1) * 8;
 	int use_lds = lds + (size_t) nav->nr_static_lds + 256 <= 160 * 1024;
 	if (!use_lds) lds = 0;
-	hipLaunchKernelGGL(k_normalise_resample, dim3(1), dim3(nthreads), lds, nav->stream, b, gw, P, nav->dp.min_eff, u, force, skipnorm,
+	hipLaunchKernelGGL(k_normalise_resample, dim3(1), dim3(nthreads), lds, st, b, gw, P, nav->dp.min_eff, u, force, skipnorm,
 	                   use_lds, src, info, sel_next, nav->frozen ? 1 : 0, nav->d_inslot);
 	HC(hipGetLastError());
 	return PHD_OK;
@@ -679,17 +701,29 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	auto dalloc = [&](void** ptr, size_t bytes) { return hipMalloc(ptr, std::max<size_t>(bytes, 16)) == hipSuccess; };
 	bool ok = hipStreamCreateWithFlags(&nav->own_stream, hipStreamNonBlocking) == hipSuccess;
 	nav->stream = nav->own_stream;
+	// The events that order the sub-range streams among themselves (same device, never inspected by the host): recorded without
+	// the system-scope fence a default event performs (5 us per step boundary; the kernels' own release / acquire at their ends
+	// and starts is what the next stream's kernels see). PHD_EVENT_FLAGS=0: default events.
+	unsigned evflags = hipEventDisableTiming | hipEventDisableSystemFence;
+	if (const char* e = getenv("PHD_EVENT_FLAGS")) {
+		const int m = atoi(e);
+		if (m == 0) evflags = hipEventDisableTiming;
+		if (m == 1) evflags = hipEventDisableTiming | hipEventReleaseToDevice;
+	}
 	for (int i = 0; i < phd_navigator::MAXSPLIT - 1; i++) {
 		ok = ok && hipStreamCreateWithFlags(&nav->aux[i], hipStreamNonBlocking) == hipSuccess;
-		ok = ok && hipEventCreateWithFlags(&nav->ev_join[i], hipEventDisableTiming) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&nav->ev_join[i], evflags) == hipSuccess;
 	}
-	ok = ok && hipEventCreateWithFlags(&nav->ev_fork, hipEventDisableTiming) == hipSuccess;
+	ok = ok && hipEventCreateWithFlags(&nav->ev_fork, evflags) == hipSuccess;
+	ok = ok && hipEventCreateWithFlags(&nav->ev_res, evflags) == hipSuccess;
+	if (const char* e = getenv("PHD_PIPELINE")) nav->pipeline = atoi(e) != 0;
 	if (const char* e = getenv("PHD_DEFER_BIG")) nav->defer_big = atoi(e) != 0;
 	if (const char* e = getenv("PHD_FUSE_EP")) nav->fuse_ep = atoi(e) != 0 ? 1 : 0;
 	if (const char* e = getenv("PHD_FUSE_SEP")) nav->fuse_sep = atoi(e) != 0 ? 1 : 0;
 	if (const char* e = getenv("PHD_NBIG")) nav->nbig = std::max(1, atoi(e));
 	if (const char* e = getenv("PHD_SPLIT")) nav->nsplit = std::max(0, atoi(e));
 	if (const char* e = getenv("PHD_CHAIN_MAX")) nav->chain_max = std::max(0, atoi(e));
+	if (const char* e = getenv("PHD_FOLD_NR")) nav->fold_nr = atoi(e) != 0;
 	size_t plane = (size_t) nav->Pcap * nav->cap;
 	for (int i = 0; i < 3 && ok; i++) {
 		ok = ok && dalloc((void**) &nav->bank[i].mix, plane * MIX_REC * 8);
@@ -718,8 +752,8 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	ok = ok && dalloc((void**) &nav->d_src, (size_t) nav->Pcap * 4);
 	ok = ok && dalloc((void**) &nav->d_murty, (size_t) nav->Pcap * sizeof(MurtyNodes));
 	nav->bigws_bytes = 128ull << 20;
-	ok = ok && dalloc((void**) &nav->d_bigws, nav->bigws_bytes) && dalloc((void**) &nav->d_bigws_used, 8);
-	if (ok) hipMemset(nav->d_bigws_used, 0, 8);
+	ok = ok && dalloc((void**) &nav->d_bigws, nav->bigws_bytes) && dalloc((void**) &nav->d_bigws_used, 16);   // [0] the slab's bump counter, [1] the chain's ticket
+	if (ok) hipMemset(nav->d_bigws_used, 0, 16);
 	nav->cmcap = nav->cap + nav->Mcap;
 	ok = ok && dalloc((void**) &nav->d_cand_count, (size_t) nav->Pcap * 4 * 4) && dalloc((void**) &nav->d_denom, (size_t) nav->Pcap * nav->Mcap * 8);
 	nav->candcap = 16 * nav->cmcap;   // a quarter of all pairs at 64 measurements (four wave segments); beyond it the full second sweep runs
@@ -838,7 +872,7 @@ void phd_destroy(phd_navigator* nav)
 {
 	if (!nav) return;
 	if (nav->multi) { multi_destroy(nav); return; }
-	hipSetDevice(nav->device);
+	enter(nav);
 	if (nav->stream) hipStreamSynchronize(nav->stream);
 	for (int i = 0; i < 3; i++) {
 		hipFree(nav->bank[i].mix); hipFree(nav->bank[i].count); hipFree(nav->bank[i].poses); hipFree(nav->bank[i].weights);
@@ -865,6 +899,7 @@ void phd_destroy(phd_navigator* nav)
 		if (nav->ev_join[i]) hipEventDestroy(nav->ev_join[i]);
 	}
 	if (nav->ev_fork) hipEventDestroy(nav->ev_fork);
+	if (nav->ev_res) hipEventDestroy(nav->ev_res);
 	hipFree(nav->d_biglist); hipFree(nav->d_ratio);
 	delete nav;
 }
@@ -878,7 +913,7 @@ static int reset_impl(phd_navigator* nav, int nparticles, const double* pose7, c
                       const double* cov9, int ncomp, double weight)
 {
 	if (nparticles < 1 || nparticles > nav->Pcap || !pose7 || ncomp < 0) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_reset: bad particle count / pose / ncomp");
-	hipSetDevice(nav->device);
+	enter(nav);
 	int rc = sync_state(nav);
 	if (rc) return rc;
 	rc = reset_indirection(nav);   // the state is replaced as a whole
@@ -923,7 +958,7 @@ int phd_set_poses(phd_navigator* nav, const double* poses7, int nparticles)
 	FINITE_OR_FAIL(nav, poses7, (size_t) nparticles * 7, "phd_set_poses");
 	if (nav->multi) return multi_set_small(nav, poses7, nullptr, nparticles);
 	if (nparticles != nav->P || !poses7) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_poses: particle count mismatch");
-	hipSetDevice(nav->device);
+	enter(nav);
 	// the bank that holds the current poses is known to the device (the roles rotate there, at the end of a step): the poses
 	// are staged and stored by a kernel that resolves it, so this is correct right behind phd_step_async and never waits
 	double* hs = stage_acquire(nav);
@@ -948,7 +983,7 @@ int phd_update_motion(phd_navigator* nav, const double* odometry6, const double*
 	if (nav->multi) return multi_update_motion(nav, odometry6, noise6, nparticles, perfect_still);
 	if (nav->prm.model != PHD_MODEL_PRM3D) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_update_motion: Pose3D odometry, the PRM3D model only");
 	if (!odometry6 || nparticles != nav->P) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_update_motion: particle count mismatch");
-	hipSetDevice(nav->device);
+	enter(nav);
 	bool zero = true;
 	for (int t = 0; t < 6; t++) zero = zero && odometry6[t] == 0;
 	const int use_noise = noise6 && !(perfect_still && zero);   // "static friction makes the robot stay put", TrackVehicle.cs:93-94
@@ -977,7 +1012,7 @@ static int quasi_batch(phd_navigator* nav, const double* poses7, int nposes, con
 	FINITE_OR_FAIL(nav, poses7, (size_t) nposes * 7, "phd_quasi_set_loglik");
 	FINITE_OR_FAIL(nav, landmarks3, (size_t) nlandmarks * 3, "phd_quasi_set_loglik");
 	FINITE_OR_FAIL(nav, z3, (size_t) nmeasurements * 3, "phd_quasi_set_loglik");
-	hipSetDevice(nav->device);
+	enter(nav);
 	// One buffer on the device and its pinned mirror on the host, packed per call:
 	//   poses[n][7] | landmarks[J][3] | z[M][3] | flag word | slab counter | out[n] | gradients[n][6]
 	// so that a call is ONE copy in (inputs, with the two words zeroed), the kernel, ONE copy out (from the flag word on) and
@@ -1046,7 +1081,7 @@ int phd_test_pairing(phd_navigator* nav, const double* matrix, int n, int mode, 
 	if (!matrix || !assignments || !values || !count || n < 1 || n > MURTY_NBIG || maxcount < 1 || (mode == 1 && n > 5) || mode < 0 || mode > 1) {
 		return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_test_pairing: n in 1..256 (1..5 for the lexicographic order), mode 0 or 1, buffers for maxcount pairings");
 	}
-	hipSetDevice(nav->device);
+	enter(nav);
 	HC(hipStreamSynchronize(nav->stream));
 	double* dm = nullptr; int* da = nullptr; double* dv = nullptr; int* dc = nullptr; char* dbig = nullptr;
 	HC(hipMalloc((void**) &dm, (size_t) n * n * 8));
@@ -1078,7 +1113,7 @@ int phd_set_weights(phd_navigator* nav, const double* weights, int nparticles)
 	FINITE_OR_FAIL(nav, weights, nparticles, "phd_set_weights");
 	if (nav->multi) return multi_set_small(nav, nullptr, weights, nparticles);
 	if (nparticles != nav->P || !weights) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_weights: particle count mismatch");
-	hipSetDevice(nav->device);
+	enter(nav);
 	double* hs = stage_acquire(nav);
 	std::memcpy(hs, weights, (size_t) nparticles * 8);
 	HC(hipMemcpyAsync(nav->d_stage, hs, (size_t) nparticles * 8, hipMemcpyHostToDevice, nav->stream));
@@ -1099,7 +1134,7 @@ int phd_set_map(phd_navigator* nav, int particle, const double* w, const double*
 	FINITE_OR_FAIL(nav, cov9, (size_t) ncomp * 9, "phd_set_map");
 	if (nav->multi) return multi_set_map(nav, particle, w, mean3, cov9, ncomp);
 	if (particle < 0 || particle >= nav->P) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_map: particle out of range");
-	hipSetDevice(nav->device);
+	enter(nav);
 	int rc = sync_state(nav);
 	if (rc) return rc;
 	rc = materialise(nav);   // a particle's slot may be shared with the other copies of its resampling source
@@ -1115,7 +1150,7 @@ static int upload_impl(phd_navigator* nav, int nparticles, int stride, const dou
                        const double* poses7, const double* weights)
 {
 	if (nparticles < 1 || nparticles > nav->Pcap || stride < 0 || stride > nav->cap) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_upload_state_soa: sizes out of range");
-	hipSetDevice(nav->device);
+	enter(nav);
 	int rc = sync_state(nav);
 	if (rc) return rc;
 	rc = reset_indirection(nav);
@@ -1166,7 +1201,7 @@ int phd_upload_state_soa(phd_navigator* nav, int nparticles, int stride, const d
 // bulk download in the same layout; planes must hold [10][P][stride] with stride >= the largest count
 static int download_impl(phd_navigator* nav, int stride, double* planes, size_t plane_stride, int32_t* counts, double* poses7, double* weights)
 {
-	hipSetDevice(nav->device);
+	enter(nav);
 	int rc = sync_state(nav);
 	if (rc) return rc;
 	if (stride < 0 || stride > nav->cap) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_download_state_soa: stride out of range");
@@ -1212,7 +1247,7 @@ int phd_set_measurements(phd_navigator* nav, const double* z3, int nmeasurements
 	if (nmeasurements < 0 || nmeasurements > nav->prm.max_measurements || (nmeasurements > 0 && !z3)) {
 		return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_set_measurements: count out of range");
 	}
-	hipSetDevice(nav->device);
+	enter(nav);
 	if (nmeasurements > 0) {
 		double* hs = stage_acquire(nav);
 		std::memcpy(hs, z3, (size_t) nmeasurements * 3 * 8);
@@ -1235,7 +1270,7 @@ int phd_set_association_workspace(phd_navigator* nav, int64_t bytes)
 {
 	if (!nav || bytes < 0) return PHD_ERR_BAD_ARGUMENT;
 	if (nav->multi) return multi_forward_int(nav, 1, bytes);
-	hipSetDevice(nav->device);
+	enter(nav);
 	HC(hipStreamSynchronize(nav->stream));
 	hipFree(nav->d_bigws);
 	nav->d_bigws = nullptr;
@@ -1264,24 +1299,79 @@ int phd_set_all_pairs(phd_navigator* nav, uint8_t all_pairs)
 	return PHD_OK;
 }
 
+// Does a step of this handle run as the one-launch chain (launch_map_kernels), and may that launch end the step itself?
+static bool chain_folds_normalise(const phd_navigator* nav)
+{
+	const int zb = zb_of(nav->M), zi = zb == 1 ? 0 : (zb == 2 ? 1 : 2);
+	if (!nav->fold_nr || !nav->chain_ok[zi] || nav->P > nav->chain_max) return false;
+	const size_t lw = (size_t) ((nav->P + 255) / 256) * 257 * 8;   // the weight vector, chunk-transposed, in the chain's pool
+	const size_t pool = zb == 1 ? chain_lds_bytes<1>(nav->cutcap) : (zb == 2 ? chain_lds_bytes<2>(nav->cutcap) : chain_lds_bytes<4>(nav->cutcap));
+	return lw <= pool;
+}
+
 int phd_step_async(phd_navigator* nav, uint8_t onlymapping, double u_resample)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	if (nav->multi) return multi_step(nav, onlymapping, u_resample);
 	if (nav->P < 1) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step: no particles (call phd_reset first)");
-	hipSetDevice(nav->device);
+	hipSetDevice(nav->device);   // (not enter(): a step behind a step leaves the streams ordered)
 	nav->timing_now = (nav->timing_step++ % nav->timing_period) == 0;
 	StepBufs b = make_bufs(nav);
-	int rc = launch_map(nav, b, !onlymapping);
-	if (rc) return rc;
-	b.defer = nav->last_defer;
-	timer_begin(nav, T_NR);
 	nav->d_res_slots = nav->d_src;
-	// the same launch hands the resampled particles their small arrays and rotates the bank roles (rotate_roles)
-	rc = launch_normalise(nav, b, nullptr, nav->P, u_resample, onlymapping ? -1 : 0, onlymapping ? 1 : 0, nav->d_src, nav->d_info,
-	                      nav->d_sel + (nav->parity ^ 1) * SEL_STRIDE);
-	timer_end(nav, T_NR);
-	if (rc) return rc;
+	const bool folded = chain_folds_normalise(nav);
+	if (folded) {
+		// a small particle set: the chain's last workgroup normalises, resamples and rotates the roles (no launch of its own)
+		b.fold_nr = 1; b.nr_u = u_resample; b.nr_force = onlymapping ? -1 : 0; b.nr_skip = onlymapping ? 1 : 0; b.nr_frozen = nav->frozen ? 1 : 0;
+		b.nr_src = nav->d_src; b.nr_info = nav->d_info; b.nr_sel_next = nav->d_sel + (nav->parity ^ 1) * SEL_STRIDE; b.nr_inslot = nav->d_inslot;
+	}
+	// The step boundary with two sub-range streams. A fork before the step and a join behind it put two markers and a barrier
+	// between the last k_alpha_density and k_normalise_resample, and one more between that and the next k_sweep: 22 + 21 us in
+	// which the device runs nothing (scripts/timeline_step.py). Posted back to back, the steps need neither: the stream whose
+	// chain starts second finishes last (`lagger`), k_normalise_resample goes behind ITS k_alpha_density (the other stream's
+	// event is long recorded), its next k_sweep behind that — and so it leads the next step, the other stream, which waits for
+	// the event, lags and takes the end of that one.
+	const int zi_ = zb_of(nav->M) == 1 ? 0 : (zb_of(nav->M) == 2 ? 1 : 2);
+	const bool chain = nav->chain_ok[zi_] && nav->P <= nav->chain_max;
+	const int want = nav->nsplit > 0 ? nav->nsplit : (nav->P >= 1024 ? 2 : 1);
+	const bool pipe = nav->pipeline && !chain && want == 2 && nav->P >= 2 && nav->stream == nav->own_stream;
+	int rc;
+	if (pipe) {
+		if (!nav->pipe_ok) {
+			// something else was enqueued on the stream since the last step (or this is the first): fork, `stream` leads
+			HC(hipEventRecord(nav->ev_fork, nav->stream));
+			HC(hipStreamWaitEvent(nav->aux[0], nav->ev_fork, 0));
+			nav->lagger = 1;
+		}
+		hipStream_t L = nav->lagger ? nav->aux[0] : nav->stream, X = nav->lagger ? nav->stream : nav->aux[0];
+		rc = launch_map(nav, b, !onlymapping, nav->lagger);
+		if (rc) { nav->pipe_ok = false; return rc; }
+		b.defer = nav->last_defer;
+		HC(hipEventRecord(nav->ev_join[0], X));
+		HC(hipStreamWaitEvent(L, nav->ev_join[0], 0));
+		timer_begin(nav, T_NR, L);
+		rc = launch_normalise(nav, b, nullptr, nav->P, u_resample, onlymapping ? -1 : 0, onlymapping ? 1 : 0, nav->d_src, nav->d_info,
+		                      nav->d_sel + (nav->parity ^ 1) * SEL_STRIDE, L);
+		timer_end(nav, T_NR, L);
+		if (rc) { nav->pipe_ok = false; return rc; }
+		HC(hipEventRecord(nav->ev_res, L));
+		HC(hipStreamWaitEvent(X, nav->ev_res, 0));
+		nav->lagger ^= 1;
+		nav->pipe_ok = true;
+	}
+	else {
+		nav->pipe_ok = false;
+		rc = launch_map(nav, b, !onlymapping);
+		if (rc) return rc;
+		if (!folded) {
+			b.defer = nav->last_defer;
+			timer_begin(nav, T_NR);
+			// the same launch hands the resampled particles their small arrays and rotates the bank roles (rotate_roles)
+			rc = launch_normalise(nav, b, nullptr, nav->P, u_resample, onlymapping ? -1 : 0, onlymapping ? 1 : 0, nav->d_src, nav->d_info,
+			                      nav->d_sel + (nav->parity ^ 1) * SEL_STRIDE);
+			timer_end(nav, T_NR);
+			if (rc) return rc;
+		}
+	}
 	nav->parity ^= 1;
 	nav->stage_valid = false;
 	nav->sel_host_valid = false;   // the rotation depends on the resampling flag, known only on the device
@@ -1292,7 +1382,7 @@ int phd_sync(phd_navigator* nav)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	if (nav->multi) return multi_sync(nav);
-	hipSetDevice(nav->device);
+	enter(nav);
 	int rc = sync_state(nav);
 	if (rc) return rc;
 	rc = check_flags(nav);
@@ -1324,7 +1414,7 @@ const double* phd_weights(phd_navigator* nav, int* length)
 {
 	if (!nav) return nullptr;
 	if (nav->multi) return multi_weights(nav, length);
-	hipSetDevice(nav->device);
+	enter(nav);
 	if (sync_state(nav)) return nullptr;
 	int bidx = res_small(nav);
 	nav->h_weights.resize(std::max(nav->P, 1));
@@ -1337,7 +1427,7 @@ int phd_best_particle(phd_navigator* nav)
 {
 	if (!nav) return -1;
 	if (nav->multi) return multi_best_particle(nav);
-	hipSetDevice(nav->device);
+	enter(nav);
 	if (sync_state(nav)) return -1;
 	return nav->h_info[0];
 }
@@ -1346,7 +1436,7 @@ const double* phd_poses(phd_navigator* nav, int* length)
 {
 	if (!nav) return nullptr;
 	if (nav->multi) return multi_poses(nav, length);
-	hipSetDevice(nav->device);
+	enter(nav);
 	if (sync_state(nav)) return nullptr;
 	int bidx = res_small(nav);
 	nav->h_poses.resize((size_t) std::max(nav->P, 1) * 7);
@@ -1360,7 +1450,7 @@ int phd_map(phd_navigator* nav, int particle, int* ncomp, const double** w, cons
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	if (nav->multi) return multi_map(nav, particle, ncomp, w, mean3, cov9);
 	if (particle < 0 || particle >= nav->P || !ncomp) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_map: particle out of range");
-	hipSetDevice(nav->device);
+	enter(nav);
 	int rc = sync_state(nav);
 	if (rc) return rc;
 	rc = fetch_map(nav, res_small(nav), particle, ncomp, res_mix(nav), res_slots(nav));
@@ -1375,7 +1465,7 @@ const int32_t* phd_resample_sources(phd_navigator* nav, int* length, uint8_t* re
 {
 	if (!nav) return nullptr;
 	if (nav->multi) return multi_resample_sources(nav, length, resampled);
-	hipSetDevice(nav->device);
+	enter(nav);
 	if (sync_state(nav)) return nullptr;
 	nav->h_src.resize(std::max(nav->P, 1));
 	if (hipMemcpy(nav->h_src.data(), nav->d_src, (size_t) nav->P * 4, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
@@ -1420,7 +1510,7 @@ int phd_stage_map(phd_navigator* nav, int stage, int particle, int* ncomp, const
 	MULTI_UNSUPPORTED(nav, "phd_stage_map");
 	if (!nav->stage_valid) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_stage_map: call phd_stage_run first");
 	if (particle < 0 || particle >= nav->P || !ncomp) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_stage_map: particle out of range");
-	hipSetDevice(nav->device);
+	enter(nav);
 	int rc = PHD_OK;
 	if (stage == PHD_STAGE_PRUNED) {
 		rc = fetch_map(nav, nav->h_sel[SEL_OUT], particle, ncomp);
@@ -1514,7 +1604,7 @@ int phd_resample(phd_navigator* nav, const double* weights, int nparticles, doub
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	if (nav->multi) nav = multi_shard0(nav);
 	if (nparticles < 1 || !weights || !sources) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_resample: bad arguments");
-	hipSetDevice(nav->device);
+	enter(nav);
 	HC(hipStreamSynchronize(nav->stream));
 	// (buffers of its own: the gathered-weight vector of a sharded handle is known to other shards by address)
 	double* d_w = nullptr;
@@ -1540,7 +1630,7 @@ int phd_particle_depleted(phd_navigator* nav, const double* weights, int npartic
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	if (nav->multi) nav = multi_shard0(nav);
 	if (nparticles < 1 || !weights || !depleted) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_particle_depleted: bad arguments");
-	hipSetDevice(nav->device);
+	enter(nav);
 	HC(hipStreamSynchronize(nav->stream));
 	double* d_w = nullptr;
 	int* d_tmp = nullptr;
@@ -1577,7 +1667,7 @@ int phd_timing_reset(phd_navigator* nav, uint8_t enabled)
 		multi_timing_reset(nav, enabled);
 		nav = multi_shard0(nav);
 	}
-	hipSetDevice(nav->device);
+	enter(nav);
 	hipStreamSynchronize(nav->stream);
 	nav->ntimers = 0;
 	nav->timing = enabled != 0;
@@ -1591,7 +1681,7 @@ int phd_last_timings(phd_navigator* nav, const char*** names, const double** ms)
 {
 	if (!nav) return 0;
 	if (nav->multi) nav = multi_shard0(nav);
-	hipSetDevice(nav->device);
+	enter(nav);
 	hipStreamSynchronize(nav->stream);
 	nav->tnames.clear();
 	nav->tms.clear();
@@ -1657,12 +1747,12 @@ static int ensure_sharded(phd_navigator* nav, bool need_send = true)
 	if (nav->sharded_ready) {
 		if (need_send && !nav->d_send) {   // (a handle first used without a send buffer: push-only hosts never need one)
 			const size_t rec = (size_t) 8 + (size_t) MIX_REC * nav->cap;
-			hipSetDevice(nav->device);
+			enter(nav);
 			HC(hipMalloc((void**) &nav->d_send, (size_t) nav->sendrecs * rec * 8));
 		}
 		return PHD_OK;
 	}
-	hipSetDevice(nav->device);
+	enter(nav);
 	const size_t rec = (size_t) 8 + (size_t) MIX_REC * nav->cap;
 	nav->plan.sendcap = nav->Pcap + PHD_MAX_DEVICES;
 	nav->recvrecs = nav->Pcap;
@@ -1713,7 +1803,7 @@ static int ensure_sharded(phd_navigator* nav, bool need_send = true)
 static int step_local(phd_navigator* nav, uint8_t onlymapping)
 {
 	if (nav->P < 1) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step_local: no particles");
-	hipSetDevice(nav->device);
+	enter(nav);
 	int rc = ensure_sharded(nav);
 	if (rc) return rc;
 	nav->sharded_used = true;
@@ -1748,7 +1838,7 @@ void* phd_device_local_weights(phd_navigator* nav)
 void* phd_device_global_weights(phd_navigator* nav, int world_particles)
 {
 	if (!nav || nav->multi || world_particles < 1) return nullptr;
-	hipSetDevice(nav->device);
+	enter(nav);
 	if (ensure_gw(nav, world_particles)) return nullptr;
 	return nav->d_gw;
 }
@@ -1758,7 +1848,7 @@ void* phd_device_global_weights(phd_navigator* nav, int world_particles)
 // weights taken as they are and resampling off. hostcounts: the plan also writes its counts to pinned host memory.
 static int step_global(phd_navigator* nav, int rank, int world_size, double u, uint8_t onlymapping, bool hostcounts, bool from_graw = false)
 {
-	hipSetDevice(nav->device);
+	enter(nav);
 	const int Pg = nav->P * world_size;
 	nav->last_world_particles = Pg;
 	nav->world = world_size; nav->rank = rank;
@@ -1815,7 +1905,7 @@ int phd_step_global_async(phd_navigator* nav, int rank, int world_size, double u
 void* phd_device_gather_buffer(phd_navigator* nav, int world_size)
 {
 	if (!nav || nav->multi || world_size < 1 || world_size > PHD_MAX_DEVICES) return nullptr;
-	hipSetDevice(nav->device);
+	enter(nav);
 	const int need = world_size * (nav->Pcap + 1);
 	if (need > nav->grawcap) {
 		if (hipStreamSynchronize(nav->stream) != hipSuccess) return nullptr;
@@ -1867,7 +1957,7 @@ int phd_migration_set_peers(phd_navigator* nav, void* const* recv_buffers, int r
 		tab[t] = (t == rank) ? nav->d_recv : (double*) recv_buffers[t];
 		if (!tab[t]) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_set_peers: the receive buffer of rank " + std::to_string(t) + " is NULL");
 	}
-	hipSetDevice(nav->device);
+	enter(nav);
 	HC(hipStreamSynchronize(nav->stream));
 	HC(hipMemcpy(nav->d_recv_tab, tab.data(), world_size * sizeof(double*), hipMemcpyHostToDevice));
 	nav->peers_set = true;
@@ -1881,7 +1971,7 @@ int phd_migration_ipc_open(phd_navigator* nav, const void* handles, int rank, in
 	if (!nav || !handles) return PHD_ERR_BAD_ARGUMENT;
 	MULTI_UNSUPPORTED(nav, "phd_migration_ipc_open");
 	if (world_size < 1 || world_size > PHD_MAX_DEVICES || rank < 0 || rank >= world_size) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_ipc_open: bad rank/world (at most 64 ranks)");
-	hipSetDevice(nav->device);
+	enter(nav);
 	for (void* q : nav->ipc_opened) hipIpcCloseMemHandle(q);
 	nav->ipc_opened.clear();
 	std::vector<void*> ptrs(world_size, nullptr);
@@ -1917,7 +2007,7 @@ int phd_migration_push_async(phd_navigator* nav)
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	MULTI_UNSUPPORTED(nav, "phd_migration_push_async");
 	if (!nav->sharded_ready || !nav->peers_set) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_push_async: no peers (phd_migration_ipc_open / phd_migration_set_peers, then phd_step_global_device_async)");
-	hipSetDevice(nav->device);
+	enter(nav);
 	StepBufs b = make_bufs(nav);
 	timer_begin(nav, T_PK);
 	hipLaunchKernelGGL(k_pack_particles, dim3(std::min(nav->plan.sendcap, 256)), dim3(256), 0, nav->stream, b, nav->plan, nav->world, (double*) nullptr,
@@ -1996,7 +2086,7 @@ int phd_test_migration_plan(phd_navigator* nav, const int32_t* gsrc, int particl
 	    !fslot || !send_dst || !nsend || !nrecv || !status) {
 		return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_test_migration_plan: sizes out of range (particles_per_rank <= max_particles, world_size <= 64)");
 	}
-	hipSetDevice(nav->device);
+	enter(nav);
 	int rc = ensure_sharded(nav);
 	if (rc) return rc;
 	HC(hipStreamSynchronize(nav->stream));
@@ -2040,7 +2130,7 @@ int phd_migration_plan(phd_navigator* nav, int rank, int world_size, int32_t* se
 	MULTI_UNSUPPORTED(nav, "phd_migration_plan");
 	if (world_size < 1 || rank < 0 || rank >= world_size || !send_counts || !recv_counts) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_plan: bad arguments");
 	if (!nav->plan_waiting || world_size != nav->world || rank != nav->rank) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_plan: call phd_step_global_async(rank, world_size) first");
-	hipSetDevice(nav->device);
+	enter(nav);
 	const int n = world_size;
 	volatile int* hc = nav->h_counts;
 	const auto t0 = std::chrono::steady_clock::now();
@@ -2095,7 +2185,7 @@ int phd_migration_pack_async(phd_navigator* nav)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	MULTI_UNSUPPORTED(nav, "phd_migration_pack_async");
-	hipSetDevice(nav->device);
+	enter(nav);
 	if (!nav->sharded_ready || nav->plan_on_device) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_pack_async: no plan known to the host (phd_step_global_async, phd_migration_plan first)");
 	if (nav->nsend == 0) return PHD_OK;   // (the per-rank host knows the counts)
 	StepBufs b = make_bufs(nav);
@@ -2110,7 +2200,7 @@ int phd_migration_pack_async(phd_navigator* nav)
 // the end of a sharded step: arrivals unpacked, small arrays gathered, roles rotated — all read from the device plan
 static int step_finish(phd_navigator* nav)
 {
-	hipSetDevice(nav->device);
+	enter(nav);
 	StepBufs b = make_bufs(nav);
 	int* sel_next = nav->d_sel + (nav->parity ^ 1) * SEL_STRIDE;
 	nav->d_res_slots = nav->d_mslot;
@@ -2139,7 +2229,7 @@ int phd_set_stream(phd_navigator* nav, void* stream, uint8_t lend)
 {
 	if (!nav) return PHD_ERR_BAD_ARGUMENT;
 	MULTI_UNSUPPORTED(nav, "phd_set_stream");
-	hipSetDevice(nav->device);
+	enter(nav);
 	HC(hipStreamSynchronize(nav->stream));
 	nav->stream = lend ? (hipStream_t) stream : nav->own_stream;   // a NULL lent stream is the legacy default stream
 	return PHD_OK;

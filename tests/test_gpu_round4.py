@@ -355,3 +355,32 @@ def test_deferred_replay_of_big_clusters_is_the_same_step(nav_mod, monkeypatch):
             assert all(np.array_equal(u, v) for u, v in zip(x, y))
     assert np.array_equal(a[2][0], b[2][0]) and np.array_equal(a[2][1], b[2][1])
     assert np.all(np.isfinite(a[2][1]))
+
+
+@pytest.mark.parametrize("shape,profile", [((256, 128, 32), "steady"), ((256, 128, 32), "survey"), ((96, 40, 20), "steady"), ((512, 64, 70), "steady")])
+def test_chain_ends_the_step_itself_as_the_separate_launch_does(nav_mod, monkeypatch, shape, profile):
+    """Small particle sets: the last workgroup of k_particle_chain to take its ticket runs k_normalise_resample's body (no launch
+    of its own). Weights, resampling sources, BestParticle, poses and maps after several un-frozen steps — resampled and not,
+    localising and mapping-only — are bit for bit those of the separate launch (PHD_FOLD_NR=0, read when a handle is created)."""
+    from monorfs_amd.synth import Frame
+    from test_gpu_round2 import make_nav
+    f = Frame(shape[0], shape[1], shape[2], 1002, weight_profile=profile)
+    results = []
+    for fold in ("1", "0"):
+        monkeypatch.setenv("PHD_FOLD_NR", fold)
+        nav, p = make_nav(nav_mod, f)
+        out = []
+        for k, u in enumerate((0.3, 0.8, 0.05, 0.6, 0.95)):
+            nav.OnlyMapping = (k == 3)
+            nav.SlamUpdate(None, f.z, u_resample=u)
+            src, resampled = nav.resample_sources()
+            out.append((nav.VehicleWeights.copy(), np.array(src).copy(), resampled, nav.BestParticle, [nav.MapModel(i) for i in (0, f.P // 2, f.P - 1)]))
+        results.append(out)
+        nav.close()
+    a, b = results
+    if profile == "steady":
+        assert any(s[2] for s in a)   # (the resampling branch was taken)
+    for (wa, sa, ra, ba, ma), (wb, sb, rb, bb, mb) in zip(a, b):
+        assert np.array_equal(wa, wb) and ra == rb and np.array_equal(sa, sb) and ba == bb
+        for x, y in zip(ma, mb):
+            assert all(np.array_equal(u, v) for u, v in zip(x, y))
