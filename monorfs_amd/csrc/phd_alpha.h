@@ -2198,7 +2198,10 @@ __device__ __forceinline__ void alpha_density_body(const DevParams& prm, const S
 		else {
 			double alpha = exp(a.setll[p] + ratio);         // :392
 			a.alpha[p] = alpha;
-			bout.weights[p] = bin.weights[p] * alpha;       // :335
+			const double wnew = bin.weights[p] * alpha;     // :335
+			// (tickets: written through to memory — k_normalise_resample on the other stream reads it without a launch boundary between)
+			if (a.tickets) __hip_atomic_store(&bout.weights[p], wnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			else bout.weights[p] = wnew;
 		}
 	}
 }
@@ -2209,6 +2212,10 @@ __global__ __launch_bounds__(256, PHD_DENS_WAVES) void k_alpha_density(const Dev
 	PHD_TL_BEGIN;
 	PHD_SET_PRIO(PHD_DENSE_PRIO);
 	alpha_density_body(prm, a, pool);
+	// (device-side ordering of the sub-range streams, phd_step_async: thread 0 wrote the particle's weight through to memory; once
+	// that store is acknowledged it takes the ticket k_normalise_resample counts. No fence: a device-scope release would write
+	// back the XCD's whole L2 — the other stream's kernels' lines with it — 2048 times a step)
+	if (a.tickets && threadIdx.x == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); atomicAdd(a.ticket, 1u); }
 	PHD_TL_END(4);
 }
 

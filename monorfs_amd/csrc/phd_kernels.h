@@ -19,6 +19,7 @@
 #define PHD_FLAG_EMIT_OVERFLOW   1   // corrected components did not fit emit_capacity
 #define PHD_FLAG_J_OVERFLOW      2   // map estimate larger than the landmark scratch
 #define PHD_FLAG_BIG_CLUSTER     4   // association cluster beyond the on-device solver's cap
+#define PHD_FLAG_ORDER_TIMEOUT   8   // a kernel that orders the sub-range streams on the device gave up waiting (see k_normalise_resample, k_gate)
 
 #define MIX_REC 10   // doubles per component record: w, m[3], P[6] (upper triangle)
 
@@ -133,7 +134,11 @@ struct StepBufs {
 	                     // mode: the unit count P C M is exact); 0: a visit whose 64 pairs all lie outside the gate is skipped
 	// k_normalise_resample folded into the one-launch chain (small particle sets): the workgroup that takes the last ticket runs it
 	int           fold_nr;      // 1: k_particle_chain ends the step itself
-	unsigned int* ticket;       // [1] workgroups of the launch that are through (the last one sets it back to 0)
+	unsigned int* ticket;       // [0] workgroups of the step's last per-particle launch(es) that are through (set back to 0 by whoever waited for them)
+	                            // [1] the number of the last step whose k_normalise_resample is through
+	int           tickets;      // 1: every workgroup of k_alpha_density publishes its weight and takes a ticket (device-side ordering of the two sub-range streams)
+	int           wait_tickets; // k_normalise_resample: wait for this many tickets first (0: the stream has ordered it)
+	unsigned int  done_value;   // k_normalise_resample: the step number it publishes in ticket[1] when through (0: none)
 	double        nr_u;         // the arguments k_normalise_resample would have got
 	int           nr_force, nr_skip, nr_frozen;
 	int*          nr_src;

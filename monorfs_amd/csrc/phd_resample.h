@@ -174,12 +174,19 @@ __device__ __forceinline__ void normalise_resample_body(const StepBufs& a, doubl
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = (int) blockDim.x, nw = nt >> 6;
 	PHD_STAMP_DECL;
 	PHD_STAMP(0);
+	// (one workgroup alone on the device: every dependent trip to memory is the kernel's time. The flag word, the bank roles and
+	// this thread's first weight — from all three banks, the role picks one — are requested together: one trip instead of three)
+	double spec0 = 0, spec1 = 0, spec2 = 0;
+	const bool spec = !gw && !a.defer && tid < P;
+	if (spec) { spec0 = a.bank[0].weights[tid]; spec1 = a.bank[1].weights[tid]; spec2 = a.bank[2].weights[tid]; }
+	const int flags_now = sel_next ? *a.flags : 0;
+	const int sel_out = a.sel[SEL_OUT];
 	if (tid == 0 && a.bigws_used && *a.bigws_used) *a.bigws_used = 0;   // the association slab is free again (every k_alpha_assoc of the step is over)
 	if (tid < 4 && a.biglist) a.biglist[(size_t) tid * a.bigstride] = 0;   // ... and the sub-ranges' lists of deferred particles are empty again
 	// A kernel of this step raised a flag (emit capacity, landmark scratch): what it wrote into the OUT bank is not a
 	// valid state. The step is dropped as a whole — the roles stay, nothing of the current state was touched — and the host
 	// finds the flag at its next phd_sync. (Every thread reads the same word, written by earlier launches.)
-	if (sel_next && *a.flags != 0) {
+	if (sel_next && flags_now != 0) {
 		if (tid < SEL_STRIDE) sel_next[tid] = a.sel[tid];
 		return;
 	}
@@ -211,7 +218,9 @@ __device__ __forceinline__ void normalise_resample_body(const StepBufs& a, doubl
 		return (i - c * CH) * LS + c;
 	};
 	if (use_lds) {
-		for (int i = tid; i < P; i += nt) lw[lpos(i)] = gwp[i];   // (global reads in whole lines; the scattered side is the LDS one)
+		// (global reads in whole lines; the scattered side is the LDS one)
+		if (spec) lw[lpos(tid)] = (sel_out == 0) ? spec0 : ((sel_out == 1) ? spec1 : spec2);
+		for (int i = spec ? tid + nt : tid; i < P; i += nt) lw[lpos(i)] = gwp[i];
 	}
 	__syncthreads();
 	PHD_STAMP(1);
@@ -506,9 +515,45 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
                                                              int* src, int* info, int* sel_next, int frozen, int* inslot)
 {
 	extern __shared__ __align__(16) double lw_nr[];   // [P] when use_lds
+	if (a.wait_tickets > 0) {
+		// Two sub-range streams, steps posted back to back (phd_step_async): this launch sits directly behind the k_alpha_density of
+		// ITS stream; the other stream's is ordered by count — every workgroup of both took a ticket behind a device-scope release of
+		// its weight. Everything waited for was submitted before this launch, on whatever queue; the wait is bounded (0.2 s of the
+		// 100 MHz counter: the step is then dropped with PHD_FLAG_ORDER_TIMEOUT).
+		if (threadIdx.x == 0) {
+			const long long t0 = wall_clock64();
+			// (relaxed loads: an acquire per poll would invalidate the L2 under the kernels still running)
+			while (__hip_atomic_load(a.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned) a.wait_tickets) {
+				if (wall_clock64() - t0 > 20000000LL) { atomicOr(a.flags, PHD_FLAG_ORDER_TIMEOUT); break; }
+				__builtin_amdgcn_s_sleep(32);
+			}
+			__hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the next step's tickets come behind this launch)
+		}
+		__syncthreads();
+		__threadfence();   // acquire in every wave: what the ticket holders published is what the loads below see
+	}
 	PHD_TL_BEGIN;
 	normalise_resample_body(a, gw, P, min_eff, u, force_resample, skip_normalise, use_lds, src, info, sel_next, frozen, inslot, lw_nr);
+	if (a.done_value) {
+		// ... and the other stream's next k_sweep waits for THIS launch by number (k_gate)
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (threadIdx.x == 0) { __threadfence(); __hip_atomic_store(a.ticket + 1, a.done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+	}
 #ifdef PHD_STAMPS
 	if (threadIdx.x == 0 && a.stamps && a.stamp_kernel == 199) { a.stamps[8] = (double) tl0_; a.stamps[9] = (double) wall_clock64(); }
 #endif
+}
+
+// The other sub-range stream's side of that ordering: one wave in front of its next k_sweep, through when k_normalise_resample
+// number `value` is (submitted before this launch; bounded like the wait above). The launch boundary behind it is the acquire.
+__global__ __launch_bounds__(64) void k_gate(const unsigned int* done, unsigned int value, int* flags)
+{
+	if (threadIdx.x == 0) {
+		const long long t0 = wall_clock64();
+		while ((int) (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - value) < 0) {
+			if (wall_clock64() - t0 > 20000000LL) { atomicOr(flags, PHD_FLAG_ORDER_TIMEOUT); break; }
+			__builtin_amdgcn_s_sleep(64);
+		}
+	}
 }

@@ -72,6 +72,10 @@ struct phd_navigator {
 	bool        pipe_ok = false;       // nothing was enqueued on `stream` since the last such step: the aux stream is ordered behind all of it
 	int         lagger = 1;            // which of the two streams (0 `stream`, 1 aux[0]) finishes the coming step last
 	hipEvent_t  ev_res = nullptr;      // k_normalise_resample is through (recorded on the stream that ran it)
+	int         device_order = 0;      // 1 (env PHD_DEVICE_ORDER): between such steps no event at all — k_normalise_resample counts the tickets of both
+	                                   // streams' k_alpha_density workgroups, the other stream's next k_sweep waits behind k_gate. Measured 0.2 % faster
+	                                   // than the events; two kernels that poll are not worth that by default
+	unsigned    step_seq = 0;          // number of the last step ended that way
 	bool sel_host_valid = false;       // h_sel mirrors the device-side bank roles without a round trip
 	int Pcap = 0, cap = 0, Mcap = 0, ecap = 0, Jcap = 0, cutcap = 0;
 	int P = 0, M = 0;
@@ -249,7 +253,7 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.born_count = nav->d_born_count; b.born_k = nav->d_born_k; b.born_mean = nav->d_born_mean;
 	b.alpha = nav->d_alpha; b.setll = nav->d_setll; b.flags = nav->d_flags; b.murty = nav->d_murty; b.jscratch = nav->d_jscratch;
 	b.bigws = nav->d_bigws; b.bigws_bytes = nav->bigws_bytes; b.bigws_used = nav->d_bigws_used;
-	b.fold_nr = 0; b.ticket = (unsigned int*) (nav->d_bigws_used + 1);
+	b.fold_nr = 0; b.ticket = (unsigned int*) (nav->d_bigws_used + 1); b.tickets = 0; b.wait_tickets = 0; b.done_value = 0;
 	b.nr_u = 0; b.nr_force = 0; b.nr_skip = 0; b.nr_frozen = 0; b.nr_src = nullptr; b.nr_info = nullptr; b.nr_sel_next = nullptr; b.nr_inslot = nullptr;
 	b.cand_count = nav->d_cand_count; b.denom = nav->d_denom;
 	b.cand = nav->d_cand; b.candcap = nav->candcap;
@@ -490,6 +494,10 @@ int check_flags(phd_navigator* nav)
 	if (f & PHD_FLAG_J_OVERFLOW) {
 		return nav->fail(PHD_ERR_CAPACITY, "map estimate larger than the landmark scratch (" + std::to_string(nav->Jcap) + ")");
 	}
+	if (f & PHD_FLAG_ORDER_TIMEOUT) {
+		return nav->fail(PHD_ERR_GENERIC, "a kernel that orders the handle's two streams on the device waited 0.2 s for work submitted before it (PHD_DEVICE_ORDER=0 "
+		                 "orders them with events instead); the step was dropped, the state is the one before it");
+	}
 	if (f & PHD_FLAG_BIG_CLUSTER) {
 		return nav->fail(PHD_ERR_ASSOCIATION, "a data-association cluster has more than " + std::to_string(MURTY_NBIG) + " rows, or the clusters beyond " +
 		                 std::to_string(MURTY_NMAX) + " rows used up the association workspace (" + std::to_string(nav->bigws_bytes >> 20) +
@@ -717,6 +725,7 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	ok = ok && hipEventCreateWithFlags(&nav->ev_fork, evflags) == hipSuccess;
 	ok = ok && hipEventCreateWithFlags(&nav->ev_res, evflags) == hipSuccess;
 	if (const char* e = getenv("PHD_PIPELINE")) nav->pipeline = atoi(e) != 0;
+	if (const char* e = getenv("PHD_DEVICE_ORDER")) nav->device_order = atoi(e) != 0;
 	if (const char* e = getenv("PHD_DEFER_BIG")) nav->defer_big = atoi(e) != 0;
 	if (const char* e = getenv("PHD_FUSE_EP")) nav->fuse_ep = atoi(e) != 0 ? 1 : 0;
 	if (const char* e = getenv("PHD_FUSE_SEP")) nav->fuse_sep = atoi(e) != 0 ? 1 : 0;
@@ -1343,18 +1352,35 @@ int phd_step_async(phd_navigator* nav, uint8_t onlymapping, double u_resample)
 			nav->lagger = 1;
 		}
 		hipStream_t L = nav->lagger ? nav->aux[0] : nav->stream, X = nav->lagger ? nav->stream : nav->aux[0];
+		// (on the device: a localising step whose densities run as k_alpha_density — that kernel's workgroups take the tickets)
+		const bool dev = nav->device_order && !onlymapping && !nav->defer_big;
+		b.tickets = dev ? 1 : 0;
 		rc = launch_map(nav, b, !onlymapping, nav->lagger);
 		if (rc) { nav->pipe_ok = false; return rc; }
 		b.defer = nav->last_defer;
-		HC(hipEventRecord(nav->ev_join[0], X));
-		HC(hipStreamWaitEvent(L, nav->ev_join[0], 0));
+		if (dev) {
+			nav->step_seq++;
+			if (nav->step_seq == 0) nav->step_seq = 1;
+			b.wait_tickets = nav->P;
+			b.done_value = nav->step_seq;
+		}
+		else {
+			HC(hipEventRecord(nav->ev_join[0], X));
+			HC(hipStreamWaitEvent(L, nav->ev_join[0], 0));
+		}
 		timer_begin(nav, T_NR, L);
 		rc = launch_normalise(nav, b, nullptr, nav->P, u_resample, onlymapping ? -1 : 0, onlymapping ? 1 : 0, nav->d_src, nav->d_info,
 		                      nav->d_sel + (nav->parity ^ 1) * SEL_STRIDE, L);
 		timer_end(nav, T_NR, L);
 		if (rc) { nav->pipe_ok = false; return rc; }
-		HC(hipEventRecord(nav->ev_res, L));
-		HC(hipStreamWaitEvent(X, nav->ev_res, 0));
+		if (dev) {
+			hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, X, b.ticket + 1, nav->step_seq, nav->d_flags);
+			HC(hipGetLastError());
+		}
+		else {
+			HC(hipEventRecord(nav->ev_res, L));
+			HC(hipStreamWaitEvent(X, nav->ev_res, 0));
+		}
 		nav->lagger ^= 1;
 		nav->pipe_ok = true;
 	}

@@ -384,3 +384,37 @@ def test_chain_ends_the_step_itself_as_the_separate_launch_does(nav_mod, monkeyp
         assert np.array_equal(wa, wb) and ra == rb and np.array_equal(sa, sb) and ba == bb
         for x, y in zip(ma, mb):
             assert all(np.array_equal(u, v) for u, v in zip(x, y))
+
+
+@pytest.mark.parametrize("mode", ["device", "events"])
+def test_steps_posted_back_to_back_end_on_the_stream_that_finishes_last(nav_mod, monkeypatch, mode):
+    """Two sub-range streams (1024 particles and more), phd_step_async after phd_step_async: no fork between the steps, the end of
+    the step behind the k_alpha_density of the stream that finishes last — ordered on the device (tickets + k_gate, the default) or
+    by events (PHD_DEVICE_ORDER=0). Twelve un-frozen steps, resampled and not, a mapping-only step and an upload in between: weights,
+    sources, BestParticle and maps bit for bit those of a handle that forks and joins around every step (PHD_PIPELINE=0)."""
+    from monorfs_amd.synth import Frame
+    from test_gpu_round2 import make_nav
+    f = Frame(1024, 48, 24, 1002, weight_profile="steady")
+    results = []
+    for env in ({"PHD_PIPELINE": "0"}, {"PHD_PIPELINE": "1", "PHD_DEVICE_ORDER": "1" if mode == "device" else "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        nav, p = make_nav(nav_mod, f)
+        nav.set_measurements(f.z)
+        out = []
+        for k, u in enumerate((0.3, 0.8, 0.05, 0.6, 0.95, 0.2, 0.5, 0.7, 0.1, 0.9, 0.4, 0.65)):
+            nav.OnlyMapping = (k == 4)
+            nav.step_async(u)
+            if k == 7:
+                nav.set_measurements(f.z[::-1].copy())   # (something else on the stream between two steps: the next one forks again)
+            if k in (2, 9, 11):
+                nav.sync()
+                src, resampled = nav.resample_sources()
+                out.append((nav.VehicleWeights.copy(), np.array(src).copy(), resampled, nav.BestParticle, [nav.MapModel(i) for i in (0, 511, 512, 1023)]))
+        results.append(out)
+        nav.close()
+    a, b = results
+    for (wa, sa, ra, ba, ma), (wb, sb, rb, bb, mb) in zip(a, b):
+        assert np.array_equal(wa, wb) and ra == rb and np.array_equal(sa, sb) and ba == bb
+        for x, y in zip(ma, mb):
+            assert all(np.array_equal(u, v) for u, v in zip(x, y))
