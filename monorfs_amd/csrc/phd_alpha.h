@@ -2019,7 +2019,9 @@ __global__ __launch_bounds__(256, 4) void k_quasi_setll(const DevParams prm, con
 // with v(.) the full, ungated mixture density (Map.Evaluate(point), Map.cs:192-202) and m_j the landmarks of
 // the map estimate left in HBM by k_alpha_assoc. Landmark per lane, component tiles broadcast from LDS.
 // =================================================================================================
+#ifndef DENS_JL
 #define DENS_JL 128   // landmarks whose partial sums stay in LDS
+#endif
 #define DENS_REC 12   // gauss_record + the weight ratio of the component's surviving misdetection copy (+ 1: records stay 16-byte aligned)
 
 #ifndef DENS_TILE
