@@ -315,7 +315,12 @@ void timer_begin(phd_navigator* nav, const char* name, hipStream_t st = nullptr,
 		Timer t;
 		t.name = name;
 		t.t0_from = -1;
-		if (hipEventCreate(&t.t0) != hipSuccess || hipEventCreate(&t.t1) != hipSuccess) { nav->timing = false; return; }
+		// (timing only, read after a stream synchronisation: no system-scope fence when they are recorded — the fence of a default event
+		// writes the caches back in front of every timed launch and is part of what the step then costs)
+		if (hipEventCreateWithFlags(&t.t0, hipEventDisableSystemFence) != hipSuccess || hipEventCreateWithFlags(&t.t1, hipEventDisableSystemFence) != hipSuccess) {
+			(void) hipGetLastError();
+			if (hipEventCreate(&t.t0) != hipSuccess || hipEventCreate(&t.t1) != hipSuccess) { nav->timing = false; return; }
+		}
 		nav->timers.push_back(t);
 	}
 	Timer& t = nav->timers[nav->ntimers];
