@@ -220,7 +220,14 @@ __device__ __forceinline__ void normalise_resample_body(const StepBufs& a, doubl
 	if (use_lds) {
 		// (global reads in whole lines; the scattered side is the LDS one)
 		if (spec) lw[lpos(tid)] = (sel_out == 0) ? spec0 : ((sel_out == 1) ? spec1 : spec2);
-		for (int i = spec ? tid + nt : tid; i < P; i += nt) lw[lpos(i)] = gwp[i];
+		// (four loads in flight per thread: one element per trip to memory made the staging of 16 384 weights sixteen trips)
+		for (int i0 = spec ? tid + nt : tid; i0 < P; i0 += 4 * nt) {
+			double v[4];
+#pragma unroll
+			for (int q = 0; q < 4; q++) v[q] = (i0 + q * nt < P) ? gwp[i0 + q * nt] : 0.0;
+#pragma unroll
+			for (int q = 0; q < 4; q++) if (i0 + q * nt < P) lw[lpos(i0 + q * nt)] = v[q];
+		}
 	}
 	__syncthreads();
 	PHD_STAMP(1);
