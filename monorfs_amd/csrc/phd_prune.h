@@ -34,7 +34,9 @@
 #ifndef PRUNE_NB
 #define PRUNE_NB 2048   // buckets of the spatial hash (16-bit counters, two per LDS word; 4096 until round 4: half of them, and the bounds below as
 #endif                  // float32, take MaxQuantity 1024's working set from 58.7 to 50.5 KB — three workgroups per CU instead of two on config S)
+#ifndef PRUNE_HEAVY
 #define PRUNE_HEAVY 32  // a row with more candidates than this is searched by a whole wave
+#endif
 #define PRUNE_ROW 12    // doubles per row of the sorted slab: w, m[3], P[6] (a component record), canonical index, spare
 
 struct PruneLds {
