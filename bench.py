@@ -32,10 +32,22 @@ FP64_SPEC_TFLOPS = 78.6        # the datasheet FP64 vector rate (4 cycles per wa
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 # SURVEY §8d's protocol is ">= 20 warm + >= 100 timed steps": the first steps behind the creation of a handle run slower than
 # the steady state (the device comes out of idle). Round 4, 20 timed steps behind 5 warm-up steps: 0.669 ms per step with 20 steps
-# rolled first, 0.653 with 60, 0.653 with 150, 0.656 with 400 (200 timed steps: 0.647 either way; scripts/r4_preroll.sh). The state
+# rolled first, 0.653 with 60, 0.653 with 150, 0.656 with 400 (200 timed steps: 0.647 either way; round 4). The state
 # is therefore rolled this many untimed steps BEFORE the --warmup steps (reported as "preroll_steps"; 40 ms of device time); the
 # timed region is still exactly --steps steps between two barriers.
 PREROLL_STEPS = int(os.environ.get("PHD_BENCH_PREROLL", "60"))
+
+
+def committed_source(relpath):
+    """provenance of a figure copied from a committed profile file rather than measured by this run (the driver's run collects
+    no PMC counters): the file and its git blob hash (= `git hash-object <file>`, computed here: the GPU box holds no .git)"""
+    import hashlib
+    try:
+        data = open(os.path.join(ROOT, relpath), "rb").read()
+        blob = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+    except Exception:
+        blob = None
+    return {"file": relpath, "git_blob": blob, "measured_in_this_run": False}
 
 
 def parse():
@@ -654,7 +666,8 @@ def main():
             alg_bytes = 160.0 * particles_per_launch * Cc   # 80 B/component read + 80 B written, per particle
             achieved = alg_bytes / (src[dom] * 1e-3) / 1e9
             traffic = None
-            for tname in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+            traffic_source = None
+            for tname in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json"):
                 tfile = os.path.join(ROOT, "profiles", tname)
                 if os.path.exists(tfile):
                     try:
@@ -662,6 +675,7 @@ def main():
                     except Exception:
                         traffic = None
                     if traffic is not None:
+                        traffic_source = committed_source("profiles/" + tname)
                         if not iso and per_step[dom] > 1 and not tname.startswith("r01"):
                             traffic = traffic / per_step[dom]   # r02 figures are per whole-range launch
                         break
@@ -671,7 +685,7 @@ def main():
             per_kernel = {k: {"kernel_ms": src[k], "frac": 160.0 * per_launch_particles[k] * Cc / (src[k] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                           for k in src if k.startswith("k_") and src[k] > 0 and k != "k_normalise_resample"}   # (one workgroup for all particles: no per-particle stream)
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "per_kernel": per_kernel,
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "per_kernel": per_kernel,
                                "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": src[dom],
                                "particles_per_launch": particles_per_launch,
                                "launches_per_step": 1 if iso else per_step[dom],
@@ -688,7 +702,7 @@ def main():
             # The step is bound by vector-ALU issue, not by HBM: the wave-level VALU instructions of one
             # step (SQ_INSTS_VALU of the committed profile, per particle) against the rate at which the chip sustains
             # FP64 FMAs (scripts/probes/fp64_clock.hip: 59.6 TFLOP/s = 4.66e11 wave instructions/s at four waves per SIMD).
-            for vname in ("r04_valu_insts.json", "r03_valu_insts.json", "r02_valu_insts.json", "r01_valu_insts.json"):
+            for vname in ("r05_valu_insts.json", "r04_valu_insts.json", "r03_valu_insts.json", "r02_valu_insts.json", "r01_valu_insts.json"):
                 vfile = os.path.join(ROOT, "profiles", vname)
                 if not os.path.exists(vfile):
                     continue
@@ -703,9 +717,10 @@ def main():
                                              "spec_wave_instructions_per_s": spec, "bound_ms_at_spec": insts / spec * 1e3, "frac_at_spec": insts / spec * 1e3 / ms,
                                              "flop_model": {"flop_per_update": 60, "tflops_delivered": 60.0 * P * Cc * M / (ms * 1e-3) / 1e12,
                                                             "frac_of_fp64_vector_peak": 60.0 * P * Cc * M / (ms * 1e-3) / 1e12 / FP64_SPEC_TFLOPS},
-                                             "in_kernel_clock_mhz": {"k_sweep": 2375, "v_fma_f64 loop at 4 waves per SIMD": 2144,
+                                             "in_kernel_clock_mhz": {"k_sweep": 2375, "v_fma_f64 loop at 4 waves per SIMD": 2144, "measured_in_this_run": False,
                                                                      "source": "profiles/r04_sweep_clock.txt, profiles/r04_fp64_clock.txt (s_memtime / s_memrealtime)"},
-                                             "source": "profiles/%s (rocprofv3 SQ_INSTS_VALU), profiles/r04_fp64_clock.txt" % vname}
+                                             "source": "profiles/%s (rocprofv3 SQ_INSTS_VALU), profiles/r04_fp64_clock.txt" % vname,
+                                             "valu_source": committed_source("profiles/" + vname)}
                         break
                 except Exception:
                     pass

@@ -216,14 +216,15 @@ int phd_map(phd_navigator* nav, int particle, int* ncomp,
  * host applies it to its own per-particle objects (trajectories). `resampled` <- 0/1.           */
 const int32_t* phd_resample_sources(phd_navigator* nav, int* length, uint8_t* resampled);
 
-/* Stage-level entry points for the unit KATs (PHDNavigator public methods). Each acts on one
- * particle of the handle's state; `phd_map`-style getters read the result back.
- *   phd_predict       ≙ PredictConditional (PHDNavigator.cs:793-819): state map -> predicted
- *   phd_correct       ≙ CorrectConditional (:829-906) fused with the MinWeight cut of PruneModel
- *   phd_prune         ≙ PruneModel (:913-948)
- *   phd_weight_alpha  ≙ WeightAlpha (:373-393)
- * `phd_stage_run` runs predict→correct→prune(→alpha) on every particle without the weight
- * normalisation / resampling, leaving per-stage results readable through phd_stage_map.          */
+/* Stage-level entry points for the unit KATs (the stages behind PHDNavigator's public methods).
+ *   phd_stage_run(z, with_alpha)  runs predict -> correct -> prune (-> alpha) on EVERY particle of the handle's state, without
+ *                                 the weight normalisation / resampling, and leaves each stage's result on the device:
+ *   phd_stage_map(stage, particle) reads one particle's mixture after that stage (phd_map's conventions):
+ *       PHD_STAGE_PREDICTED  ≙ PredictConditional (PHDNavigator.cs:793-819): state map -> predicted (prior + births)
+ *       PHD_STAGE_CORRECTED  ≙ CorrectConditional (:829-906) fused with the MinWeight cut of PruneModel, unsorted
+ *       PHD_STAGE_PRUNED     ≙ PruneModel (:913-948)
+ *   phd_stage_alpha()        ≙ WeightAlpha (:373-393), one value per particle
+ *   phd_stage_setloglik()    ≙ SetLogLikelihood (:462-515), one value per particle                                        */
 #define PHD_STAGE_PREDICTED 0
 #define PHD_STAGE_CORRECTED 1   /* corrected components with weight >= MinWeight, unsorted */
 #define PHD_STAGE_PRUNED    2

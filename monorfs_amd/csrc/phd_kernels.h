@@ -256,6 +256,8 @@ __global__ __launch_bounds__(256, 1) void k_particle_chain(const DevParams prm, 
 	}
 }
 
+#ifdef PHD_WITH_FUSE_SEP   // (a measured-and-dropped variant, DESIGN §4: compiled only into diagnostic builds, -DPHD_WITH_FUSE_SEP; the product
+                           // library carries neither its four instantiations nor the switch)
 // k_sweep, k_emit_finish and k_prune_merge as ONE launch on a full machine (environment PHD_FUSE_SEP=1): the first three bodies
 // of the chain above at k_sweep's own register budget (four workgroups per CU), k_alpha_assoc and k_alpha_density behind it as
 // launches of their own (compiled into one kernel with the others they cost occupancy: 245 registers). The workgroups of a CU
@@ -270,6 +272,7 @@ __global__ __launch_bounds__(256, 4) void k_sweep_emit_prune(const DevParams prm
 	__syncthreads();
 	prune_merge_body(prm, a, cutcap, smem);
 }
+#endif
 
 // Test surface (phd_stage_map, PHD_STAGE_CORRECTED): the emitted list carries no mean / covariance for the misdetection
 // copies (k_sweep writes their weight and index only); this fills them in from the predicted components.

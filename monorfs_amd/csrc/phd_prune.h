@@ -201,7 +201,7 @@ __device__ __forceinline__ unsigned int prune_next32(double w, int sbits)
 	return (unsigned int) ((((unsigned long long) __double_as_longlong(w) << 1) << (32 - sbits)) >> 32);
 }
 
-__device__ __forceinline__ void prune_merge_body(const DevParams& prm, const StepBufs& a, int cutcap, double* smem)
+__device__ __forceinline__ void prune_merge_body(const DevParams& prm, const StepBufs& a, int cutcap, double* smem, long long tk0 = 0)
 {
 	const PruneLds lay = prune_lds(cutcap);
 	const int cc = (cutcap + 1) & ~1, NS = lay.NS;
@@ -1165,6 +1165,9 @@ PHD_REF_ARITH
 	PHD_STAMP(5);
 	if (tid == 0) vout.count[p] = nsurv_before;
 	PHD_STAMP_FLUSH(2, 12);
+#ifdef PHD_STAMPS   // (the fused launch: cycles of the emit body in front of this one, slot 15)
+	if (tid == 0 && a.stamps && a.stamp_kernel == 2 && tk0) a.stamps[(size_t) p * 16 + 15] = (double) (stamp_[0] - tk0);
+#endif
 }
 
 #ifndef PHD_PRUNE_WAVES
@@ -1184,8 +1187,13 @@ __global__ __launch_bounds__(256, PHD_PRUNE_WAVES) void k_emit_prune(const DevPa
 	extern __shared__ __align__(16) double smem[];
 	PHD_TL_BEGIN;
 	PHD_SET_PRIO(PHD_LAT_PRIO);
+#ifdef PHD_STAMPS
+	const long long tk0 = clock64();
+#else
+	const long long tk0 = 0;
+#endif
 	emit_finish_body(prm, a, smem);
 	__syncthreads();   // (workgroup scope: what this workgroup's waves stored is visible to its loads behind the barrier)
-	prune_merge_body(prm, a, cutcap, smem);
+	prune_merge_body(prm, a, cutcap, smem, tk0);
 	PHD_TL_END(2);
 }

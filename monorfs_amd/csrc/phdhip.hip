@@ -60,7 +60,7 @@ struct phd_navigator {
 	int         fuse_ep = -1;          // k_emit_finish and k_prune_merge as one launch (k_emit_prune): -1 = for frames of up to 64 measurements (measured on
 	                                   // two streams: config B 0.677 -> 0.667 ms survey, 0.634 -> 0.615 steady; config S, 128 measurements, 3.67 -> 3.85:
 	                                   // its Kalman path is long and pays for the 128 registers); environment PHD_FUSE_EP = 0 / 1 forces
-	int         fuse_sep = 0;          // environment PHD_FUSE_SEP=1: k_sweep, k_emit_finish and k_prune_merge as one launch
+	int         fuse_sep = 0;          // builds with -DPHD_WITH_FUSE_SEP only, environment PHD_FUSE_SEP=1: k_sweep, k_emit_finish and k_prune_merge as one launch
 	int         last_defer = 0;        // the last launch_map left alpha open (k_normalise_resample / k_push_weights / k_alpha_combine finish it)
 	int*        d_biglist = nullptr;   // [MAXSPLIT][Pcap + 2]
 	double*     d_ratio = nullptr;     // [Pcap]
@@ -394,6 +394,7 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha, 
 		const int n = (int) ((long long) P * (s + 1) / S) - b.p0;
 		if (n <= 0) continue;
 		hipStream_t st = s == 0 ? nav->stream : nav->aux[s - 1];
+#ifdef PHD_WITH_FUSE_SEP
 		if (nav->fuse_sep) {
 			const size_t ld3 = std::max(std::max(lp, (size_t) EMIT_LDS_DOUBLES * 8), (size_t) SweepLds<ZB>::doubles * 8);
 			timer_begin(nav, T_SEP, st);
@@ -401,7 +402,9 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha, 
 			else hipLaunchKernelGGL(k_sweep_emit_prune<ZB>, dim3(n), dim3(256), ld3, st, nav->dp, b, nav->cutcap);
 			timer_end(nav, T_SEP, st);
 		}
-		else {
+		else
+#endif
+		{
 		timer_begin(nav, T_SW, st);
 		if (ZB == 1 && nav->M <= 32) hipLaunchKernelGGL((k_sweep<1, true>), dim3(n), dim3(256), 0, st, nav->dp, b);
 		else hipLaunchKernelGGL(k_sweep<ZB>, dim3(n), dim3(256), 0, st, nav->dp, b);
@@ -723,17 +726,29 @@ phd_navigator* phd_create(const phd_params* params, int device)
 		if (m == 0) evflags = hipEventDisableTiming;
 		if (m == 1) evflags = hipEventDisableTiming | hipEventReleaseToDevice;
 	}
+	// (a runtime that refuses the fence-less flag gets plain untimed events: slower boundaries, the same order)
+	auto ev_create = [&](hipEvent_t* ev, unsigned flags) {
+		if (hipEventCreateWithFlags(ev, flags) == hipSuccess) return true;
+		(void) hipGetLastError();
+		return hipEventCreateWithFlags(ev, hipEventDisableTiming) == hipSuccess;
+	};
 	for (int i = 0; i < phd_navigator::MAXSPLIT - 1; i++) {
 		ok = ok && hipStreamCreateWithFlags(&nav->aux[i], hipStreamNonBlocking) == hipSuccess;
-		ok = ok && hipEventCreateWithFlags(&nav->ev_join[i], evflags) == hipSuccess;
+		ok = ok && ev_create(&nav->ev_join[i], evflags);
 	}
-	ok = ok && hipEventCreateWithFlags(&nav->ev_fork, evflags) == hipSuccess;
-	ok = ok && hipEventCreateWithFlags(&nav->ev_res, evflags) == hipSuccess;
+	// ev_fork keeps the default (system-scope) release: it is recorded exactly when something ELSE preceded the step on the
+	// handle's stream — typically the host-to-device copy of phd_set_measurements — and is then the only link between that copy
+	// and the aux stream's k_sweep. It is off the back-to-back path (phd_step_async behind phd_step_async records no fork), so its
+	// 5 us do not touch the steady state.
+	ok = ok && ev_create(&nav->ev_fork, hipEventDisableTiming);
+	ok = ok && ev_create(&nav->ev_res, evflags);
 	if (const char* e = getenv("PHD_PIPELINE")) nav->pipeline = atoi(e) != 0;
 	if (const char* e = getenv("PHD_DEVICE_ORDER")) nav->device_order = atoi(e) != 0;
 	if (const char* e = getenv("PHD_DEFER_BIG")) nav->defer_big = atoi(e) != 0;
 	if (const char* e = getenv("PHD_FUSE_EP")) nav->fuse_ep = atoi(e) != 0 ? 1 : 0;
+#ifdef PHD_WITH_FUSE_SEP
 	if (const char* e = getenv("PHD_FUSE_SEP")) nav->fuse_sep = atoi(e) != 0 ? 1 : 0;
+#endif
 	if (const char* e = getenv("PHD_NBIG")) nav->nbig = std::max(1, atoi(e));
 	if (const char* e = getenv("PHD_SPLIT")) nav->nsplit = std::max(0, atoi(e));
 	if (const char* e = getenv("PHD_CHAIN_MAX")) nav->chain_max = std::max(0, atoi(e));
@@ -802,11 +817,13 @@ phd_navigator* phd_create(const phd_params* params, int device)
 		if (lp > lim.prune) {
 			ok = ok && hipFuncSetAttribute((const void*) k_prune_merge, hipFuncAttributeMaxDynamicSharedMemorySize, lp) == hipSuccess;
 			ok = ok && hipFuncSetAttribute((const void*) k_emit_prune, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lp, (int) (EMIT_LDS_DOUBLES * 8))) == hipSuccess;
+#ifdef PHD_WITH_FUSE_SEP
 			const int l3[3] = {std::max(lp, (int) (SweepLds<1>::doubles * 8)), std::max(lp, (int) (SweepLds<2>::doubles * 8)), std::max(lp, (int) (SweepLds<4>::doubles * 8))};
 			ok = ok && hipFuncSetAttribute((const void*) k_sweep_emit_prune<1>, hipFuncAttributeMaxDynamicSharedMemorySize, l3[0]) == hipSuccess;
 			ok = ok && hipFuncSetAttribute((const void*) k_sweep_emit_prune<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, l3[0]) == hipSuccess;
 			ok = ok && hipFuncSetAttribute((const void*) k_sweep_emit_prune<2>, hipFuncAttributeMaxDynamicSharedMemorySize, l3[1]) == hipSuccess;
 			ok = ok && hipFuncSetAttribute((const void*) k_sweep_emit_prune<4>, hipFuncAttributeMaxDynamicSharedMemorySize, l3[2]) == hipSuccess;
+#endif
 			lim.prune = lp;
 		}
 		const int la[3] = {alpha_lds(64, nav->cutcap).bytes, alpha_lds(128, nav->cutcap).bytes, alpha_lds(256, nav->cutcap).bytes};
@@ -2003,9 +2020,15 @@ int phd_migration_ipc_open(phd_navigator* nav, const void* handles, int rank, in
 	MULTI_UNSUPPORTED(nav, "phd_migration_ipc_open");
 	if (world_size < 1 || world_size > PHD_MAX_DEVICES || rank < 0 || rank >= world_size) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_ipc_open: bad rank/world (at most 64 ranks)");
 	enter(nav);
+	// Work in flight on the stream may still store into the mappings of an earlier call: it ends first. From here until
+	// phd_migration_set_peers has filled the table again the handle has NO peers — a failure below leaves it that way
+	// (phd_step_global_device_async / phd_migration_push_async then refuse), never with a table of closed mappings.
+	HC(hipStreamSynchronize(nav->stream));
+	nav->peers_set = false;
 	for (void* q : nav->ipc_opened) hipIpcCloseMemHandle(q);
 	nav->ipc_opened.clear();
 	std::vector<void*> ptrs(world_size, nullptr);
+	std::vector<void*> opened;
 	for (int t = 0; t < world_size; t++) {
 		if (t == rank) continue;
 		hipIpcMemHandle_t h;
@@ -2014,13 +2037,20 @@ int phd_migration_ipc_open(phd_navigator* nav, const void* handles, int rank, in
 		const hipError_t e = hipIpcOpenMemHandle(&q, h, hipIpcMemLazyEnablePeerAccess);
 		if (e != hipSuccess) {
 			(void) hipGetLastError();
+			for (void* o : opened) hipIpcCloseMemHandle(o);   // what this attempt opened
 			return nav->fail(PHD_ERR_DEVICE, "phd_migration_ipc_open: the receive buffer of rank " + std::to_string(t) + " cannot be opened: " + hipGetErrorString(e) +
 			                 " (the ranks' GPUs must reach each other peer to peer; HSA_ENABLE_IPC_MODE_LEGACY=0 on this pool)");
 		}
-		nav->ipc_opened.push_back(q);
+		opened.push_back(q);
 		ptrs[t] = q;
 	}
-	return phd_migration_set_peers(nav, ptrs.data(), rank, world_size);
+	const int rc = phd_migration_set_peers(nav, ptrs.data(), rank, world_size);
+	if (rc) {
+		for (void* o : opened) hipIpcCloseMemHandle(o);
+		return rc;
+	}
+	nav->ipc_opened = opened;
+	return PHD_OK;
 }
 
 // 1: the receive buffer is fine-grained device memory (coherent for the peers storing into it); 0: an ordinary allocation

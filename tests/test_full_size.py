@@ -222,3 +222,67 @@ def test_sharded_step_after_a_single_handle_resampling():
         assert all(np.array_equal(x, y) for x, y in zip(a.MapModel(g), b.MapModel(g)))
     a.close()
     b.close()
+
+
+def _state_of(nav, particles):
+    src, res = nav.resample_sources()
+    return {"w": nav.VehicleWeights, "src": src, "res": res, "best": nav.BestParticle,
+            "maps": [nav.MapModel(int(i)) for i in particles]}
+
+
+@pytest.mark.parametrize("cfg,profile", [("B", "survey"), ("B", "steady"), ("S", "survey"), ("S", "steady")])
+def test_timed_mode_equals_the_gated_mode(cfg, profile):
+    """The mode `bench.py` times — phd_set_all_pairs(1) + phd_set_frozen(1), the default two-stream split, steps posted back
+    to back — against the default gated mode on the same frame: the gate only selects what is summed
+    (PHDNavigator.cs:882-890; a masked pair adds an exact zero), so particle weights, resampling decision and sources,
+    BestParticle and sampled maps must be BIT-identical after a SlamUpdate, and alpha, the set log-likelihood and the pruned
+    maps of run_stages too. The oracle sample of test_full_size_properties_and_sample is repeated in all-pairs mode."""
+    gated, p, f = setup(cfg, profile)
+    timed, _, _ = setup(cfg, profile)
+    timed.set_measurements(f.z)
+    timed.set_frozen(True)
+    timed.set_all_pairs(True)
+    rng = np.random.default_rng(5)
+    sample = rng.choice(f.P, 3, replace=False)
+    # one SlamUpdate in the default mode | five steps posted back to back in the timed mode (frozen: each sees the same input)
+    gated.SlamUpdate(None, f.z, u_resample=0.41)
+    for _ in range(5):
+        timed.step_async(0.41)
+    timed.sync()
+    a, b = _state_of(gated, sample), _state_of(timed, sample)
+    assert a["res"] == b["res"] and a["best"] == b["best"]
+    assert np.array_equal(a["src"], b["src"]), "resampling sources differ between the gated and the all-pairs mode"
+    assert np.array_equal(a["w"], b["w"]), "particle weights differ between the gated and the all-pairs mode"
+    for i, ma, mb in zip(sample, a["maps"], b["maps"]):
+        assert all(np.array_equal(x, y) for x, y in zip(ma, mb)), "map of particle %d" % i
+    # the timed mode's synchronous entry point too (what `ms_per_synchronous_update` times)
+    timed.SlamUpdate(None, f.z, u_resample=0.41)
+    c = _state_of(timed, sample)
+    assert np.array_equal(a["w"], c["w"]) and np.array_equal(a["src"], c["src"])
+    gated.close()
+    # stage by stage, all-pairs | gated, from the same (frozen: untouched) state
+    gated, _, _ = setup(cfg, profile)
+    gated.run_stages(f.z, with_alpha=True)
+    timed.run_stages(f.z, with_alpha=True)
+    assert np.array_equal(gated.WeightAlpha(), timed.WeightAlpha()), "alpha differs between the modes"
+    assert np.array_equal(gated.SetLogLikelihood(), timed.SetLogLikelihood())
+    alpha = timed.WeightAlpha()
+    for i in sample:
+        i = int(i)
+        for stage in ("PredictConditional", "CorrectConditional", "PruneModel"):
+            ga, ta = getattr(gated, stage)(i), getattr(timed, stage)(i)
+            if stage == "CorrectConditional":   # (an unsorted list: its order is that of the queue's atomics — the same entries, bit for bit)
+                ga, ta = (tuple(x[np.lexsort((m[1][:, 2], m[1][:, 1], m[1][:, 0], m[0]))] for x in m) for m in (ga, ta))
+            assert all(np.array_equal(x, y) for x, y in zip(ga, ta)), "%s[%d]" % (stage, i)
+        # the oracle on this particle, against the all-pairs run
+        pw, pm, pc = timed.PruneModel(i)
+        pred = orc.predict(p, f.poses[i], f.z, f.map(i))
+        opr = orc.prune(p, orc.correct(p, f.poses[i], f.z, pred))
+        assert len(opr[0]) == len(pw)
+        assert np.allclose(pw, opr[0], rtol=1e-7) and np.allclose(pm, opr[1], rtol=1e-7, atol=1e-11)
+        iu = np.triu_indices(3)
+        assert np.allclose(pc[:, iu[0], iu[1]], opr[2][:, iu[0], iu[1]], rtol=1e-7, atol=1e-13)
+        al, _ = orc.weight_alpha(p, f.poses[i], f.z, pred, opr)
+        assert np.isclose(alpha[i], al, rtol=1e-6, atol=0)
+    gated.close()
+    timed.close()

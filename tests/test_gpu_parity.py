@@ -80,10 +80,28 @@ CASES = [
 
 @pytest.mark.parametrize("P,C,M,seed,profile,over", CASES)
 def test_stage_parity(nav_mod, P, C, M, seed, profile, over):
+    stage_parity(nav_mod, P, C, M, seed, profile, over)
+
+
+@pytest.mark.parametrize("chain_max", [None, 0])
+@pytest.mark.parametrize("P,C,M,seed,profile,over", [CASES[1], (6, 130, 32, 12, "steady", {}), CASES[2], CASES[3], CASES[4], CASES[8]])
+def test_stage_parity_in_the_timed_mode(nav_mod, monkeypatch, chain_max, P, C, M, seed, profile, over):
+    """the same stages against the oracle with phd_set_all_pairs(1) + phd_set_frozen(1) — the mode bench.py times —, through
+    the one-launch chain (the default at these sizes) and through the separate kernels on two streams (PHD_CHAIN_MAX=0)"""
+    if chain_max is not None:
+        monkeypatch.setenv("PHD_CHAIN_MAX", str(chain_max))
+        monkeypatch.setenv("PHD_SPLIT", "2")
+    stage_parity(nav_mod, P, C, M, seed, profile, over, timed_mode=True)
+
+
+def stage_parity(nav_mod, P, C, M, seed, profile, over, timed_mode=False):
     f = Frame(P, C, M, seed, weight_profile=profile) if C > 0 else Frame(P, 1, M, seed, weight_profile="survey")
     if C == 0:
         f.counts[:] = 0
     nav, p = make_nav(nav_mod, f, **over)
+    if timed_mode:
+        nav.set_frozen(True)
+        nav.set_all_pairs(True)
     nav.run_stages(f.z, with_alpha=True)
     alpha = nav.WeightAlpha()
     setll = nav.SetLogLikelihood()
