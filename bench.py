@@ -68,6 +68,11 @@ def parse():
                     help="how the particle weights meet (sharded step): allgather = RCCL all-gather of P + 1 doubles per rank (SURVEY 8e's recommendation, the default); "
                          "allreduce = the north star's wording, one RCCL all-reduce(sum) over the zero-padded global vector (every element has one non-zero "
                          "contributor, so the result is the gathered vector, bit for bit)")
+    ap.add_argument("--landing", default="flags", choices=["flags", "allreduce"],
+                    help="sharded step, how a receiver learns that the migrating particles have landed: flags = the senders leave a step-stamped word "
+                         "behind their records in the receiver's fine-grained buffer and k_finish_sharded waits for it on the device — ONE collective per "
+                         "step, the weights (round 5, the default; falls back to allreduce when a rank has no fine-grained buffer); allreduce = a one-word "
+                         "RCCL all-reduce on the stream between push and unpack (rounds 3 - 4)")
     ap.add_argument("--host-plan", action="store_true",
                     help="sharded step as in round 3: the host waits for the plan's split sizes and moves the migrating particles with all_to_all_single "
                          "(default: no host wait — peer stores through IPC-opened receive buffers, a one-word all-reduce as the landing barrier)")
@@ -353,7 +358,16 @@ def main():
             graw = torch.as_tensor(DevArray(lib.phd_device_gather_buffer(h, world), world * (P + 1)), device="cuda")
             lw1 = torch.as_tensor(DevArray(lw_ptr, P + 1), device="cuda")
             token = torch.zeros(1, dtype=torch.float32, device="cuda")
-            sharded_info = {"plan": "device", "migration": "peer stores into IPC-opened receive buffers, one-word all-reduce as the landing barrier",
+            # the landing flags need fine-grained receive buffers on EVERY rank (a peer's store must be visible while the receiver's
+            # kernel runs): agreed between the ranks, like the IPC path itself
+            fg = torch.tensor([1 if lib.phd_migration_recv_is_finegrained(h) == 1 else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(fg, op=dist.ReduceOp.MIN)
+            if args.landing == "flags" and int(fg.item()) != 1:
+                args.landing = "allreduce"
+            if args.landing == "flags":
+                nav._check(lib.phd_migration_set_landing(h, 1))
+            sharded_info = {"plan": "device", "migration": "peer stores into IPC-opened receive buffers", "landing": args.landing,
+                            "collectives_per_step": 1 if args.landing == "flags" else 2,
                             "collective": args.collective, "recv_buffer_finegrained": bool(lib.phd_migration_recv_is_finegrained(h) == 1),
                             "p2p": [bool(r == local_rank or torch.cuda.can_device_access_peer(local_rank, r)) for r in range(torch.cuda.device_count())][:max(world, 1)]}
 
@@ -394,8 +408,9 @@ def main():
             mark(3)
             nav._check(lib.phd_migration_push_async(h))
             mark(4)
-            dist.all_reduce(token)       # stream-ordered behind the push: once it has run, every rank's records have landed
-            mark(5)
+            if args.landing == "allreduce":
+                dist.all_reduce(token)   # stream-ordered behind the push: once it has run, every rank's records have landed
+            mark(5)                      # (--landing flags: the push left flags in the receivers' buffers; k_finish_sharded waits for them)
             nav._check(lib.phd_migration_unpack_async(h))
             mark(6)
             return

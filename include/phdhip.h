@@ -291,7 +291,11 @@ int   phd_migration_unpack_async(phd_navigator* nav);
  *             phd_step_global_device_async   the status words of ALL ranks are read (a flag anywhere drops the step everywhere),
  *                                            global normalise / BestParticle / resampling, the migration plan — on the device
  *             phd_migration_push_async       peer stores of the migrating records
- *             a one-word all-reduce on the same stream: "every rank's records have landed"
+ *             "every rank's records have landed": with phd_migration_set_landing(1) (round 5) the push ends with a store of
+ *                                            the step's number into a flag word of every peer's receive buffer and the unpack
+ *                                            waits, on the device, for the words of the ranks it takes records from — ONE
+ *                                            collective per step, the weights; with the default (0) the caller puts a
+ *                                            collective on the same stream here (a one-word all-reduce, rounds 3 - 4)
  *             phd_migration_unpack_async
  * The host never learns whether the step resampled, how many particles moved, or whether a flag dropped it, before phd_sync
  * (which reports a step dropped here because ANOTHER rank raised a flag as PHD_ERR_GENERIC; that rank's own phd_sync names
@@ -303,6 +307,10 @@ int   phd_migration_ipc_open(phd_navigator* nav, const void* handles /* [world_s
 int   phd_migration_set_peers(phd_navigator* nav, void* const* recv_buffers /* [world_size], entry `rank` ignored */, int rank, int world_size);
 int   phd_migration_recv_is_finegrained(phd_navigator* nav);         /* 1 / 0; -1: no buffer                                         */
 int   phd_migration_push_async(phd_navigator* nav);
+/* 1: landing flags (needs fine-grained receive buffers: refused with PHD_ERR_BAD_ARGUMENT otherwise); 0: the caller's collective.
+ * A flag that does not arrive within 10 s (environment PHD_LANDING_TIMEOUT_MS, read by this call) ends the wait; the next phd_sync
+ * reports PHD_ERR_GENERIC (a peer has died; the handle's state is then undefined: phd_reset / upload).                             */
+int   phd_migration_set_landing(phd_navigator* nav, int flags);
 void* phd_stream(phd_navigator* nav);                               /* hipStream_t of the handle   */
 /* Lend the handle a host stream (hipStream_t, NULL = the default stream): kernels and the host's
  * collectives are then ordered by that stream and need no synchronisation in between;

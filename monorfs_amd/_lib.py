@@ -117,6 +117,7 @@ def load():
         "phd_migration_set_peers": (C.c_int, [P, C.POINTER(C.c_void_p), C.c_int, C.c_int]),
         "phd_migration_recv_is_finegrained": (C.c_int, [P]),
         "phd_migration_push_async": (C.c_int, [P]),
+        "phd_migration_set_landing": (C.c_int, [P, C.c_int]),
         "phd_stream": (C.c_void_p, [P]),
         "phd_set_stream": (C.c_int, [P, C.c_void_p, C.c_uint8]),
         "phd_timing_reset": (C.c_int, [P, C.c_uint8]),
@@ -137,5 +138,5 @@ EXPORTS = ["phd_api_version", "phd_default_params", "phd_create", "phd_create_mu
            "phd_device_local_weights", "phd_device_global_weights", "phd_step_global_async", "phd_migration_plan",
            "phd_plan_migration", "phd_test_migration_plan", "phd_multi_report", "phd_last_resampled", "phd_migration_send_buffer", "phd_migration_recv_buffer", "phd_migration_pack_async",
            "phd_migration_unpack_async", "phd_device_gather_buffer", "phd_step_global_device_async", "phd_migration_ipc_export", "phd_migration_ipc_open",
-           "phd_migration_set_peers", "phd_migration_recv_is_finegrained", "phd_migration_push_async", "phd_stream", "phd_set_stream", "phd_timing_reset", "phd_last_timings", "phd_last_timing_counts", "phd_upload_state_soa",
+           "phd_migration_set_peers", "phd_migration_recv_is_finegrained", "phd_migration_push_async", "phd_migration_set_landing", "phd_stream", "phd_set_stream", "phd_timing_reset", "phd_last_timings", "phd_last_timing_counts", "phd_upload_state_soa",
            "phd_download_state_soa"]

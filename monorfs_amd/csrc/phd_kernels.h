@@ -180,10 +180,15 @@ __device__ __forceinline__ size_t in_base(const StepBufs& a, int p) { return (si
 
 #include "phd_correct.h"
 
+// (PHD_ONLY_EP: a translation unit of k_emit_finish / k_prune_merge / k_emit_prune alone — scripts/kres.sh compiles it in seconds
+// to read one kernel's registers and scratch while it is being worked on; never the product build)
+#ifndef PHD_ONLY_EP
 #include "phd_sweep.h"
+#endif
 
 #include "phd_prune.h"
 
+#ifndef PHD_ONLY_EP
 #include "phd_alpha.h"
 
 #include "phd_resample.h"
@@ -726,6 +731,21 @@ __global__ __launch_bounds__(256) void k_pack_particles(const StepBufs a, const 
 	}
 }
 
+// The landing flags (round 5): behind k_pack_particles on the sender's stream, one wave stores the step's number into word
+// `rank` of the flag area at the end of EVERY peer's receive buffer (fine-grained memory, system-scope release: this launch
+// begins when the pack kernel — its peer stores with it — has ended, and the fence orders whatever is still in flight
+// before the flag). The receiver's k_finish_sharded waits for the words of the ranks it takes records from: the
+// one-word all-reduce that played landing barrier until round 4 is a second collective the step does not need.
+__global__ __launch_bounds__(64) void k_post_landing(double* const* recvbase, int n, int rank, size_t flagoff, unsigned long long seq)
+{
+	const int t = threadIdx.x;
+	__threadfence_system();
+	if (t < n && t != rank) {
+		unsigned long long* w = (unsigned long long*) (recvbase[t] + flagoff) + rank;
+		__hip_atomic_store(w, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+}
+
 // End of a sharded step, one workgroup per local particle; what it does is read from the device plan, not decided by the
 // host (rotate_roles in phd_resample.h has the rules of the single-handle step, which are these):
 //   dropped step (a flag was raised): the roles stay as they were, nothing is touched
@@ -736,12 +756,26 @@ __global__ __launch_bounds__(256) void k_pack_particles(const StepBufs a, const 
 //     there. Block b unpacks record b (if there is one) and sets up particle b: small arrays into TMP, slot into inslot.
 //     (IN, OUT, TMP, INMIX) = (T, I, O, O)
 //   frozen: roles and slots stay (benchmark steady state); RES / RESMIX / slots say where the result is
+//   landing != NULL: the flag words of this rank's receive buffer (k_post_landing); a step that takes records from rank t waits
+//   for word t to reach `seq` — bounded (landing_ticks of the 100 MHz counter; PHD_FLAG_ORDER_TIMEOUT: a peer that never posts has died)
 __global__ __launch_bounds__(256) void k_finish_sharded(const StepBufs a, const MigPlan pl, int n, const double* recvbuf, double weight,
-                                                        int* sel_next, int frozen, int* inslot, int* slots)
+                                                        int* sel_next, int frozen, int* inslot, int* slots,
+                                                        const unsigned long long* landing, unsigned long long seq, long long landing_ticks)
 {
 	const int i = blockIdx.x, tid = threadIdx.x;
 	const int nrecv = pl.counts[2 * n + 1], status = pl.counts[2 * n + 2], resampled = pl.counts[2 * n + 3];
 	const int I = a.sel[SEL_IN], O = a.sel[SEL_OUT], T = a.sel[SEL_TMP], X = a.sel[SEL_INMIX];
+	if (landing && status == MIG_OK && resampled && nrecv > 0) {   // (uniform over the launch: every workgroup that may read a record waits)
+		if (tid < n && pl.counts[n + tid] > 0) {
+			const long long t0 = wall_clock64();
+			while ((long long) (__hip_atomic_load(landing + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+				if (wall_clock64() - t0 > landing_ticks) { atomicOr(a.flags, PHD_FLAG_ORDER_TIMEOUT); break; }
+				__builtin_amdgcn_s_sleep(8);
+			}
+		}
+		__syncthreads();
+		__threadfence_system();   // acquire in every wave: the records behind the flags are what the loads below see
+	}
 	if (status != MIG_OK) {
 		if (i == 0 && tid < SEL_STRIDE) sel_next[tid] = a.sel[tid];
 		return;
@@ -789,3 +823,4 @@ __global__ __launch_bounds__(256) void k_finish_sharded(const StepBufs a, const 
 		if (!frozen) inslot[i] = slot;
 	}
 }
+#endif   // PHD_ONLY_EP

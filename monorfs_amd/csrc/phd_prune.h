@@ -219,7 +219,11 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 	int*    scan  = (int*) (smem + lay.scan);              // [264]
 	double* bred  = smem + lay.scan;                       // [28] block reduction scratch (before `scan` is used)
 
-	const int p = a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	// (the particle's number through an empty asm: in the fused launch the compiler otherwise computes this body's addresses at the
+	// top of the kernel and carries them — spilled — across the emit body)
+	int p_ = a.p0 + blockIdx.x;
+	asm volatile("" : "+s"(p_));
+	const int p = p_, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	PHD_STAMP_DECL;
 	const MixView vout = bank_view(a, SEL_OUT);
 	const int ne = a.emit_count[p];
@@ -1192,7 +1196,7 @@ __global__ __launch_bounds__(256, PHD_PRUNE_WAVES) void k_emit_prune(const DevPa
 #else
 	const long long tk0 = 0;
 #endif
-	emit_finish_body(prm, a, smem);
+	emit_finish_body<true>(prm, a, smem);
 	__syncthreads();   // (workgroup scope: what this workgroup's waves stored is visible to its loads behind the barrier)
 	prune_merge_body(prm, a, cutcap, smem, tk0);
 	PHD_TL_END(2);

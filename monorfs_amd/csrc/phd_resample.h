@@ -564,3 +564,352 @@ __global__ __launch_bounds__(64) void k_gate(const unsigned int* done, unsigned 
 		}
 	}
 }
+
+// =================================================================================================================================
+// The same step over a GRID of workgroups (round 5), for weight vectors of NR_GRID_MIN entries and more — what every rank of a
+// multi-GPU run resamples per step (config C8: 16 384 weights on each of 8 GPUs): one workgroup of 1024 threads spent 48 us on
+// them, bound by ONE compute unit's FP64 rate while 255 others idled. Here every thread owns ONE particle, a workgroup 256
+// consecutive ones, and what the whole vector must agree on meets between four launches (a dependent launch boundary costs
+// 2 - 3 us; a grid-wide barrier inside one launch costs the same in fences and needs every workgroup resident):
+//   k_nr_sum      the workgroups' partial sums of the un-normalised weights
+//   k_nr_stats    the total (fixed order over the workgroups), the normalised weights, per workgroup: sum of squares, first
+//                 maximum, a negative / NaN weight seen, the double-double sum of its weights; per particle: the inclusive
+//                 double-double prefix inside its workgroup
+//   k_nr_slots    depleted? (PHDNavigator.cs:768-777); if not: identity sources, BestParticle, the roles. Else per particle the
+//                 slots it takes, [N(S_k), N(S_k+1)) — the verified speculation of the kernel above, one particle per thread —,
+//                 the margin tests, the candidate for BestParticle
+//   k_nr_sources  every slot finds its source by bisection over the particles' upper slot bounds (non-decreasing), the weights
+//                 become 1 / P, the small arrays of the resampled particles are gathered, the roles rotate; one wave replays
+//                 the recurrence literally when a margin test failed (never seen outside the tests that force it)
+// The shape of every sum depends on the length of the vector only, as in the one-workgroup kernel: all ranks of a sharded run
+// and a single handle holding all particles get the same bits. (The two kernels' sums have different shapes — a thread's chunk
+// there, one weight per thread here —: which one runs is decided by the vector's length alone, too.)
+#define NR_GRID_MIN 4096
+#define NR_STAT 8   // doubles per workgroup in the statistics block: sum, sum of squares, max, index of the max, bad, dd sum hi / lo, spare
+#define NR_SLOT 4   // ... in the slots block: ok, best weight, best slot, spare
+
+struct NrGrid {
+	double* part;     // [G][NR_STAT]
+	double* slotres;  // [G][NR_SLOT]
+	double* pre;      // [P][2] inclusive double-double prefix of a particle's weight inside its workgroup
+	int*    hi;       // [P] N(S_(k+1)): the first slot particle k does NOT take
+	int*    state;    // [4] decision of k_nr_slots: [0] depleted
+	int     G;
+};
+
+// Exclusive double-double scan over the workgroups' sums (G <= 256 values, stat[g * NR_STAT + 5 / 6]) by the 256 threads of a
+// workgroup — every workgroup computes the same numbers from the same block: excl <- the prefix in front of workgroup g,
+// next <- the prefix in front of workgroup g + 1 (the total behind the last). s_hi / s_lo: 8 doubles of LDS each.
+__device__ __forceinline__ void nr_scan_groups(const double* stat, int G, int g, double* s_hi, double* s_lo, int tid, dd& excl, dd& next)
+{
+#pragma clang fp contract(off)
+	const int lane = tid & 63, wv = tid >> 6;
+	dd inc = (tid < G) ? dd{stat[(size_t) tid * NR_STAT + 5], stat[(size_t) tid * NR_STAT + 6]} : dd{0, 0};
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		dd y = {shfl_up_d(inc.hi, o), shfl_up_d(inc.lo, o)};
+		if (lane >= o) inc = dd_add(y, inc);
+	}
+	if (lane == 63) { s_hi[wv] = inc.hi; s_lo[wv] = inc.lo; }
+	__syncthreads();
+	dd incl = inc;
+	if (wv > 0) {
+		dd off = {s_hi[0], s_lo[0]};
+		for (int w = 1; w < wv; w++) off = dd_add(off, dd{s_hi[w], s_lo[w]});
+		incl = dd_add(off, inc);
+	}
+	if (tid == g - 1) { s_hi[4] = incl.hi; s_lo[4] = incl.lo; }
+	if (tid == g)     { s_hi[5] = incl.hi; s_lo[5] = incl.lo; }
+	__syncthreads();
+	excl = (g == 0) ? dd{0, 0} : dd{s_hi[4], s_lo[4]};
+	next = dd{s_hi[5], s_lo[5]};
+}
+
+
+// this thread's weight of the vector the step works on: the gathered vector, or — single handle — the OUT bank's, whose role is
+// read from the device: the three banks' words are requested together with the role (one trip to memory, not two)
+__device__ __forceinline__ double nr_weight(const StepBufs& a, const double* gw, int k, bool live)
+{
+	if (gw) return live ? gw[k] : 0.0;
+	const double w0 = live ? a.bank[0].weights[k] : 0.0, w1 = live ? a.bank[1].weights[k] : 0.0, w2 = live ? a.bank[2].weights[k] : 0.0;
+	const int so = a.sel[SEL_OUT];
+	return (so == 0) ? w0 : ((so == 1) ? w1 : w2);
+}
+
+__global__ __launch_bounds__(256) void k_nr_sum(const StepBufs a, double* gw, int P, int skip_normalise, int* sel_next, NrGrid nr)
+{
+	__shared__ double s4[4];
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = blockIdx.x, k = g * 256 + tid;
+	if (g == 0 && tid == 0 && a.bigws_used && *a.bigws_used) *a.bigws_used = 0;   // the association slab is free again
+	if (g == 0 && tid < 4 && a.biglist) a.biglist[(size_t) tid * a.bigstride] = 0;
+	const int flags_now = sel_next ? *a.flags : 0;   // (requested with the weights below: one trip)
+	double w = 0;
+	if (a.defer && !gw) {   // WeightAlpha's last line, left open by k_alpha_density (PHD_DEFER_BIG)
+		if (k < P) {
+			const double alpha = exp(a.setll[k] + a.ratio[k]);
+			a.alpha[k] = alpha;
+			w = bank_of(a, SEL_IN).weights[k] * alpha;
+			bank_of(a, SEL_OUT).weights[k] = w;
+		}
+	}
+	else w = nr_weight(a, gw, k, k < P);
+	if (flags_now != 0) {   // a kernel of this step raised a flag: the step is dropped as a whole (see the body above)
+		if (g == 0 && tid < SEL_STRIDE) sel_next[tid] = a.sel[tid];
+		return;
+	}
+	double s = skip_normalise ? 0.0 : wave_sum(w);
+	if (lane == 0) s4[wv] = s;
+	__syncthreads();
+	if (tid == 0) nr.part[(size_t) g * NR_STAT] = ((s4[0] + s4[1]) + s4[2]) + s4[3];
+}
+
+__global__ __launch_bounds__(256) void k_nr_stats(const StepBufs a, double* gw, int P, int skip_normalise, int* sel_next, NrGrid nr)
+{
+#pragma clang fp contract(off)
+	__shared__ double s4[4], s4b[4], s_hi[4], s_lo[4];
+	__shared__ int s_i4[4], s_bad;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = blockIdx.x, k = g * 256 + tid;
+	const int flags_now = sel_next ? *a.flags : 0;
+	double wk = nr_weight(a, gw, k, k < P);
+	double nsum = 1;
+	if (!skip_normalise) {
+		double sum = 0;
+		for (int q = 0; q < nr.G; q++) sum += nr.part[(size_t) q * NR_STAT];   // the same order in every workgroup
+		nsum = (sum == 0) ? 1 : sum;
+	}
+	if (flags_now != 0) return;
+	if (tid == 0) s_bad = 0;
+	if (k < P && !skip_normalise) {
+		wk = wk / nsum;   // :343-345
+		(gw ? gw : bank_of(a, SEL_OUT).weights)[k] = wk;
+	}
+	const bool bad = k < P && !(wk >= 0);
+	// sum of squares (:772-774), first maximum (:347-354)
+	const double sq = wave_sum(wk * wk);
+	double m = (k < P) ? wk : -INFINITY;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+	const unsigned long long bal = ballot64(k < P && wk == m);
+	const int firstl = bal ? __ffsll((long long) bal) - 1 : 0;
+	// inclusive double-double prefix inside the workgroup
+	dd inc = {wk, 0};
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		dd y = {shfl_up_d(inc.hi, o), shfl_up_d(inc.lo, o)};
+		if (lane >= o) inc = dd_add(y, inc);
+	}
+	__syncthreads();
+	if (bad) s_bad = 1;
+	if (lane == 0) { s4[wv] = sq; s4b[wv] = bal ? m : -INFINITY; s_i4[wv] = g * 256 + wv * 64 + firstl; }
+	if (lane == 63) { s_hi[wv] = inc.hi; s_lo[wv] = inc.lo; }
+	__syncthreads();
+	dd off = {0, 0};
+	for (int w = 0; w < wv; w++) off = dd_add(off, dd{s_hi[w], s_lo[w]});
+	const dd incl = (wv == 0) ? inc : dd_add(off, inc);
+	if (k < P) { nr.pre[(size_t) k * 2] = incl.hi; nr.pre[(size_t) k * 2 + 1] = incl.lo; }
+	if (tid == 255) { nr.part[(size_t) g * NR_STAT + 5] = incl.hi; nr.part[(size_t) g * NR_STAT + 6] = incl.lo; }   // (weights beyond P are 0: the total)
+	if (tid == 0) {
+		double gm = -INFINITY;
+		int gi = 0;
+		for (int q = 0; q < 4; q++) {
+			if (s4b[q] > gm) { gm = s4b[q]; gi = s_i4[q]; }
+		}
+		double* o = nr.part + (size_t) g * NR_STAT;
+		o[1] = ((s4[0] + s4[1]) + s4[2]) + s4[3];
+		o[2] = gm; o[3] = (double) gi; o[4] = (double) s_bad;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_nr_slots(const StepBufs a, double* gw, int P, double min_eff, double u, int force_resample,
+                                                  int* src, int* info, int* sel_next, int frozen, int* inslot, NrGrid nr)
+{
+#pragma clang fp contract(off)
+	__shared__ double s_hi[12], s_lo[12], s_bw[4];
+	__shared__ int s_hilast[4], s_ok, s_best;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = blockIdx.x, k = g * 256 + tid;
+	const int flags_now = sel_next ? *a.flags : 0;
+	const bool live = k < P;
+	const double wk = nr_weight(a, gw, k, live);
+	const dd incl = live ? dd{nr.pre[(size_t) k * 2], nr.pre[(size_t) k * 2 + 1]} : dd{0, 0};
+	if (flags_now != 0) return;
+	// what every workgroup derives alike from the statistics block
+	double cum = 0, gmax = -INFINITY;
+	int gbest = 0;
+	bool bad = false;
+	for (int q = 0; q < nr.G; q++) {
+		const double* st = nr.part + (size_t) q * NR_STAT;
+		cum += st[1];
+		if (st[2] > gmax) { gmax = st[2]; gbest = (int) st[3]; }
+		bad = bad || st[4] != 0.0;
+	}
+	if (!(gmax > 0)) gbest = 0;   // maxweight starts at 0 and the comparison is strict (:347-353)
+	bool depleted = (1.0 / cum < min_eff * P);   // :776
+	if (force_resample > 0) depleted = true;
+	if (force_resample < 0) depleted = false;
+	if (g == 0 && tid == 0) nr.state[0] = depleted ? 1 : 0;
+	if (!depleted) {
+		if (g == 0 && tid == 0) { info[0] = gbest; info[1] = 0; }
+		if (k < P) {
+			src[k] = k;
+			if (sel_next && !frozen) inslot[k] = k;
+		}
+		if (sel_next && g == 0 && tid == 0) {
+			const int I = a.sel[SEL_IN], O = a.sel[SEL_OUT], T = a.sel[SEL_TMP], X = a.sel[SEL_INMIX];
+			if (frozen) { sel_next[SEL_IN] = I; sel_next[SEL_OUT] = O; sel_next[SEL_TMP] = T; sel_next[SEL_INMIX] = X; }
+			else        { sel_next[SEL_IN] = O; sel_next[SEL_OUT] = I; sel_next[SEL_TMP] = T; sel_next[SEL_INMIX] = O; }
+			sel_next[SEL_RES] = O; sel_next[SEL_RESMIX] = O;
+		}
+		return;
+	}
+	// ---- ResampleParticles (:724-760) by verified speculation, one particle per thread: particle k takes the slots
+	// [N(S_k), N(S_(k+1))), N(x) = #{i : T_i <= x} (see the kernel above). S_k = the workgroup's offset + the prefix of the lane
+	// before; the numbers on the two sides of every boundary — between lanes, waves and workgroups — are the same numbers, so the
+	// ranges tile [0, P).
+	dd woff, wnext;
+	nr_scan_groups(nr.part, nr.G, g, s_hi, s_lo, tid, woff, wnext);
+	if (tid == 0) { s_ok = 1; s_best = 0x7fffffff; }
+	const double R0 = u / P, invP = 1.0 / P;
+	const double B = 8.0 * P * 1.1102230246251565e-16 * (fmax(gmax, 0.0) + fabs(R0) + invP);
+	bool ok = !bad, settled = true;
+	// S_(k+1); at the workgroup's last particle: what the NEXT workgroup starts from
+	const bool lastofgroup = tid == 255 && g + 1 < nr.G;
+	const dd Sb = lastofgroup ? wnext : dd_add(woff, incl);
+	const int hinat = live ? slots_upto(Sb, R0, invP, P, &settled) : 0;
+	int hi = (k == P - 1) ? P : hinat;   // the recurrence runs into P: whatever is left goes to the last particle
+	// the inclusive prefix and the upper slot bound of the particle before: the lane before, or the last lane of the wave before
+	dd pin = {__shfl_up(incl.hi, 1, 64), __shfl_up(incl.lo, 1, 64)};
+	int lo = __shfl_up(hi, 1, 64);
+	if (lane == 63) { s_hi[8 + wv] = incl.hi; s_lo[8 + wv] = incl.lo; s_hilast[wv] = hi; }
+	__syncthreads();
+	if (lane == 0 && wv > 0) { pin = dd{s_hi[8 + wv - 1], s_lo[8 + wv - 1]}; lo = s_hilast[wv - 1]; }
+	const dd S = (tid == 0) ? woff : dd_add(woff, pin);   // S_k
+	if (tid == 0) lo = (g == 0) ? 0 : slots_upto(woff, R0, invP, P, &settled);   // (slot 0 belongs to the first particle even when u == 0: the clamp of :739)
+	double mybestw = -INFINITY;
+	int mybesti = 0x7fffffff;
+	if (live) {
+		if (hi < lo) { ok = false; hi = lo; }
+		if (hi > lo) {
+			// the last comparison that came out positive, at the particle's first slot (none for particle 0: `random` is u / P itself there)
+			if (k > 0) ok = ok && dd_diff(slot_target(lo, R0, invP), S) > B;
+			// the comparison that stopped the loop, at its last slot (none for the slots the last particle gets by k == P)
+			if (hinat > lo) ok = ok && dd_diff(Sb, slot_target(hinat - 1, R0, invP)) > B;
+			mybestw = wk; mybesti = lo;
+		}
+		nr.hi[k] = hi;
+	}
+	ok = ok && settled;
+	if (!ok) s_ok = 0;
+	// BestParticle = first slot whose source has the largest weight (:745-748): the workgroup's candidate
+	double m = mybestw;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+	if (lane == 0) s_bw[wv] = m;
+	__syncthreads();
+	const double gmw = fmax(fmax(s_bw[0], s_bw[1]), fmax(s_bw[2], s_bw[3]));
+	if (mybesti != 0x7fffffff && mybestw == gmw) atomicMin(&s_best, mybesti);
+	__syncthreads();
+	if (tid == 0) {
+		double* o = nr.slotres + (size_t) g * NR_SLOT;
+		o[0] = (double) s_ok; o[1] = gmw; o[2] = (double) s_best;
+	}
+}
+
+__global__ __launch_bounds__(256) void k_nr_sources(const StepBufs a, double* gw, int P, double u, int* src, int* info, int* sel_next,
+                                                    int frozen, int* inslot, NrGrid nr)
+{
+	const int tid = threadIdx.x, lane = tid & 63, g = blockIdx.x, i = g * 256 + tid;
+	const int flags_now = sel_next ? *a.flags : 0, depleted = nr.state[0];
+	if (flags_now != 0 || depleted == 0) return;   // a dropped step | not depleted: k_nr_slots ended the step
+	double* gwp = gw ? gw : bank_of(a, SEL_OUT).weights;
+	bool ok = true;
+	double gm = -INFINITY;
+	int best = 0x7fffffff;
+	for (int q = 0; q < nr.G; q++) {
+		const double* r = nr.slotres + (size_t) q * NR_SLOT;
+		ok = ok && r[0] != 0.0;
+		if (r[1] > gm) { gm = r[1]; best = (int) r[2]; }
+		else if (r[1] == gm && (int) r[2] < best) best = (int) r[2];
+	}
+	const Bank bo = bank_of(a, SEL_OUT), bt = bank_of(a, SEL_TMP);
+	auto finish_slot = [&](int s_i, int slot) {   // slot `slot` takes particle s_i: the small arrays of the resampled state (rotate_roles above)
+		if (sel_next) {
+			const int c0 = bo.count[s_i];
+			double q0[7];
+#pragma unroll
+			for (int t = 0; t < 7; t++) q0[t] = bo.poses[(size_t) s_i * 7 + t];
+			bt.count[slot] = c0; bt.weights[slot] = 1.0 / P;
+#pragma unroll
+			for (int t = 0; t < 7; t++) bt.poses[(size_t) slot * 7 + t] = q0[t];
+			if (!frozen) inslot[slot] = s_i;
+		}
+	};
+	auto roles = [&]() {
+		const int I = a.sel[SEL_IN], O = a.sel[SEL_OUT], T = a.sel[SEL_TMP], X = a.sel[SEL_INMIX];
+		if (frozen) { sel_next[SEL_IN] = I; sel_next[SEL_OUT] = O; sel_next[SEL_TMP] = T; sel_next[SEL_INMIX] = X; }
+		else        { sel_next[SEL_IN] = T; sel_next[SEL_OUT] = I; sel_next[SEL_TMP] = O; sel_next[SEL_INMIX] = O; }
+		sel_next[SEL_RES] = T; sel_next[SEL_RESMIX] = O;
+	};
+	if (ok) {
+		if (g == 0 && tid == 0) {
+			info[0] = (gm > 0) ? best : 0; info[1] = 1;
+			if (sel_next) roles();
+		}
+		if (i < P) {
+			// the source of slot i: the first particle whose upper slot bound lies beyond i (the bounds never decrease; the last is P)
+			// (sixteen ways per trip to memory — fifteen pivots requested together — instead of two: four trips at 16 384 weights,
+			// not fourteen; a workgroup alone on its CU pays every dependent trip in full)
+			int lo = 0, cnt = P;   // the answer lies in [lo, lo + cnt): hi[lo + cnt - 1] > i
+			while (cnt > 1) {
+				const int stride = (cnt + 15) >> 4, end = lo + cnt;
+				int below = 0;
+				int v[15];
+#pragma unroll
+				for (int j = 0; j < 15; j++) {
+					const int idx = lo + (j + 1) * stride - 1;
+					v[j] = (idx < end - 1) ? nr.hi[idx] : 0x7fffffff;
+				}
+#pragma unroll
+				for (int j = 0; j < 15; j++) below += (v[j] <= i) ? 1 : 0;
+				lo += below * stride;
+				cnt = min(stride, end - lo);
+			}
+			src[i] = lo;
+			gwp[i] = 1.0 / P;   // :742
+			finish_slot(lo, i);
+		}
+		return;
+	}
+	// ---- fallback: the recurrence itself, by one wave (weights through v_readlane, scalar control flow); the weights are
+	// normalised in place already
+	if (g != 0) return;
+	if (tid < 64) {
+		auto rl = [](double v, int l) {
+			int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+			return __hiloint2double(hi, lo);
+		};
+		const double invP = 1.0 / P;
+		double random = u / P, maxweight = 0;
+		int k = 0, bestslot = 0, cb = 0;
+		double cur = (lane < P) ? gwp[lane] : 0.0, prev = 0.0;
+		for (int s = 0; s < P; s++) {
+			while (k < P && __builtin_amdgcn_readfirstlane((int) (random > 0))) {
+				if (k >= cb + 64) { prev = cur; cb += 64; cur = (cb + lane < P) ? gwp[cb + lane] : 0.0; }
+				random -= rl(cur, k - cb);
+				k++;
+			}
+			const int sidx = (k - 1 < 0) ? 0 : k - 1;   // u == 0 would index -1 in the reference: clamped
+			if (lane == 0) src[s] = sidx;
+			random += invP;
+			const double ws = (sidx >= cb) ? rl(cur, sidx - cb) : rl(prev, sidx - (cb - 64));
+			if (__builtin_amdgcn_readfirstlane((int) (ws > maxweight))) { maxweight = ws; bestslot = s; }
+		}
+		if (lane == 0) { info[0] = bestslot; info[1] = 1; }
+	}
+	__threadfence_block();
+	__syncthreads();
+	for (int s = tid; s < P; s += 256) {
+		gwp[s] = 1.0 / P;
+		finish_slot(src[s], s);
+	}
+	if (sel_next && tid == 0) roles();
+}

@@ -118,6 +118,9 @@ struct phd_navigator {
 	double* h_stage[2] = {nullptr, nullptr}; hipEvent_t ev_stage[2] = {nullptr, nullptr}; bool stage_used[2] = {false, false};
 	int stage_i = 0; size_t stagecap = 0;
 	int nr_static_lds = 0;                           // static LDS of k_normalise_resample
+	// the step over a grid of workgroups (k_nr_*, phd_resample.h) for weight vectors of nr_grid_min .. 65 536 entries (environment
+	// PHD_NR_GRID_MIN; 0: never): its scratch, made on first use
+	int nr_grid_min = NR_GRID_MIN; int nrcap = 0; double* d_nrd = nullptr; int* d_nri = nullptr;
 	// sharded step (one rank of a multi-GPU particle set: a process of its own, or a shard of a phd_create_multi handle)
 	double*  d_lw = nullptr;                         // [Pcap] local weights, exported for the host's all-gather (per-rank host)
 	double** d_dst_tab = nullptr; int ndst = 1;      // device table: where k_push_weights stores the local weights (own d_lw | every shard's d_gw)
@@ -135,6 +138,9 @@ struct phd_navigator {
 	bool sharded_used = false;
 	bool sharded_ready = false;                      // every buffer of ensure_sharded is there (set behind the last allocation)
 	bool recv_finegrained = false;                   // d_recv is fine-grained device memory (coherent for the peers that store into it)
+	int  landing_flags = 0;                          // phd_migration_set_landing: 1 = push posts step-stamped flags into the peers' receive buffers, unpack waits for them
+	unsigned long long landing_seq = 0;              // number of the last device-path global step (the flags' stamp)
+	long long landing_ticks = 1000000000LL;          // bound of the wait for a flag, in ticks of the 100 MHz counter: 10 s (environment PHD_LANDING_TIMEOUT_MS)
 	double* d_graw = nullptr; int grawcap = 0;       // per-rank host: the all-gather's landing buffer, [world][P + 1] (weights | status word)
 	std::vector<void*> ipc_opened;                   // peers' receive buffers opened with hipIpcOpenMemHandle (closed in phd_destroy)
 	bool plan_on_device = false;                     // the last global step left its plan on the device only (phd_step_global_device_async)
@@ -479,6 +485,32 @@ int launch_normalise(phd_navigator* nav, const StepBufs& b, double* gw, int P, d
                      int* sel_next = nullptr, hipStream_t st = nullptr)
 {
 	if (!st) st = nav->stream;
+	if (nav->nr_grid_min > 0 && P >= nav->nr_grid_min && P <= 65536 && b.wait_tickets == 0 && b.done_value == 0) {
+		// one particle per thread over a grid, four launches (phd_resample.h, "over a GRID"): 16 384 weights in ~15 us instead of 48
+		if (P > nav->nrcap) {
+			HC(hipDeviceSynchronize());   // (first use, or a longer vector than ever before: rare)
+			hipFree(nav->d_nrd); hipFree(nav->d_nri);
+			nav->d_nrd = nullptr; nav->d_nri = nullptr; nav->nrcap = 0;
+			const int Gc = (P + 255) / 256;
+			HC(hipMalloc((void**) &nav->d_nrd, ((size_t) Gc * (NR_STAT + NR_SLOT) + 2 * (size_t) P) * 8));
+			HC(hipMalloc((void**) &nav->d_nri, ((size_t) P + 4) * 4));
+			nav->nrcap = P;
+		}
+		NrGrid nr;
+		nr.G = (P + 255) / 256;
+		nr.part = nav->d_nrd;
+		nr.slotres = nr.part + (size_t) nr.G * NR_STAT;
+		nr.pre = nr.slotres + (size_t) nr.G * NR_SLOT;
+		nr.hi = nav->d_nri;
+		nr.state = nav->d_nri + P;
+		const int fr = nav->frozen ? 1 : 0;
+		hipLaunchKernelGGL(k_nr_sum, dim3(nr.G), dim3(256), 0, st, b, gw, P, skipnorm, sel_next, nr);
+		hipLaunchKernelGGL(k_nr_stats, dim3(nr.G), dim3(256), 0, st, b, gw, P, skipnorm, sel_next, nr);
+		hipLaunchKernelGGL(k_nr_slots, dim3(nr.G), dim3(256), 0, st, b, gw, P, nav->dp.min_eff, u, force, src, info, sel_next, fr, nav->d_inslot, nr);
+		hipLaunchKernelGGL(k_nr_sources, dim3(nr.G), dim3(256), 0, st, b, gw, P, u, src, info, sel_next, fr, nav->d_inslot, nr);
+		HC(hipGetLastError());
+		return PHD_OK;
+	}
 	// one workgroup; 256 / 512 threads for shorter weight vectors (fewer waves to meet at every barrier), 1024 beyond 4096
 	static const int nr_env = getenv("PHD_NR_THREADS") ? atoi(getenv("PHD_NR_THREADS")) : 0;
 	const int nthreads = (nr_env == 256 || nr_env == 512 || nr_env == 1024) ? nr_env : (P <= 512 ? 256 : (P <= 4096 ? 512 : 1024));
@@ -503,8 +535,9 @@ int check_flags(phd_navigator* nav)
 		return nav->fail(PHD_ERR_CAPACITY, "map estimate larger than the landmark scratch (" + std::to_string(nav->Jcap) + ")");
 	}
 	if (f & PHD_FLAG_ORDER_TIMEOUT) {
-		return nav->fail(PHD_ERR_GENERIC, "a kernel that orders the handle's two streams on the device waited 0.2 s for work submitted before it (PHD_DEVICE_ORDER=0 "
-		                 "orders them with events instead); the step was dropped, the state is the one before it");
+		return nav->fail(PHD_ERR_GENERIC, "a kernel gave up a bounded wait on the device: for work of the handle's other stream submitted before it (PHD_DEVICE_ORDER=1: 0.2 s; "
+		                 "the step was dropped, the state is the one before it), or for the landing flag of a peer's migrating particles (phd_migration_set_landing: "
+		                 "PHD_LANDING_TIMEOUT_MS; a rank has died, the state of this handle is undefined)");
 	}
 	if (f & PHD_FLAG_BIG_CLUSTER) {
 		return nav->fail(PHD_ERR_ASSOCIATION, "a data-association cluster has more than " + std::to_string(MURTY_NBIG) + " rows, or the clusters beyond " +
@@ -753,6 +786,7 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	if (const char* e = getenv("PHD_SPLIT")) nav->nsplit = std::max(0, atoi(e));
 	if (const char* e = getenv("PHD_CHAIN_MAX")) nav->chain_max = std::max(0, atoi(e));
 	if (const char* e = getenv("PHD_FOLD_NR")) nav->fold_nr = atoi(e) != 0;
+	if (const char* e = getenv("PHD_NR_GRID_MIN")) nav->nr_grid_min = std::max(0, atoi(e));
 	size_t plane = (size_t) nav->Pcap * nav->cap;
 	for (int i = 0; i < 3 && ok; i++) {
 		ok = ok && dalloc((void**) &nav->bank[i].mix, plane * MIX_REC * 8);
@@ -911,7 +945,7 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_sel); hipFree(nav->d_inslot); hipFree(nav->d_mslot); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_src);
-	hipFree(nav->d_murty); hipFree(nav->d_bigws); hipFree(nav->d_bigws_used); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_outw); hipFree(nav->d_wcopy); hipFree(nav->d_cover); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan);
+	hipFree(nav->d_murty); hipFree(nav->d_bigws); hipFree(nav->d_bigws_used); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_outw); hipFree(nav->d_wcopy); hipFree(nav->d_cover); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan); hipFree(nav->d_nrd); hipFree(nav->d_nri);
 	hipFree(nav->d_lw); hipFree(nav->d_dst_tab); hipFree(nav->d_recv_tab); hipFree(nav->plan.code); hipFree(nav->plan.fslot); hipFree(nav->plan.sendlist); hipFree(nav->plan.senddst); hipFree(nav->plan.counts);
 	if (nav->h_counts) hipHostFree(nav->h_counts);
 	for (void* q : nav->ipc_opened) hipIpcCloseMemHandle(q);
@@ -1829,13 +1863,16 @@ static int ensure_sharded(phd_navigator* nav, bool need_send = true)
 	// processes through IPC) and read here: fine-grained device memory, coherent between agents without cache maintenance —
 	// what RCCL allocates for its own peer-to-peer buffers. (See the head of phd_multi.inc for the visibility argument.)
 	if (e == hipSuccess) {
+		// (+ PHD_MAX_DEVICES words behind the records: the landing flags, one per sending rank — k_post_landing)
+		const size_t recv_bytes = ((size_t) nav->recvrecs * rec + PHD_MAX_DEVICES) * 8;
 		nav->recv_finegrained = getenv("PHD_COARSE_RECV") == nullptr &&
-		                        hipExtMallocWithFlags((void**) &nav->d_recv, (size_t) nav->recvrecs * rec * 8, hipDeviceMallocFinegrained) == hipSuccess;
+		                        hipExtMallocWithFlags((void**) &nav->d_recv, recv_bytes, hipDeviceMallocFinegrained) == hipSuccess;
 		if (!nav->recv_finegrained) {
 			(void) hipGetLastError();
 			nav->d_recv = nullptr;
-			want(hipMalloc((void**) &nav->d_recv, (size_t) nav->recvrecs * rec * 8));
+			want(hipMalloc((void**) &nav->d_recv, recv_bytes));
 		}
+		if (e == hipSuccess) want(hipMemset(nav->d_recv + (size_t) nav->recvrecs * rec, 0, PHD_MAX_DEVICES * 8));
 	}
 	if (e != hipSuccess) {
 		(void) hipGetLastError();
@@ -1973,7 +2010,30 @@ int phd_step_global_device_async(phd_navigator* nav, int rank, int world_size, d
 	if (world_size < 1 || world_size > PHD_MAX_DEVICES || rank < 0 || rank >= world_size) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step_global_device: bad rank/world (at most 64 ranks)");
 	if (!nav->d_graw || nav->grawcap < world_size * (nav->P + 1)) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step_global_device: no gather buffer (phd_device_gather_buffer(world_size) first)");
 	if (!nav->peers_set && world_size > 1) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_step_global_device: the peers' receive buffers are not known (phd_migration_ipc_open / phd_migration_set_peers first)");
+	nav->landing_seq++;
 	return step_global(nav, rank, world_size, u_resample, onlymapping, false, true);
+}
+
+// How the receiver of a device-path step learns that the migrating particles have landed (phd_migration_push_async ->
+// phd_migration_unpack_async):
+//   0 (default)  the caller orders the two calls itself — a collective on the stream between them (the one-word all-reduce of
+//                rounds 3 - 4), or one stream for all the handles of a process;
+//   1            flags: the push ends with a store of the step's number into every peer's receive buffer, the unpack waits (on
+//                the device, bounded) for the flags of the ranks it takes records from. No second collective per step. Needs
+//                fine-grained receive buffers (phd_migration_recv_is_finegrained): with ordinary device memory a peer's store is
+//                only visible at a kernel boundary, and the call is refused.
+int phd_migration_set_landing(phd_navigator* nav, int flags)
+{
+	if (!nav) return PHD_ERR_BAD_ARGUMENT;
+	MULTI_UNSUPPORTED(nav, "phd_migration_set_landing");
+	int rc = ensure_sharded(nav, false);
+	if (rc) return rc;
+	if (flags && !nav->recv_finegrained) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_set_landing: the receive buffer is not fine-grained memory: order push and unpack with a collective instead");
+	enter(nav);
+	HC(hipStreamSynchronize(nav->stream));
+	nav->landing_flags = flags ? 1 : 0;
+	if (const char* e = getenv("PHD_LANDING_TIMEOUT_MS")) nav->landing_ticks = std::max(1LL, atoll(e)) * 100000LL;
+	return PHD_OK;
 }
 
 // the 64-byte hipIpcMemHandle_t of this rank's receive buffer, for the other ranks' processes to open
@@ -1987,7 +2047,7 @@ int phd_migration_ipc_export(phd_navigator* nav, void* handle64, int64_t* buffer
 	hipIpcMemHandle_t h;
 	HC(hipIpcGetMemHandle(&h, nav->d_recv));
 	std::memcpy(handle64, &h, 64);
-	if (buffer_bytes) *buffer_bytes = (int64_t) ((size_t) nav->recvrecs * ((size_t) 8 + (size_t) MIX_REC * nav->cap) * 8);
+	if (buffer_bytes) *buffer_bytes = (int64_t) (((size_t) nav->recvrecs * ((size_t) 8 + (size_t) MIX_REC * nav->cap) + PHD_MAX_DEVICES) * 8);
 	return PHD_OK;
 }
 
@@ -2073,6 +2133,11 @@ int phd_migration_push_async(phd_navigator* nav)
 	timer_begin(nav, T_PK);
 	hipLaunchKernelGGL(k_pack_particles, dim3(std::min(nav->plan.sendcap, 256)), dim3(256), 0, nav->stream, b, nav->plan, nav->world, (double*) nullptr,
 	                   (double* const*) nav->d_recv_tab);
+	if (nav->landing_flags && nav->world > 1) {
+		const size_t rec = (size_t) 8 + (size_t) MIX_REC * nav->cap;
+		hipLaunchKernelGGL(k_post_landing, dim3(1), dim3(64), 0, nav->stream, (double* const*) nav->d_recv_tab, nav->world, nav->rank,
+		                   (size_t) nav->recvrecs * rec, nav->landing_seq);
+	}
 	timer_end(nav, T_PK);
 	HC(hipGetLastError());
 	return PHD_OK;
@@ -2266,8 +2331,13 @@ static int step_finish(phd_navigator* nav)
 	int* sel_next = nav->d_sel + (nav->parity ^ 1) * SEL_STRIDE;
 	nav->d_res_slots = nav->d_mslot;
 	timer_begin(nav, T_GR);
+	const unsigned long long* landing = nullptr;
+	if (nav->landing_flags && nav->plan_on_device && nav->world > 1) {
+		const size_t rec = (size_t) 8 + (size_t) MIX_REC * nav->cap;
+		landing = (const unsigned long long*) (nav->d_recv + (size_t) nav->recvrecs * rec);
+	}
 	hipLaunchKernelGGL(k_finish_sharded, dim3(nav->P), dim3(256), 0, nav->stream, b, nav->plan, nav->world, (const double*) nav->d_recv,
-	                   1.0 / (double) nav->last_world_particles, sel_next, nav->frozen ? 1 : 0, nav->d_inslot, nav->d_mslot);
+	                   1.0 / (double) nav->last_world_particles, sel_next, nav->frozen ? 1 : 0, nav->d_inslot, nav->d_mslot, landing, nav->landing_seq, nav->landing_ticks);
 	timer_end(nav, T_GR);
 	HC(hipGetLastError());
 	nav->parity ^= 1;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: per-phase shader-clock shares of a stamped kernel (build with -DPHD_STAMPS into
 monorfs_amd/csrc/libphdhip_stamps.so; never the product build). Usage on the GPU box:
-    python scripts/stamps.py [steady|survey] [kernel id: 2 = k_prune_merge, 3 = k_alpha_assoc]"""
+    python scripts/stamps.py [steady|survey] [kernel id: 2 = k_prune_merge (+ slot 15: the emit body in front of it in the fused launch), 3 = k_alpha_assoc, 7 = the emit body's own stamps]"""
 import ctypes as C
 import os
 import subprocess
@@ -39,6 +39,11 @@ out = np.zeros((shape[0], 16))
 nav._lib.phd_debug_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
 nav._lib.phd_debug_stamps(nav._h, out.ctypes.data_as(C.POINTER(C.c_double)))
 m = out.mean(0)   # stamp i = cycles since stamp 0 (stamps need not be numbered in time order)
+if os.environ.get("PHD_STAMP_KERNEL") == "7":   # the emit body (wave 0 of every workgroup): its own layout
+    print(prof, "emit body: cycles %d, of them inside the Kalman path %d in %.2f rounds of wave 0; runs (components with kept pairs) of the particle: %.0f, its queue entries: %.0f"
+          % (m[1], m[2], m[3], m[4], m[5]))
+    nav.close()
+    sys.exit(0)
 idx = [i for i in np.argsort(m[:12], kind="stable") if i == 0 or m[i] > 0]
 print("counters 12..15 (sum over steps run):", m[12:16])
 print(prof, "cycles between stamps:", " ".join("%d->%d:%d" % (a, b, m[b] - m[a]) for a, b in zip(idx[:-1], idx[1:])), "total", int(m[:12].max()))

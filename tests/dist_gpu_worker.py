@@ -5,6 +5,8 @@ and compares.
   mode "device" (argv[1], the default; what bench.py --gpus N runs): no host wait — the weights (+ status words) are
       all-gathered, the plan stays on the device, every rank's kernels store the migrating particles straight into the other
       PROCESSES' receive buffers (opened through hipIpcMemHandle), a barrier stands in for the one-word all-reduce;
+  mode "flags": the same with phd_migration_set_landing(1) — nothing at all between push and unpack: the senders leave a
+      step-stamped flag behind their records, the receiver's k_finish_sharded waits for it on the device (round 5);
   mode "host": round 3's sequence — the host waits for the plan's split sizes and moves the records with all_to_all_single."""
 import ctypes as C
 import os
@@ -54,6 +56,9 @@ def main():
         one.upload_state(planes, f.counts, f.poses, f.weights)
     nresampled = 0
     mode = sys.argv[1] if len(sys.argv) > 1 else "device"
+    flags = mode == "flags"
+    if flags:
+        mode = "device"
     if mode == "device":
         graw = dev(lib.phd_device_gather_buffer(h, world), world * (Pl + 1))
         hbuf = C.create_string_buffer(64)
@@ -61,6 +66,9 @@ def main():
         handles = [None] * world
         dist.all_gather_object(handles, bytes(hbuf.raw))
         nav._check(lib.phd_migration_ipc_open(h, b"".join(handles), rank, world))
+        if flags:
+            assert lib.phd_migration_recv_is_finegrained(h) == 1, "no fine-grained receive buffer on this box: the flags need one"
+            nav._check(lib.phd_migration_set_landing(h, 1))
     for step in range(steps):
         u = 0.3 + 0.2 * step
         nav._check(lib.phd_step_local_async(h, 0))
@@ -71,8 +79,9 @@ def main():
             graw.copy_(g_host)
             nav._check(lib.phd_step_global_device_async(h, rank, world, C.c_double(u), 0))
             nav._check(lib.phd_migration_push_async(h))
-            torch.cuda.synchronize()
-            dist.barrier()                      # every rank's records have landed (bench.py: a one-word all-reduce on the stream)
+            if not flags:
+                torch.cuda.synchronize()
+                dist.barrier()                  # every rank's records have landed (bench.py --landing allreduce: a one-word all-reduce on the stream)
             nav._check(lib.phd_migration_unpack_async(h))
             nav.sync()
             ns = nr = 0
@@ -88,7 +97,7 @@ def main():
                     for j, i in enumerate((0, Pl // 2, Pl - 1)):
                         a_, b_ = one.MapModel(r * Pl + i), w_all[r][2][j]
                         assert all(np.array_equal(x, y) for x, y in zip(a_, b_)), "step %d rank %d particle %d" % (step, r, i)
-                print("step %d ok (device plan, IPC push)" % step, flush=True)
+                print("step %d ok (device plan, IPC push%s)" % (step, ", landing flags" if flags else ""), flush=True)
             continue
         lw = dev(lib.phd_device_local_weights(h), Pl).cpu()
         gw_host = torch.empty(Pg, dtype=torch.float64)

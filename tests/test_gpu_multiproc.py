@@ -1,7 +1,8 @@
 """Two / three real processes, one rank each, sharing the GPU: the sharded SlamUpdate (collectives on gloo, staged through
 host memory because RCCL refuses two ranks on one device) against a single handle holding all particles — in the sequence
 bench.py runs (plan on the device, migrating particles stored into the other processes' IPC-opened buffers, no host wait) and
-in round 3's (host-side split sizes, all_to_all_single)."""
+with the landing flags in place of the barrier behind the push (round 5: nothing between push and unpack), and in round 3's
+(host-side split sizes, all_to_all_single)."""
 import os
 import subprocess
 import sys
@@ -13,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,mode", [(2, "device"), (3, "device"), (2, "host"), (3, "host")])
+@pytest.mark.parametrize("world,mode", [(2, "device"), (3, "device"), (2, "flags"), (3, "flags"), (2, "host"), (3, "host")])
 def test_sharded_sequence_in_real_processes(world, mode):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29530 + world))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")

@@ -83,3 +83,172 @@ def test_emit_and_prune_as_one_launch_or_two(nav_mod, monkeypatch, M):
         assert np.array_equal(got[mode][0], got["default"][0]) and np.array_equal(got[mode][1], got["default"][1]), "PHD_FUSE_EP=%s" % mode
         for a, b in zip(got[mode][2], got["default"][2]):
             assert all(np.array_equal(x, y) for x, y in zip(a, b)), "PHD_FUSE_EP=%s" % mode
+
+
+# ---- the landing flags: no second collective in the sharded step (phd_migration_set_landing) -------------------------------------
+def _depleted_frame(world, Pl, Cc, M, seed):
+    f = Frame(Pl * world, Cc, M, seed, weight_profile="steady")
+    f.weights = np.random.default_rng(world).random(f.P) ** 12      # depleted from the start: the first step resamples, long runs cross the rank boundaries
+    f.weights /= f.weights.sum()
+    return f
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_landing_flags_sharded_step_equals_single_handle(nav_mod, world):
+    """The device-path sequence with phd_migration_set_landing(1): k_post_landing behind every push, k_finish_sharded waiting for
+    the flags of the ranks it takes records from — `world` handles in one process on one stream (every push is enqueued before
+    any unpack, so the waits find their flags), bit for bit the single handle, over steps that resample and migrate and one that
+    does not (no records: nobody waits)."""
+    from test_gpu_round4 import _device_path_handles, _device_path_step
+    Pl, Cc, M = 56, 70, 18
+    f = _depleted_frame(world, Pl, Cc, M, 5100 + world)
+    p1 = prm3d_defaults(max_particles=Pl * world, max_components=600, max_measurements=M)
+    one = nav_mod.PHDNavigator(p1, particlecount=Pl * world)
+    one.upload_state(f.planes(), f.counts, f.poses, f.weights)
+    navs = _device_path_handles(nav_mod, f, world, Pl, M)
+    for nv in navs:
+        if nv._lib.phd_migration_recv_is_finegrained(nv._h) != 1:
+            pytest.skip("no fine-grained receive buffers on this box")
+        nv._check(nv._lib.phd_migration_set_landing(nv._h, 1))
+    nres = 0
+    for u in (0.31, 0.77, 0.12):
+        one.SlamUpdate(None, f.z, u_resample=u)
+        _device_path_step(navs, Pl, u)
+        nres += int(one.resample_sources()[1])
+        assert np.array_equal(one.VehicleWeights, np.concatenate([nv.VehicleWeights for nv in navs]))
+        assert np.array_equal(one.poses(), np.concatenate([nv.poses() for nv in navs]))
+        for g in list(range(0, Pl * world, 7)) + [Pl * world - 1]:
+            a_, b_ = one.MapModel(g), navs[g // Pl].MapModel(g % Pl)
+            assert all(np.array_equal(x, y) for x, y in zip(a_, b_)), "particle %d" % g
+    assert nres >= 1, "the sequence did not resample: the flags were never waited for"
+    one.close()
+    for nv in navs:
+        nv.close()
+
+
+def test_a_landing_flag_that_never_comes_is_a_bounded_wait(nav_mod, monkeypatch):
+    """rank 0 ends a resampling step whose records rank 1 never pushed: its k_finish_sharded gives up after the bound (1.5 s here) and phd_sync
+    reports the step as failed (a peer died) — a bounded wait, not a hung device"""
+    import time
+    from test_gpu_round4 import _Dev, _device_path_handles
+    import torch
+    monkeypatch.setenv("PHD_LANDING_TIMEOUT_MS", "1500")
+    world, Pl, Cc, M = 2, 56, 70, 18
+    f = _depleted_frame(world, Pl, Cc, M, 5102)
+    f.weights[Pl:] *= 50.0            # the heavy particles live on rank 1: rank 0's slots take records from there
+    f.weights /= f.weights.sum()
+    navs = _device_path_handles(nav_mod, f, world, Pl, M)
+    lib = navs[0]._lib
+    for nv in navs:
+        if lib.phd_migration_recv_is_finegrained(nv._h) != 1:
+            pytest.skip("no fine-grained receive buffers on this box")
+        nv._check(lib.phd_migration_set_landing(nv._h, 1))
+    for nv in navs:
+        nv._check(lib.phd_step_local_async(nv._h, 0))
+    allw = torch.cat([torch.as_tensor(_Dev(lib.phd_device_local_weights(nv._h), Pl + 1), device="cuda") for nv in navs])
+    for nv in navs:
+        torch.as_tensor(_Dev(lib.phd_device_gather_buffer(nv._h, world), world * (Pl + 1)), device="cuda").copy_(allw)
+    for r, nv in enumerate(navs):
+        nv._check(lib.phd_step_global_device_async(nv._h, r, world, C.c_double(0.31), 0))
+    navs[0]._check(lib.phd_migration_push_async(navs[0]._h))        # rank 1 never pushes
+    navs[0]._check(lib.phd_migration_unpack_async(navs[0]._h))
+    t0 = time.time()
+    with pytest.raises(nav_mod.PHDError):
+        navs[0].sync()
+    assert 1.0 < time.time() - t0 < 30.0
+    for nv in navs:
+        nv.close()
+
+
+# ---- normalise / BestParticle / depletion / resampling over a grid of workgroups (k_nr_*, phd_resample.h) ---------------------------
+def _resample_vectors(P, rng):
+    vectors = {"uniform": np.full(P, 1.0 / P)}
+    w = rng.random(P) ** 6
+    vectors["random^6"] = w / w.sum()
+    w = rng.random(P) * (rng.random(P) < 0.1)
+    w[rng.integers(P)] += 1e-3
+    vectors["nine tenths zero"] = w / w.sum()
+    for at in sorted({0, P // 2, P - 1}):
+        w = np.zeros(P)
+        w[at] = 1.0
+        vectors["all in %d" % at] = w
+    w = np.where(np.arange(P) % 2 == 0, 1.0, 1e-12)
+    vectors["alternating"] = w / w.sum()
+    return vectors
+
+
+def test_grid_resampling_at_every_size_and_on_degenerate_weights(nav_mod, monkeypatch):
+    """The grid kernels forced on EVERY vector length (PHD_NR_GRID_MIN=1; by default they take 4096 .. 65 536 weights): one
+    workgroup and many, lengths around the workgroup and wave boundaries, vectors that sit on the slot boundaries (uniform:
+    the margin test fails and one wave replays the recurrence), mostly zeros, one particle holding everything, u at both ends —
+    sources and BestParticle bit-exact against the sequential recurrence (PHDNavigator.cs:724-760), the depletion test too."""
+    monkeypatch.setenv("PHD_NR_GRID_MIN", "1")
+    p = prm3d_defaults(max_particles=4, max_components=600, max_measurements=8)
+    nav = nav_mod.PHDNavigator(p, particlecount=4)
+    rng = np.random.default_rng(12)
+    for P in [1, 2, 3, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1000, 1024, 1025, 4097, 12345, 16384, 65536]:
+        for name, w in _resample_vectors(P, rng).items():
+            for u in (0.0, 2.0 ** -60, 0.5, 1.0 - 2.0 ** -53):
+                src, best = nav.ResampleParticles(w, u)
+                osrc, obest = orc.resample(w, u)
+                assert np.array_equal(src, osrc), "P=%d %s u=%g: %d sources differ" % (P, name, u, np.count_nonzero(src != osrc))
+                assert best == obest, "P=%d %s u=%g: best %d, oracle %d" % (P, name, u, best, obest)
+            assert nav.ParticleDepleted(w) == orc.particle_depleted(p, w), "P=%d %s" % (P, name)
+    nav.close()
+
+
+def test_vectors_beyond_the_grid_take_the_one_workgroup_kernel(nav_mod):
+    """65 537 weights and more: the grid's statistics block holds 256 workgroups — the one-workgroup kernel's global-memory walk it is"""
+    p = prm3d_defaults(max_particles=4, max_components=600, max_measurements=8)
+    nav = nav_mod.PHDNavigator(p, particlecount=4)
+    rng = np.random.default_rng(13)
+    for P in (65537, 70000):
+        w = rng.random(P) ** 8
+        w /= w.sum()
+        src, best = nav.ResampleParticles(w, 0.37)
+        osrc, obest = orc.resample(w, 0.37)
+        assert np.array_equal(src, osrc) and best == obest
+    nav.close()
+
+
+@pytest.mark.parametrize("frozen", [False, True])
+def test_steps_that_end_on_the_grid_kernels(nav_mod, monkeypatch, frozen):
+    """Whole SlamUpdate steps whose end (normalise, BestParticle, depletion, resampling, the gather of the small arrays, the
+    rotation of the bank roles) runs on the grid kernels (forced: PHD_NR_GRID_MIN=64) against the oracle and against a handle
+    that ends its steps on the one-workgroup kernel: resampling decision, sources and BestParticle exact, weights to the
+    tolerance of two summation orders (1e-12 between the kernels, 1e-6 against the oracle), maps bit for bit."""
+    f = Frame(300, 50, 12, 520, weight_profile="steady")
+    f.weights = np.random.default_rng(5).random(f.P) ** 8     # a depleted set: the first step resamples (the frozen runs repeat that step)
+    f.weights /= f.weights.sum()
+    one, p = _handle(nav_mod, f)
+    monkeypatch.setenv("PHD_NR_GRID_MIN", "64")
+    grid, _ = _handle(nav_mod, f)
+    st = orc.State(f.P, 700)
+    st.poses[:] = f.poses
+    st.w[:, :f.C], st.mean[:, :f.C], st.cov[:, :f.C], st.n[:] = f.w, f.mean, f.cov, f.C
+    st.weights[:] = f.weights
+    rng = np.random.default_rng(521)
+    nres = 0
+    for step in range(4):
+        z = f.z + rng.normal(size=f.z.shape) * np.sqrt([2.0, 2.0, 1e-3]) * 0.3
+        u = float(rng.uniform(0.05, 0.95))
+        if frozen:          # the frozen step leaves the state where it was: every step starts from the same one, on both handles
+            one.set_frozen(True)
+            grid.set_frozen(True)
+        one.SlamUpdate(None, z, u_resample=u)
+        grid.SlamUpdate(None, z, u_resample=u)
+        (s1, r1), (s2, r2) = one.resample_sources(), grid.resample_sources()
+        assert r1 == r2 and np.array_equal(s1, s2), "step %d: the two kernels resample differently" % step
+        assert one.BestParticle == grid.BestParticle
+        assert np.allclose(one.VehicleWeights, grid.VehicleWeights, rtol=1e-12, atol=0)
+        for i in (0, 17, 150, f.P - 1):
+            assert all(np.array_equal(x, y) for x, y in zip(one.MapModel(i), grid.MapModel(i))), "step %d map %d" % (step, i)
+        assert np.array_equal(one.poses(), grid.poses())
+        if not frozen:
+            best, src, res, _ = orc.slam_update(p, st, z, u=u, threads=4)
+            assert res == r2 and np.array_equal(src, s2) and best == grid.BestParticle
+            assert np.allclose(grid.VehicleWeights, st.weights, rtol=1e-6, atol=1e-300)
+        nres += int(r2)
+    assert nres >= 1, "no step resampled"
+    one.close()
+    grid.close()
