@@ -48,7 +48,10 @@ __device__ __forceinline__ void load_predicted(const DevParams& prm, const StepB
 // LEAN (the fused launch k_emit_prune, compiled at the prune's 128 registers): the component's mean and covariance are read AGAIN
 // behind the gain instead of living through the 3 x 3 inverse; where the registers are not short (k_emit_finish at three waves
 // per SIMD, the one-launch chain) the second read only adds a trip to the chain.
-template <bool LEAN = false>
+// SPREAD (the one-launch chain: one workgroup per CU, one wave per SIMD): the runs are dealt to the four waves in turn, so that all
+// four SIMDs work on a short list; on a full machine a wave takes 64 neighbouring runs (fewest wave-passes through the Kalman path:
+// the SIMDs are shared with three other workgroups in the same phase).
+template <bool LEAN = false, bool SPREAD = false>
 __device__ __forceinline__ void emit_finish_body(const DevParams& prm, const StepBufs& a, double* pool)
 {
 	double* const etab = pool;
@@ -204,12 +207,14 @@ __device__ __forceinline__ void emit_finish_body(const DevParams& prm, const Ste
 			if (tid == 0) { s_nlist = 0; s_nlead = 0; }
 			__syncthreads();   // (also: ldenom is written)
 			const int cend = min(ncw, ch0 + EMIT_CAP / 4);
+			int2 nxt = (ch0 + lane < cend) ? seg[ch0 + lane] : make_int2(0, 0);   // (the queue is read one group of 64 ahead)
 			for (int j0 = ch0; j0 < cend; j0 += 64) {
 				const int j = j0 + lane;
 				bool keep = false;
 				int  code = 0;
+				const int2 cd = nxt;
+				nxt = (j + 64 < cend) ? seg[j + 64] : make_int2(0, 0);
 				if (j < cend) {
-					const int2 cd = seg[j];
 					code = cd.x;
 					const double x = (double) __int_as_float(cd.y);
 					keep = !(x - ldenom[code & 255] < lminw - 1e-3 - 1e-6 * fabs(x));
@@ -248,8 +253,8 @@ __device__ __forceinline__ void emit_finish_body(const DevParams& prm, const Ste
 #ifdef PHD_STAMPS
 			const long long em_p0 = clock64();
 #endif
-			for (int t0 = wv * 64; t0 < nlead; t0 += 256) {   // (wave-uniform: a wave without a head left skips the Kalman path)
-				const int t = t0 + lane;
+			for (int t0 = SPREAD ? 0 : wv * 64; t0 < nlead; t0 += 256) {   // (wave-uniform: a wave without a head left skips the Kalman path)
+				const int t = SPREAD ? t0 + lane * 4 + wv : t0 + lane;
 				if (t < nlead) {
 					const int hd = lead[t];
 					const int* run = list + (hd >> 8);

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, 1) void k_particle_chain(const DevParams prm, 
 	sweep_body<ZB, HALF>(prm, a, smem);
 	__syncthreads();   // (workgroup scope: the global writes of the step before are visible to this workgroup's loads)
 	PHD_STAMP(1);
-	emit_finish_body(prm, a, smem);
+	emit_finish_body<false, true>(prm, a, smem);
 	__syncthreads();
 	PHD_STAMP(2);
 	prune_merge_body(prm, a, cutcap, smem);
@@ -689,6 +689,226 @@ __global__ __launch_bounds__(1024) void k_plan_migration(const int* __restrict__
 		for (int t = tid; t < n; t += nt) {
 			__hip_atomic_store(hostcounts + t, (live && t != rank) ? cnt[t * n + rank] : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			__hip_atomic_store(hostcounts + n + t, (live && t != rank) ? cnt[rank * n + t] : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+		if (tid == 0) {
+			__hip_atomic_store(hostcounts + 2 * n, nsend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(hostcounts + 2 * n + 1, nrecv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(hostcounts + 2 * n + 2, status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(hostcounts + 2 * n + 3, resampled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(hostcounts + 2 * n + 4, info[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(hostcounts + 2 * n + 5, *lflags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		}
+		__threadfence_system();
+		__syncthreads();
+		if (tid == 0) __hip_atomic_store(hostcounts + 2 * n + 6, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+}
+
+// =================================================================================================================================
+// The same plan over a GRID of workgroups (round 5), for global vectors of PLAN_GRID_MIN slots and more: one workgroup of 1024
+// threads took 34 us for the five passes over an 8 x 2048 vector — instruction-bound on ONE compute unit, on every rank, in
+// every resampling step. Here every thread owns one slot of the global vector and two launches do the work:
+//   k_plan_count   every slot: is it the head of a run that needs a record (flags of neighbouring slots, as above)? The n x n
+//                  count matrix by atomics (only heads add: a few hundred), per wave the heads whose source is MINE (the send
+//                  list's order) and, over this rank's own slots, the heads at all (the record numbers) and the bitmap of OUT
+//                  slots that stay a local particle's source
+//   k_plan_lists   positions = (counts of the waves before) + (heads before in the wave): the send list with each record's
+//                  destination and number, the code of every local slot; one workgroup lays the arrivals' free slots out and
+//                  writes the counts (to the host too, when it waits for them)
+// Two sets of the accumulators alternate between launches: k_plan_lists clears the set the NEXT pair of launches adds to, so
+// that no launch — and no memset on the stream — stands between the resampling kernel and k_plan_count.
+#define PLAN_GRID_MIN 4096
+#define PLAN_GRID_MAXSLOTS 65536          // per-wave count arrays: 1024 global waves
+
+struct PlanGrid {
+	int* cnt;      // [n][n] records rank t takes from rank s            (this launch pair's set)
+	int* wcg;      // [Pg / 64] heads whose source is mine, per global wave
+	int* lcg;      // [Pl / 64] heads among my own slots, per local wave
+	unsigned int* used;   // [(Pl + 31) / 32] bit c: OUT slot c stays the source of a local particle
+	int* bad;      // [1]
+	int* cnt_next; unsigned int* used_next; int* bad_next;   // the other set: cleared by k_plan_lists
+};
+
+// the flags of slot g (see k_plan_migration): source, owner rank, source rank, head of a run fed from another rank, malformed
+__device__ __forceinline__ void plan_look(const int* __restrict__ gsrc, int g, int Pg, int Pl, float rPl, bool bigidx, int lane,
+                                          int& s, int& t, int& sr, bool& head, bool& bad)
+{
+	s = (g < Pg) ? gsrc[g] : 0;
+	int prev = __shfl_up(s, 1, 64);
+	if (lane == 0) prev = (g > 0 && g < Pg) ? gsrc[g - 1] : 0;
+	auto rank_of = [&](int x) { return bigidx ? x / Pl : small_div(x, Pl, rPl); };
+	bad = g < Pg && (s < 0 || s >= Pg || (g > 0 && prev > s));
+	t = rank_of(min(g, Pg - 1));
+	sr = rank_of(min(max(s, 0), Pg - 1));
+	head = g < Pg && sr != t && (g == t * Pl || prev != s);
+}
+
+// a flag raised on this rank, or — the gathered status words, one per lane — on any other: one trip to memory
+__device__ __forceinline__ bool plan_dropped(const int* lflags, const double* gflags, int n, int lane)
+{
+	const int lf = *lflags;
+	const double gf = (gflags && lane < n) ? gflags[lane] : 0.0;
+	return lf != 0 || ballot64(gf != 0.0) != 0ull;
+}
+
+__global__ __launch_bounds__(256) void k_plan_count(const int* __restrict__ gsrc, const int* __restrict__ info, const int* lflags,
+                                                    const double* gflags, int Pl, int n, int rank, PlanGrid pg, const StepBufs a, const double* gw)
+{
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int Pg = Pl * n, first = rank * Pl, g = blockIdx.x * 256 + tid;
+	int s, t, sr;
+	bool head, bad;
+	const bool bigidx = Pg >= (1 << 24);
+	plan_look(gsrc, g, Pg, Pl, 1.0f / (float) Pl, bigidx, lane, s, t, sr, head, bad);   // (its loads are in flight while the status words arrive)
+	if (gw && g >= first && g < first + Pl) bank_of(a, SEL_OUT).weights[g - first] = gw[g];   // this rank's slice of the (normalised, or 1 / P) weights
+	const int resampled = info[1];
+	const bool drop = plan_dropped(lflags, gflags, n, lane);
+	if (drop || !resampled) return;   // dropped, or not resampled: nothing moves (k_plan_lists writes the status)
+	if (bad) atomicOr(pg.bad, 1);
+	if (head && !bad) atomicAdd(&pg.cnt[t * n + sr], 1);
+	const unsigned long long mine = ballot64(head && !bad && sr == rank);
+	if (lane == 0 && g < Pg) pg.wcg[blockIdx.x * 4 + wv] = __popcll(mine);
+	// (Pl is a multiple of 64 here — the host takes the one-workgroup kernel otherwise —: a wave's slots belong to one rank)
+	const bool myslot = g < Pg && t == rank;
+	if (myslot) {
+		// the heads among my own slots, per wave of them: the records' numbers (k_plan_lists)
+		const unsigned long long lb = ballot64(head && !bad);
+		if (lane == 0) pg.lcg[(g - first) >> 6] = __popcll(lb);
+	}
+	// The OUT slots that stay a local particle's source, as a bitmap. The sources never decrease, so a wave's 64 slots name a run
+	// of neighbouring bits — mostly the same few: the lanes OR theirs together per word first (an atomic per slot was 2048
+	// atomics on 64 words, serialised at the L2: most of this launch) and the first lane of each word's run adds it.
+	{
+		const bool loc = myslot && sr == rank && !bad;
+		const int word = loc ? (s - first) >> 5 : -1 - lane;   // (distinct negative numbers: no run)
+		unsigned int bits = loc ? 1u << ((s - first) & 31) : 0u;
+		// segmented OR over runs of equal `word` (the lanes of a run are neighbours): log steps, a lane takes what the lane `o`
+		// further on holds when that lane belongs to the same word
+#pragma unroll
+		for (int o = 1; o < 64; o <<= 1) {
+			const int wo = __shfl_down(word, o, 64);
+			const unsigned int bo = __shfl_down(bits, o, 64);
+			if (lane + o < 64 && wo == word) bits |= bo;
+		}
+		const int wp = __shfl_up(word, 1, 64);
+		if (loc && (lane == 0 || wp != word)) atomicOr(&pg.used[word], bits);
+	}
+}
+
+__global__ __launch_bounds__(256) void k_plan_lists(const int* __restrict__ gsrc, const int* __restrict__ info, const int* lflags,
+                                                    const double* gflags, int Pl, int n, int rank, MigPlan pl, PlanGrid pg, int* hostcounts, int seq)
+{
+	__shared__ int s_cnt[64 * 64], s_base[64], s_roff[64], s_w[20], s_ns, s_nr;   // (at most 64 ranks: PHD_MAX_DEVICES)
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+	const int Pg = Pl * n, first = rank * Pl, g = blockIdx.x * 256 + tid;
+	int s, t, sr;
+	bool head, bad;
+	const bool bigidx = Pg >= (1 << 24);
+	plan_look(gsrc, g, Pg, Pl, 1.0f / (float) Pl, bigidx, lane, s, t, sr, head, bad);
+	// the accumulators of the next pair of launches
+	{
+		const int gt = blockIdx.x * 256 + tid, gn = gridDim.x * 256;
+		for (int q = gt; q < n * n; q += gn) pg.cnt_next[q] = 0;
+		for (int q = gt; q < (Pl + 31) / 32; q += gn) pg.used_next[q] = 0u;
+		if (gt == 0) pg.bad_next[0] = 0;
+	}
+	// Everything this launch reads of k_plan_count's results is requested up front, together — the count matrix into LDS, the
+	// waves' counts into registers — and only then looked at: every dependent trip to memory is a microsecond here.
+	const int resampled = info[1], badword = pg.bad[0];
+	const bool drop = plan_dropped(lflags, gflags, n, lane);
+	int cv[16];
+#pragma unroll
+	for (int q = 0; q < 16; q++) cv[q] = (tid + 256 * q < n * n) ? pg.cnt[tid + 256 * q] : 0;
+	const int gwv = blockIdx.x * 4 + wv;                 // this wave's number among all slots' waves (at most 1024)
+	const bool myslots = g < Pg && t == rank;            // (wave-uniform: Pl is a multiple of 64)
+	const int lw = myslots ? (g - first) >> 6 : 0;       // ... and among my own slots' waves
+	int wq[16], lq[16];
+#pragma unroll
+	for (int q = 0; q < 16; q++) {
+		wq[q] = (lane + 64 * q < gwv) ? pg.wcg[lane + 64 * q] : 0;
+		lq[q] = (lane + 64 * q < lw) ? pg.lcg[lane + 64 * q] : 0;
+	}
+#pragma unroll
+	for (int q = 0; q < 16; q++) if (tid + 256 * q < n * n) s_cnt[tid + 256 * q] = cv[q];
+	__syncthreads();
+	if (tid < n) {
+		int b = 0, r = 0;
+		for (int q = 0; q < tid; q++) b += (q != rank) ? s_cnt[q * n + rank] : 0;      // destinations before `tid`
+		for (int q = 0; q < rank; q++) r += (q != tid) ? s_cnt[tid * n + q] : 0;       // sources before me at destination `tid`
+		s_base[tid] = b; s_roff[tid] = r;
+	}
+	if (wv == 0) {
+		int ns = (lane < n && lane != rank) ? s_cnt[lane * n + rank] : 0, nr_ = (lane < n && lane != rank) ? s_cnt[rank * n + lane] : 0;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) { ns += __shfl_xor(ns, o, 64); nr_ += __shfl_xor(nr_, o, 64); }
+		if (lane == 0) { s_ns = ns; s_nr = nr_; }
+	}
+	__syncthreads();
+	int status = drop ? MIG_DROPPED : MIG_OK, nsend = 0, nrecv = 0;
+	if (resampled && !drop) {
+		if (badword) status = MIG_BAD;
+		nsend = s_ns; nrecv = s_nr;
+		if (status == MIG_OK && nsend > pl.sendcap) status = MIG_OVERFLOW;
+	}
+	const bool live = resampled && status == MIG_OK;
+	if (live) {
+		// heads of mine in the waves before this one; heads among my slots in the local waves before
+		int acc = 0, lacc = 0;
+#pragma unroll
+		for (int q = 0; q < 16; q++) { acc += wq[q]; lacc += lq[q]; }
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) { acc += __shfl_xor(acc, o, 64); lacc += __shfl_xor(lacc, o, 64); }
+		const bool mine = head && sr == rank;
+		const unsigned long long bal = ballot64(mine);
+		if (mine) {
+			const int k = acc + __popcll(bal & lanemask_lt());
+			pl.sendlist[k] = s - first;
+			pl.senddst[k] = ((long long) t << 32) | (long long) (s_roff[t] + (k - s_base[t]));
+		}
+		if (myslots) {   // (wave-uniform)
+			const int i = g - first;
+			// heads up to and including this slot, among my slots: the number of the record that feeds it (a slot inside a run
+			// carries the count of its run's head: no head lies in between)
+			const unsigned long long hb = ballot64(head);
+			if (sr == rank) pl.code[i] = s - first;
+			else pl.code[i] = -(lacc + __popcll(hb & (lanemask_lt() | (1ull << lane))));   // record (that count) - 1
+		}
+	}
+	if (blockIdx.x != 0) return;
+	// ---- one workgroup: the arrivals' free slots, the counts
+	if (live) {
+		const int words = (Pl + 31) / 32, CHW = (words + 255) / 256;
+		const int e0 = min(words, tid * CHW), e1 = min(words, e0 + CHW);
+		int nfree = 0;
+		for (int e = e0; e < e1; e++) {
+			unsigned int fr = ~pg.used[e];
+			if (e == words - 1 && (Pl & 31)) fr &= (1u << (Pl & 31)) - 1u;
+			nfree += __popc(fr);
+		}
+		int totfree;
+		int f = block_excl_scan(nfree, s_w, tid, &totfree);
+		for (int e = e0; e < e1 && f < nrecv; e++) {
+			unsigned int fr = ~pg.used[e];
+			if (e == words - 1 && (Pl & 31)) fr &= (1u << (Pl & 31)) - 1u;
+			while (fr && f < nrecv) {
+				const int bit = __ffs((int) fr) - 1;
+				fr &= fr - 1;
+				pl.fslot[f++] = e * 32 + bit;
+			}
+		}
+	}
+	else { nsend = 0; nrecv = 0; }
+	for (int q = tid; q < n; q += 256) {
+		pl.counts[q]     = (live && q != rank) ? s_cnt[q * n + rank] : 0;
+		pl.counts[n + q] = (live && q != rank) ? s_cnt[rank * n + q] : 0;
+	}
+	if (tid == 0) {
+		pl.counts[2 * n] = nsend; pl.counts[2 * n + 1] = nrecv; pl.counts[2 * n + 2] = status; pl.counts[2 * n + 3] = resampled;
+	}
+	if (hostcounts) {
+		for (int q = tid; q < n; q += 256) {
+			__hip_atomic_store(hostcounts + q, (live && q != rank) ? s_cnt[q * n + rank] : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__hip_atomic_store(hostcounts + n + q, (live && q != rank) ? s_cnt[rank * n + q] : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 		if (tid == 0) {
 			__hip_atomic_store(hostcounts + 2 * n, nsend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

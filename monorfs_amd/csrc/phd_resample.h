@@ -578,7 +578,7 @@ __global__ __launch_bounds__(64) void k_gate(const unsigned int* done, unsigned 
 //   k_nr_slots    depleted? (PHDNavigator.cs:768-777); if not: identity sources, BestParticle, the roles. Else per particle the
 //                 slots it takes, [N(S_k), N(S_k+1)) — the verified speculation of the kernel above, one particle per thread —,
 //                 the margin tests, the candidate for BestParticle
-//   k_nr_sources  every slot finds its source by bisection over the particles' upper slot bounds (non-decreasing), the weights
+//   k_nr_sources  every slot finds its source by a sixteen-way search over the particles' upper slot bounds (non-decreasing), the weights
 //                 become 1 / P, the small arrays of the resampled particles are gathered, the roles rotate; one wave replays
 //                 the recurrence literally when a margin test failed (never seen outside the tests that force it)
 // The shape of every sum depends on the length of the vector only, as in the one-workgroup kernel: all ranks of a sharded run
@@ -597,14 +597,14 @@ struct NrGrid {
 	int     G;
 };
 
-// Exclusive double-double scan over the workgroups' sums (G <= 256 values, stat[g * NR_STAT + 5 / 6]) by the 256 threads of a
+// Exclusive double-double scan over the workgroups' sums (G <= 256 values, thread q holding workgroup q's) by the 256 threads of a
 // workgroup — every workgroup computes the same numbers from the same block: excl <- the prefix in front of workgroup g,
 // next <- the prefix in front of workgroup g + 1 (the total behind the last). s_hi / s_lo: 8 doubles of LDS each.
-__device__ __forceinline__ void nr_scan_groups(const double* stat, int G, int g, double* s_hi, double* s_lo, int tid, dd& excl, dd& next)
+__device__ __forceinline__ void nr_scan_groups(dd mine, int g, double* s_hi, double* s_lo, int tid, dd& excl, dd& next)
 {
 #pragma clang fp contract(off)
 	const int lane = tid & 63, wv = tid >> 6;
-	dd inc = (tid < G) ? dd{stat[(size_t) tid * NR_STAT + 5], stat[(size_t) tid * NR_STAT + 6]} : dd{0, 0};
+	dd inc = mine;   // workgroup `tid`'s sum (zero beyond the last workgroup)
 #pragma unroll
 	for (int o = 1; o < 64; o <<= 1) {
 		dd y = {shfl_up_d(inc.hi, o), shfl_up_d(inc.lo, o)};
@@ -671,11 +671,16 @@ __global__ __launch_bounds__(256) void k_nr_stats(const StepBufs a, double* gw, 
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = blockIdx.x, k = g * 256 + tid;
 	const int flags_now = sel_next ? *a.flags : 0;
 	double wk = nr_weight(a, gw, k, k < P);
+	// (the workgroups' partial sums: one per thread, requested with the weight above — a loop over them was a chain of dependent trips
+	// to memory, one per workgroup; the tree below has the same shape in every workgroup)
 	double nsum = 1;
 	if (!skip_normalise) {
-		double sum = 0;
-		for (int q = 0; q < nr.G; q++) sum += nr.part[(size_t) q * NR_STAT];   // the same order in every workgroup
+		const double pv = wave_sum((tid < nr.G) ? nr.part[(size_t) tid * NR_STAT] : 0.0);
+		if (lane == 0) s4[wv] = pv;
+		__syncthreads();
+		const double sum = ((s4[0] + s4[1]) + s4[2]) + s4[3];
 		nsum = (sum == 0) ? 1 : sum;
+		__syncthreads();   // (s4 is used again below)
 	}
 	if (flags_now != 0) return;
 	if (tid == 0) s_bad = 0;
@@ -732,15 +737,34 @@ __global__ __launch_bounds__(256) void k_nr_slots(const StepBufs a, double* gw, 
 	const double wk = nr_weight(a, gw, k, live);
 	const dd incl = live ? dd{nr.pre[(size_t) k * 2], nr.pre[(size_t) k * 2 + 1]} : dd{0, 0};
 	if (flags_now != 0) return;
-	// what every workgroup derives alike from the statistics block
-	double cum = 0, gmax = -INFINITY;
-	int gbest = 0;
-	bool bad = false;
-	for (int q = 0; q < nr.G; q++) {
-		const double* st = nr.part + (size_t) q * NR_STAT;
-		cum += st[1];
-		if (st[2] > gmax) { gmax = st[2]; gbest = (int) st[3]; }
-		bad = bad || st[4] != 0.0;
+	// what every workgroup derives alike from the statistics block: workgroup `tid`'s entries by thread `tid`, one trip to memory
+	// (a loop over the workgroups was a chain of dependent trips), then a tree of the same shape everywhere
+	double cum, gmax;
+	int gbest;
+	bool bad;
+	dd gsum;   // workgroup `tid`'s double-double sum, for the scan below
+	{
+		const bool has = tid < nr.G;
+		const double* st = nr.part + (size_t) (has ? tid : 0) * NR_STAT;
+		const double q1 = has ? st[1] : 0.0, q2 = has ? st[2] : -INFINITY, q3 = has ? st[3] : 0.0, q4 = has ? st[4] : 0.0;
+		gsum = has ? dd{st[5], st[6]} : dd{0, 0};
+		const double csum = wave_sum(q1);
+		double m = q2;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+		const unsigned long long mb = ballot64(has && q2 == m);
+		const int fl = mb ? __ffsll((long long) mb) - 1 : 0;
+		const int gi = (int) __shfl(q3, fl, 64);
+		const unsigned long long bb = ballot64(q4 != 0.0);
+		if (lane == 0) { s_hi[wv] = csum; s_lo[wv] = mb ? m : -INFINITY; s_hilast[wv] = gi; s_bw[wv] = bb ? 1.0 : 0.0; }
+		__syncthreads();
+		cum = ((s_hi[0] + s_hi[1]) + s_hi[2]) + s_hi[3];
+		gmax = -INFINITY; gbest = 0;
+		for (int w = 0; w < 4; w++) {
+			if (s_lo[w] > gmax) { gmax = s_lo[w]; gbest = s_hilast[w]; }   // first maximum: the workgroups in order
+		}
+		bad = (s_bw[0] + s_bw[1] + s_bw[2] + s_bw[3]) != 0.0;
+		__syncthreads();   // (the arrays are used again below)
 	}
 	if (!(gmax > 0)) gbest = 0;   // maxweight starts at 0 and the comparison is strict (:347-353)
 	bool depleted = (1.0 / cum < min_eff * P);   // :776
@@ -766,7 +790,7 @@ __global__ __launch_bounds__(256) void k_nr_slots(const StepBufs a, double* gw, 
 	// before; the numbers on the two sides of every boundary — between lanes, waves and workgroups — are the same numbers, so the
 	// ranges tile [0, P).
 	dd woff, wnext;
-	nr_scan_groups(nr.part, nr.G, g, s_hi, s_lo, tid, woff, wnext);
+	nr_scan_groups(gsum, g, s_hi, s_lo, tid, woff, wnext);
 	if (tid == 0) { s_ok = 1; s_best = 0x7fffffff; }
 	const double R0 = u / P, invP = 1.0 / P;
 	const double B = 8.0 * P * 1.1102230246251565e-16 * (fmax(gmax, 0.0) + fabs(R0) + invP);
@@ -817,18 +841,33 @@ __global__ __launch_bounds__(256) void k_nr_slots(const StepBufs a, double* gw, 
 __global__ __launch_bounds__(256) void k_nr_sources(const StepBufs a, double* gw, int P, double u, int* src, int* info, int* sel_next,
                                                     int frozen, int* inslot, NrGrid nr)
 {
-	const int tid = threadIdx.x, lane = tid & 63, g = blockIdx.x, i = g * 256 + tid;
+	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = blockIdx.x, i = g * 256 + tid;
 	const int flags_now = sel_next ? *a.flags : 0, depleted = nr.state[0];
 	if (flags_now != 0 || depleted == 0) return;   // a dropped step | not depleted: k_nr_slots ended the step
 	double* gwp = gw ? gw : bank_of(a, SEL_OUT).weights;
-	bool ok = true;
-	double gm = -INFINITY;
-	int best = 0x7fffffff;
-	for (int q = 0; q < nr.G; q++) {
-		const double* r = nr.slotres + (size_t) q * NR_SLOT;
-		ok = ok && r[0] != 0.0;
-		if (r[1] > gm) { gm = r[1]; best = (int) r[2]; }
-		else if (r[1] == gm && (int) r[2] < best) best = (int) r[2];
+	// the workgroups' verdicts and candidates: one per thread, one trip, then the same reduction everywhere
+	__shared__ double s_gm[4];
+	__shared__ int s_bs[4], s_okw[4];
+	bool ok;
+	double gm;
+	int best;
+	{
+		const bool has = tid < nr.G;
+		const double* r = nr.slotres + (size_t) (has ? tid : 0) * NR_SLOT;
+		const double r0 = has ? r[0] : 1.0, r1 = has ? r[1] : -INFINITY, r2 = has ? r[2] : 2147483647.0;
+		double m = r1;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+		int bs = (has && r1 == m) ? (int) r2 : 0x7fffffff;   // the smallest slot among the candidates with the largest weight
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) bs = min(bs, __shfl_xor(bs, o, 64));
+		const unsigned long long nb = ballot64(r0 == 0.0);
+		if (lane == 0) { s_gm[wv] = m; s_bs[wv] = bs; s_okw[wv] = nb ? 0 : 1; }
+		__syncthreads();
+		gm = fmax(fmax(s_gm[0], s_gm[1]), fmax(s_gm[2], s_gm[3]));
+		best = 0x7fffffff;
+		for (int w = 0; w < 4; w++) if (s_gm[w] == gm) best = min(best, s_bs[w]);
+		ok = (s_okw[0] & s_okw[1] & s_okw[2] & s_okw[3]) != 0;
 	}
 	const Bank bo = bank_of(a, SEL_OUT), bt = bank_of(a, SEL_TMP);
 	auto finish_slot = [&](int s_i, int slot) {   // slot `slot` takes particle s_i: the small arrays of the resampled state (rotate_roles above)

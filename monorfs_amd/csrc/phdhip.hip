@@ -131,6 +131,9 @@ struct phd_navigator {
 	const double* d_gflags = nullptr;                // the gathered status words (multi-device handle)
 	double* d_send = nullptr; double* d_recv = nullptr; int* d_plan = nullptr; int sendrecs = 0, recvrecs = 0;
 	MigPlan plan = {nullptr, nullptr, nullptr, nullptr, nullptr, 0};   // device-resident migration plan (k_plan_migration)
+	// the plan over a grid of workgroups (k_plan_count / k_plan_lists) for global vectors of plan_grid_min .. 65 536 slots whose
+	// ranks hold a multiple of 64 particles (environment PHD_PLAN_GRID_MIN; 0: never): its accumulators (two sets, alternating)
+	int plan_grid_min = PLAN_GRID_MIN; int* d_plang = nullptr; int plan_par = 0;
 	int* h_counts = nullptr; int plan_seq = 0;       // pinned + mapped: the plan's counts as the kernel writes them, and the word the host polls
 	bool plan_waiting = false;                       // a plan kernel with host counts is in flight
 	int world = 1, rank = 0;                         // of the last global step
@@ -787,6 +790,7 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	if (const char* e = getenv("PHD_CHAIN_MAX")) nav->chain_max = std::max(0, atoi(e));
 	if (const char* e = getenv("PHD_FOLD_NR")) nav->fold_nr = atoi(e) != 0;
 	if (const char* e = getenv("PHD_NR_GRID_MIN")) nav->nr_grid_min = std::max(0, atoi(e));
+	if (const char* e = getenv("PHD_PLAN_GRID_MIN")) nav->plan_grid_min = std::max(0, atoi(e));
 	size_t plane = (size_t) nav->Pcap * nav->cap;
 	for (int i = 0; i < 3 && ok; i++) {
 		ok = ok && dalloc((void**) &nav->bank[i].mix, plane * MIX_REC * 8);
@@ -1818,6 +1822,7 @@ static void free_sharded(phd_navigator* nav)
 	if (nav->h_counts) hipHostFree(nav->h_counts);
 	nav->h_counts = nullptr;
 	hipFree(nav->d_mslot); nav->d_mslot = nullptr;
+	hipFree(nav->d_plang); nav->d_plang = nullptr;
 	hipFree(nav->d_send); nav->d_send = nullptr;
 	hipFree(nav->d_recv); nav->d_recv = nullptr;
 	hipFree(nav->d_recv_tab); nav->d_recv_tab = nullptr;
@@ -1858,6 +1863,12 @@ static int ensure_sharded(phd_navigator* nav, bool need_send = true)
 	want(hipHostMalloc((void**) &nav->h_counts, (2 * PHD_MAX_DEVICES + 8) * 4, hipHostMallocMapped | hipHostMallocCoherent));
 	if (e == hipSuccess) std::memset(nav->h_counts, 0, (2 * PHD_MAX_DEVICES + 8) * 4);
 	want(hipMalloc((void**) &nav->d_mslot, (size_t) nav->Pcap * 4));
+	{   // k_plan_count / k_plan_lists: [2 sets][cnt 64 x 64 | used Pcap / 32 + 1 | bad 1] | wcg [1024] | lcg [Pcap / 64 + 1]
+		const size_t set = (size_t) PHD_MAX_DEVICES * PHD_MAX_DEVICES + (size_t) (nav->Pcap + 31) / 32 + 2;
+		const size_t words = 2 * set + 1024 + (size_t) nav->Pcap / 64 + 2;
+		want(hipMalloc((void**) &nav->d_plang, words * 4));
+		if (e == hipSuccess) want(hipMemset(nav->d_plang, 0, words * 4));
+	}
 	if (need_send) want(hipMalloc((void**) &nav->d_send, (size_t) nav->sendrecs * rec * 8));   // (a shard of a multi-device handle packs straight into its peers' receive buffers)
 	// The receive buffer is written by OTHER devices (peer stores of a multi-device handle's shards, or of other ranks'
 	// processes through IPC) and read here: fine-grained device memory, coherent between agents without cache maintenance —
@@ -1928,6 +1939,34 @@ void* phd_device_global_weights(phd_navigator* nav, int world_particles)
 	return nav->d_gw;
 }
 
+// The migration plan from the global source vector: over a grid of workgroups (two launches) where the vector is long enough to
+// pay for them, by one workgroup otherwise (k_plan_migration).
+static int launch_plan(phd_navigator* nav, const StepBufs& b, const int* gsrc, const int* info, const int* lflags, const double* gflags,
+                       int Pl, int n, int rank, int* hostcounts, int seq, const double* gw)
+{
+	const long long Pg = (long long) Pl * n;
+	if (nav->plan_grid_min > 0 && Pg >= nav->plan_grid_min && Pg <= PLAN_GRID_MAXSLOTS && (Pl & 63) == 0 && nav->d_plang) {
+		const size_t set = (size_t) PHD_MAX_DEVICES * PHD_MAX_DEVICES + (size_t) (nav->Pcap + 31) / 32 + 2;
+		int* cur = nav->d_plang + (size_t) nav->plan_par * set;
+		int* nxt = nav->d_plang + (size_t) (nav->plan_par ^ 1) * set;
+		nav->plan_par ^= 1;
+		PlanGrid pg;
+		pg.cnt = cur; pg.used = (unsigned int*) (cur + PHD_MAX_DEVICES * PHD_MAX_DEVICES); pg.bad = cur + set - 1;
+		pg.cnt_next = nxt; pg.used_next = (unsigned int*) (nxt + PHD_MAX_DEVICES * PHD_MAX_DEVICES); pg.bad_next = nxt + set - 1;
+		pg.wcg = nav->d_plang + 2 * set;
+		pg.lcg = pg.wcg + 1024;
+		const int G = (int) ((Pg + 255) / 256);
+		hipLaunchKernelGGL(k_plan_count, dim3(G), dim3(256), 0, nav->stream, gsrc, info, lflags, gflags, Pl, n, rank, pg, b, gw);
+		hipLaunchKernelGGL(k_plan_lists, dim3(G), dim3(256), 0, nav->stream, gsrc, info, lflags, gflags, Pl, n, rank, nav->plan, pg, hostcounts, seq);
+	}
+	else {
+		hipLaunchKernelGGL(k_plan_migration, dim3(1), dim3(1024), plan_lds_bytes(Pl, n), nav->stream, gsrc, info, lflags, gflags, Pl, n, rank, nav->plan,
+		                   hostcounts, seq, b, gw);
+	}
+	HC(hipGetLastError());
+	return PHD_OK;
+}
+
 // the global part: the resampling kernel on the gathered vector, this rank's weights back into its bank, the plan.
 // onlymapping: OnlyMapping keeps the weights and never resamples (PHDNavigator.cs:330-336) — the same kernel with the
 // weights taken as they are and resampling off. hostcounts: the plan also writes its counts to pinned host memory.
@@ -1953,7 +1992,6 @@ static int step_global(phd_navigator* nav, int rank, int world_size, double u, u
 	rc = launch_normalise(nav, b, nav->d_gw, Pg, u, onlymapping ? -1 : 0, onlymapping ? 1 : 0, nav->d_plan, nav->d_info);
 	timer_end(nav, T_NR);
 	if (rc) return rc;
-	const size_t lds = plan_lds_bytes(nav->P, world_size);
 	int* hc = nullptr;
 	if (hostcounts) {
 		HC(hipHostGetDevicePointer((void**) &hc, nav->h_counts, 0));
@@ -1961,11 +1999,10 @@ static int step_global(phd_navigator* nav, int rank, int world_size, double u, u
 		nav->plan_waiting = true;
 	}
 	timer_begin(nav, T_PL);
-	hipLaunchKernelGGL(k_plan_migration, dim3(1), dim3(1024), lds, nav->stream, (const int*) nav->d_plan, (const int*) nav->d_info, (const int*) nav->d_flags,
-	                   nav->d_gflags, nav->P, world_size, rank, nav->plan, hc, nav->plan_seq, b, (const double*) nav->d_gw);
+	rc = launch_plan(nav, b, (const int*) nav->d_plan, (const int*) nav->d_info, (const int*) nav->d_flags, nav->d_gflags, nav->P, world_size, rank, hc,
+	                 nav->plan_seq, (const double*) nav->d_gw);
 	timer_end(nav, T_PL);
-	HC(hipGetLastError());
-	return PHD_OK;
+	return rc;
 }
 
 int phd_step_global_async(phd_navigator* nav, int rank, int world_size, double u_resample)
@@ -2222,10 +2259,10 @@ int phd_test_migration_plan(phd_navigator* nav, const int32_t* gsrc, int particl
 	const int info[3] = {0, resampled ? 1 : 0, 0};
 	hipError_t e = hipMemcpy(d_g, gsrc, (size_t) Pl * n * 4, hipMemcpyHostToDevice);
 	if (e == hipSuccess) e = hipMemcpy(d_i, info, 12, hipMemcpyHostToDevice);
-	const size_t lds = plan_lds_bytes(Pl, n);
 	if (e == hipSuccess) {
-		hipLaunchKernelGGL(k_plan_migration, dim3(1), dim3(1024), lds, nav->stream, (const int*) d_g, (const int*) d_i, (const int*) (d_i + 2), (const double*) nullptr,
-		                   Pl, n, rank, nav->plan, (int*) nullptr, 0, make_bufs(nav), (const double*) nullptr);
+		rc = launch_plan(nav, make_bufs(nav), (const int*) d_g, (const int*) d_i, (const int*) (d_i + 2), (const double*) nullptr, Pl, n, rank, (int*) nullptr, 0,
+		                 (const double*) nullptr);
+		if (rc) { hipFree(d_g); return rc; }
 		e = hipStreamSynchronize(nav->stream);
 	}
 	std::vector<int> c(2 * n + 4);

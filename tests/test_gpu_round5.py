@@ -252,3 +252,67 @@ def test_steps_that_end_on_the_grid_kernels(nav_mod, monkeypatch, frozen):
     assert nres >= 1, "no step resampled"
     one.close()
     grid.close()
+
+
+# ---- the migration plan over a grid of workgroups (k_plan_count / k_plan_lists) ---------------------------------------------------
+@pytest.mark.parametrize("Pl,world,power", [(64, 2, 30), (64, 64, 8), (128, 3, 60), (448, 5, 2), (2048, 8, 60), (2048, 8, 2), (1024, 64, 20)])
+def test_grid_migration_plan_equals_the_host_plan(nav_mod, monkeypatch, Pl, world, power):
+    """phd_plan_migration (the host statement of the plan) against the two grid kernels, forced on every size whose ranks hold a
+    multiple of 64 particles (PHD_PLAN_GRID_MIN=1; by default they take global vectors of 4096 .. 65 536 slots): every rank's
+    lists, the senders' record numbers against the receivers' slot codes, the free slots; several plans one after the other
+    (the accumulators alternate between two sets that the kernels clear for each other); a vector that is no resampling result."""
+    from test_gpu_round3 import check_plans
+    monkeypatch.setenv("PHD_PLAN_GRID_MIN", "1")
+    p = prm3d_defaults(max_particles=Pl, max_components=600, max_measurements=8)
+    nav = nav_mod.PHDNavigator(p, particlecount=Pl)
+    rng = np.random.default_rng(Pl * 100 + world)
+    Pg = Pl * world
+    for trial in range(3):
+        w = rng.random(Pg) ** power + 1e-300   # depleted: few sources, long runs, many of them across rank boundaries
+        w /= w.sum()
+        gsrc, _ = nav.ResampleParticles(w, float(rng.uniform(0.01, 0.99)))
+        assert np.all(np.diff(gsrc) >= 0)
+        check_plans(nav, gsrc, Pl, world)
+    check_plans(nav, np.full(Pg, Pg // 2, np.int32), Pl, world)          # every slot from one particle
+    check_plans(nav, np.arange(Pg, dtype=np.int32), Pl, world)           # the identity: nothing moves
+    d = nav.test_migration_plan(np.arange(Pg, dtype=np.int32), Pl, world, 0, resampled=False)
+    assert d["status"] == 0 and d["nsend"] == 0 and d["nrecv"] == 0 and not d["send_counts"].any()
+    bad = np.arange(Pg, dtype=np.int32)[::-1].copy()
+    assert nav.test_migration_plan(bad, Pl, world, world - 1)["status"] == 2
+    w = rng.random(Pg) ** power + 1e-300                                   # ... and a good plan again behind the refused one
+    gsrc, _ = nav.ResampleParticles(w / w.sum(), 0.5)
+    check_plans(nav, gsrc, Pl, world)
+    nav.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_steps_on_the_grid_kernels_equal_the_single_handle(nav_mod, monkeypatch, world):
+    """the device-path sharded sequence with BOTH global kernels on their grid versions (forced: 64 particles per rank are far
+    below the default thresholds) and the landing flags: bit for bit the single handle (which ends its steps on the grid
+    resampling kernels too: the sums' shape depends on the vector's length and the kernel)"""
+    from test_gpu_round4 import _device_path_handles, _device_path_step
+    monkeypatch.setenv("PHD_PLAN_GRID_MIN", "1")
+    monkeypatch.setenv("PHD_NR_GRID_MIN", "1")
+    Pl, Cc, M = 64, 70, 18
+    f = _depleted_frame(world, Pl, Cc, M, 5300 + world)
+    p1 = prm3d_defaults(max_particles=Pl * world, max_components=600, max_measurements=M)
+    one = nav_mod.PHDNavigator(p1, particlecount=Pl * world)
+    one.upload_state(f.planes(), f.counts, f.poses, f.weights)
+    navs = _device_path_handles(nav_mod, f, world, Pl, M)
+    for nv in navs:
+        if nv._lib.phd_migration_recv_is_finegrained(nv._h) == 1:
+            nv._check(nv._lib.phd_migration_set_landing(nv._h, 1))
+    nres = 0
+    for u in (0.31, 0.77, 0.12, 0.6):
+        one.SlamUpdate(None, f.z, u_resample=u)
+        _device_path_step(navs, Pl, u)
+        nres += int(one.resample_sources()[1])
+        assert np.array_equal(one.VehicleWeights, np.concatenate([nv.VehicleWeights for nv in navs]))
+        assert np.array_equal(one.poses(), np.concatenate([nv.poses() for nv in navs]))
+        for g in list(range(0, Pl * world, 5)) + [Pl * world - 1]:
+            a_, b_ = one.MapModel(g), navs[g // Pl].MapModel(g % Pl)
+            assert all(np.array_equal(x, y) for x, y in zip(a_, b_)), "particle %d" % g
+    assert nres >= 1
+    one.close()
+    for nv in navs:
+        nv.close()
