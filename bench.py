@@ -434,6 +434,37 @@ def main():
         nav.sync()
 
     nav.timing_reset(False)
+    if use_dist and not args.host_plan and args.landing == "flags" and (world > 1 or os.environ.get("PHD_BENCH_LANDING_TRIAL")):   # (the variable: rehearsal of this block at one rank)
+        # The landing flags have run between processes sharing ONE GPU (tests/test_gpu_multiproc.py) — never, before this very
+        # run, between GPUs. A few steps with a short bound first: should a peer's flag not become visible on this node, every
+        # rank learns it here (phd_sync reports the timed-out wait), all ranks switch to the one-word all-reduce together, and the
+        # state — undefined after a timed-out wait — is uploaded again. The line says which landing ran.
+        os.environ["PHD_LANDING_TIMEOUT_MS"] = "3000"
+        nav._check(lib.phd_migration_set_landing(h, 1))
+        ok = 1
+        try:
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
+            nav.sync()
+        except Exception as e:
+            ok = 0
+            print("bench.py rank %d: landing flags failed their trial (%s): one-word all-reduce instead" % (rank, e), file=sys.stderr)
+        agreed = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        os.environ["PHD_LANDING_TIMEOUT_MS"] = "10000"
+        if int(agreed.item()) == 1:
+            nav._check(lib.phd_migration_set_landing(h, 1))
+        else:
+            args.landing = "allreduce"
+            sharded_info["landing"] = "allreduce (the flags' trial failed on this node)"
+            sharded_info["collectives_per_step"] = 2
+            nav._check(lib.phd_migration_set_landing(h, 0))
+            nav.set_frozen(False)
+            nav.upload_state(frame.planes(), frame.counts, frame.poses, frame.weights)
+            nav.set_measurements(frame.z)
+            nav.set_frozen(True)
+            nav._check(lib.phd_set_stream(h, C.c_void_p(torch.cuda.current_stream().cuda_stream), 1))
     for _ in range(PREROLL_STEPS + args.warmup):
         step()
     barrier()

@@ -76,7 +76,7 @@ __device__ __forceinline__ void emit_finish_body(const DevParams& prm, const Ste
 	const bool overflow = nc0 > segcap || nc1 > segcap || nc2 > segcap || nc3 > segcap;
 #ifdef PHD_STAMPS   // diagnostic build, PHD_STAMP_KERNEL=7: wave 0's cycles in the Kalman path, its rounds, the runs and the queue length
 	const long long em_t0 = clock64();
-	long long em_pair = 0, em_nb = 0, em_runs = 0;
+	long long em_pair = 0, em_nb = 0, em_runs = 0, em_setup = 0, em_scan = 0;
 #endif
 	exp_tab_init(etab, tid);
 	if (tid == 0) s_npair = 0;
@@ -203,7 +203,16 @@ __device__ __forceinline__ void emit_finish_body(const DevParams& prm, const Ste
 		const int ncw = (wv == 0) ? nc0 : ((wv == 1) ? nc1 : ((wv == 2) ? nc2 : nc3));
 		const int ncmax = max(max(nc0, nc1), max(nc2, nc3));
 		const int2* seg = cands + (size_t) wv * segcap;
+		// (measured and dropped: a quarter of the lists per wave with scalar counters — no LDS atomic, no shuffle of the bases in
+		// the scan —: the scan 22.6 k -> 21.3 k cycles of the body's 80 k, 48 bytes of scratch instead of 12; eight groups of the
+		// queue requested ahead instead of one: the body 86 k -> 112 k cycles)
+#ifdef PHD_STAMPS
+		em_setup = clock64() - em_t0;
+#endif
 		for (int ch0 = 0; ch0 < ncmax; ch0 += EMIT_CAP / 4) {   // (workgroup-uniform; one trip unless a wave queued more than 512 pairs)
+#ifdef PHD_STAMPS
+			const long long em_s0 = clock64();
+#endif
 			if (tid == 0) { s_nlist = 0; s_nlead = 0; }
 			__syncthreads();   // (also: ldenom is written)
 			const int cend = min(ncw, ch0 + EMIT_CAP / 4);
@@ -252,6 +261,7 @@ __device__ __forceinline__ void emit_finish_body(const DevParams& prm, const Ste
 			const int nlead = s_nlead;
 #ifdef PHD_STAMPS
 			const long long em_p0 = clock64();
+			em_scan += em_p0 - em_s0;
 #endif
 			for (int t0 = SPREAD ? 0 : wv * 64; t0 < nlead; t0 += 256) {   // (wave-uniform: a wave without a head left skips the Kalman path)
 				const int t = SPREAD ? t0 + lane * 4 + wv : t0 + lane;
@@ -273,6 +283,7 @@ __device__ __forceinline__ void emit_finish_body(const DevParams& prm, const Ste
 		if (tid == 0 && a.stamps && a.stamp_kernel == 7) {
 			double* o = a.stamps + (size_t) p * 16;
 			o[0] = 0; o[1] = (double) (clock64() - em_t0); o[2] = (double) em_pair; o[3] = (double) em_nb; o[4] = (double) em_runs; o[5] = (double) (nc0 + nc1 + nc2 + nc3);
+			o[6] = (double) em_setup; o[7] = (double) em_scan;
 		}
 #endif
 	}

@@ -636,7 +636,10 @@ __device__ __forceinline__ double nr_weight(const StepBufs& a, const double* gw,
 	return (so == 0) ? w0 : ((so == 1) ? w1 : w2);
 }
 
-__global__ __launch_bounds__(256) void k_nr_sum(const StepBufs a, double* gw, int P, int skip_normalise, int* sel_next, NrGrid nr)
+//   graw != NULL (per-rank host): the all-gather landed as [rank][Pl + 1] (weights | status word): this launch is also the un-gather —
+//   the weights into the contiguous vector gw, the status words behind it — instead of a launch of its own in front of it
+__global__ __launch_bounds__(256) void k_nr_sum(const StepBufs a, double* gw, int P, int skip_normalise, int* sel_next, NrGrid nr,
+                                                const double* __restrict__ graw, int Pl, int world)
 {
 	__shared__ double s4[4];
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = blockIdx.x, k = g * 256 + tid;
@@ -651,6 +654,14 @@ __global__ __launch_bounds__(256) void k_nr_sum(const StepBufs a, double* gw, in
 			w = bank_of(a, SEL_IN).weights[k] * alpha;
 			bank_of(a, SEL_OUT).weights[k] = w;
 		}
+	}
+	else if (graw) {
+		if (k < P) {
+			const int r = k / Pl;
+			w = graw[(size_t) r * (Pl + 1) + (k - r * Pl)];
+			gw[k] = w;
+		}
+		if (k < world) gw[P + k] = graw[(size_t) k * (Pl + 1) + Pl];
 	}
 	else w = nr_weight(a, gw, k, k < P);
 	if (flags_now != 0) {   // a kernel of this step raised a flag: the step is dropped as a whole (see the body above)

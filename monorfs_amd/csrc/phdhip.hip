@@ -484,8 +484,9 @@ int launch_map(phd_navigator* nav, const StepBufs& b, bool with_alpha, int pipe 
 	}
 }
 
+// graw / Pl / world (per-rank host): the weights still lie as the all-gather delivered them, [rank][Pl + 1]; the first launch un-gathers them
 int launch_normalise(phd_navigator* nav, const StepBufs& b, double* gw, int P, double u, int force, int skipnorm, int* src, int* info,
-                     int* sel_next = nullptr, hipStream_t st = nullptr)
+                     int* sel_next = nullptr, hipStream_t st = nullptr, const double* graw = nullptr, int Pl = 0, int world = 0)
 {
 	if (!st) st = nav->stream;
 	if (nav->nr_grid_min > 0 && P >= nav->nr_grid_min && P <= 65536 && b.wait_tickets == 0 && b.done_value == 0) {
@@ -507,13 +508,14 @@ int launch_normalise(phd_navigator* nav, const StepBufs& b, double* gw, int P, d
 		nr.hi = nav->d_nri;
 		nr.state = nav->d_nri + P;
 		const int fr = nav->frozen ? 1 : 0;
-		hipLaunchKernelGGL(k_nr_sum, dim3(nr.G), dim3(256), 0, st, b, gw, P, skipnorm, sel_next, nr);
+		hipLaunchKernelGGL(k_nr_sum, dim3(nr.G), dim3(256), 0, st, b, gw, P, skipnorm, sel_next, nr, graw, Pl, world);
 		hipLaunchKernelGGL(k_nr_stats, dim3(nr.G), dim3(256), 0, st, b, gw, P, skipnorm, sel_next, nr);
 		hipLaunchKernelGGL(k_nr_slots, dim3(nr.G), dim3(256), 0, st, b, gw, P, nav->dp.min_eff, u, force, src, info, sel_next, fr, nav->d_inslot, nr);
 		hipLaunchKernelGGL(k_nr_sources, dim3(nr.G), dim3(256), 0, st, b, gw, P, u, src, info, sel_next, fr, nav->d_inslot, nr);
 		HC(hipGetLastError());
 		return PHD_OK;
 	}
+	if (graw) hipLaunchKernelGGL(k_ungather, dim3((P + world + 255) / 256), dim3(256), 0, st, graw, gw, Pl, world);
 	// one workgroup; 256 / 512 threads for shorter weight vectors (fewer waves to meet at every barrier), 1024 beyond 4096
 	static const int nr_env = getenv("PHD_NR_THREADS") ? atoi(getenv("PHD_NR_THREADS")) : 0;
 	const int nthreads = (nr_env == 256 || nr_env == 512 || nr_env == 1024) ? nr_env : (P <= 512 ? 256 : (P <= 4096 ? 512 : 1024));
@@ -1981,15 +1983,14 @@ static int step_global(phd_navigator* nav, int rank, int world_size, double u, u
 	if (rc) return rc;
 	nav->plan_on_device = !hostcounts;
 	StepBufs b = make_bufs(nav);
-	if (from_graw) {
-		// the all-gather landed as [rank][P + 1] (weights | status word): the weights into the contiguous vector the global
-		// kernel takes, the status words behind it — a flag raised on ANY rank then drops the step on every rank alike
-		hipLaunchKernelGGL(k_ungather, dim3((Pg + world_size + 255) / 256), dim3(256), 0, nav->stream, (const double*) nav->d_graw, nav->d_gw, nav->P, world_size);
-		nav->d_gflags = nav->d_gw + Pg;
-	}
+	// (from_graw: the all-gather landed as [rank][P + 1] (weights | status word): the weights go into the contiguous vector the global
+	// kernel takes, the status words behind it — a flag raised on ANY rank then drops the step on every rank alike; done by the
+	// resampling's own first launch, or by k_ungather in front of the one-workgroup kernel)
+	if (from_graw) nav->d_gflags = nav->d_gw + Pg;
 	else if (!nav->gw_shared) nav->d_gflags = nullptr;   // (the host-plan path gathers the weights only: every rank answers for its own flags)
 	timer_begin(nav, T_NR);
-	rc = launch_normalise(nav, b, nav->d_gw, Pg, u, onlymapping ? -1 : 0, onlymapping ? 1 : 0, nav->d_plan, nav->d_info);
+	rc = launch_normalise(nav, b, nav->d_gw, Pg, u, onlymapping ? -1 : 0, onlymapping ? 1 : 0, nav->d_plan, nav->d_info, nullptr, nullptr,
+	                      from_graw ? (const double*) nav->d_graw : nullptr, nav->P, world_size);
 	timer_end(nav, T_NR);
 	if (rc) return rc;
 	int* hc = nullptr;
@@ -2166,6 +2167,7 @@ int phd_migration_push_async(phd_navigator* nav)
 	MULTI_UNSUPPORTED(nav, "phd_migration_push_async");
 	if (!nav->sharded_ready || !nav->peers_set) return nav->fail(PHD_ERR_BAD_ARGUMENT, "phd_migration_push_async: no peers (phd_migration_ipc_open / phd_migration_set_peers, then phd_step_global_device_async)");
 	enter(nav);
+	if (nav->world <= 1) return PHD_OK;   // (one rank: nothing ever leaves it)
 	StepBufs b = make_bufs(nav);
 	timer_begin(nav, T_PK);
 	hipLaunchKernelGGL(k_pack_particles, dim3(std::min(nav->plan.sendcap, 256)), dim3(256), 0, nav->stream, b, nav->plan, nav->world, (double*) nullptr,

@@ -42,6 +42,7 @@ m = out.mean(0)   # stamp i = cycles since stamp 0 (stamps need not be numbered 
 if os.environ.get("PHD_STAMP_KERNEL") == "7":   # the emit body (wave 0 of every workgroup): its own layout
     print(prof, "emit body: cycles %d, of them inside the Kalman path %d in %.2f rounds of wave 0; runs (components with kept pairs) of the particle: %.0f, its queue entries: %.0f"
           % (m[1], m[2], m[3], m[4], m[5]))
+    print("   before the queue scan (tables, staging of z and the denominators, pose): %d; the scan with its barriers: %d" % (m[6], m[7]))
     nav.close()
     sys.exit(0)
 idx = [i for i in np.argsort(m[:12], kind="stable") if i == 0 or m[i] > 0]
