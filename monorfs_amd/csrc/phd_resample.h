@@ -584,7 +584,7 @@ __global__ __launch_bounds__(64) void k_gate(const unsigned int* done, unsigned 
 // The shape of every sum depends on the length of the vector only, as in the one-workgroup kernel: all ranks of a sharded run
 // and a single handle holding all particles get the same bits. (The two kernels' sums have different shapes — a thread's chunk
 // there, one weight per thread here —: which one runs is decided by the vector's length alone, too.)
-#define NR_GRID_MIN 4096
+#define NR_GRID_MIN 8192
 #define NR_STAT 8   // doubles per workgroup in the statistics block: sum, sum of squares, max, index of the max, bad, dd sum hi / lo, spare
 #define NR_SLOT 4   // ... in the slots block: ok, best weight, best slot, spare
 

@@ -83,10 +83,14 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 	// the particle keeps its pose and (until the reweight kernel runs) its weight in the output bank
 	if (tid < 7) bout.poses[(size_t) p * 7 + tid] = bin.poses[(size_t) p * 7 + tid];
 	if (tid == 7) bout.weights[p] = bin.weights[p];
-	double rq[9];
-	conj_matrix(pose, rq);
-#pragma unroll
-	for (int t = 0; t < 9; t++) rq[t] = uniform_d(rq[t]);
+	// (the rotation matrix of the Jacobian is rebuilt from the quaternion — scalar registers — where a staging phase needs it: ~20
+	// scalar-operand instructions per tile against nine doubles that were kept across the pair loops, i.e. spilled: the kernel
+	// is at its 106 scalar and 128 vector registers)
+	auto rotation = [&](double* rq) {
+		PoseD pq = pose;
+		asm volatile("" : "+s"(pq.qw), "+s"(pq.qx), "+s"(pq.qy), "+s"(pq.qz));   // (keeps the compiler from hoisting the products out of the tile loop)
+		conj_matrix(pq, rq);
+	};
 	exp_tab_init(etab, tid);
 	if (tid == 0) { s_nb = 0; s_nmis = 0; s_nu = 0; }
 	for (int k = tid; k < MP; k += 256) {
@@ -199,6 +203,8 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 					double P[6], m[3], w;
 					load_comp(vin.rec + (sb + c) * MIX_REC, w, m, P);
 					CompMeas q;
+					double rq[9];
+					rotation(rq);
 					comp_measure(prm, pose, rq, m, P, q);
 					tt[0] = q.zh[0]; tt[1] = q.zh[1]; tt[2] = q.zh[2];
 					tt[3] = -0.5 * q.Sinv[0];
@@ -360,6 +366,8 @@ __device__ __forceinline__ void sweep_body(const DevParams& prm, const StepBufs&
 				const int k = born[bi];
 				m[0] = zmap[k * 3]; m[1] = zmap[k * 3 + 1]; m[2] = zmap[k * 3 + 2];
 				CompMeas q;
+				double rq[9];
+				rotation(rq);
 				comp_measure(prm, pose, rq, m, prm.birthP, q);
 				double* tt = tile + bi * 13;
 				tt[0] = q.zh[0]; tt[1] = q.zh[1]; tt[2] = q.zh[2];
