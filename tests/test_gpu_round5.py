@@ -316,3 +316,47 @@ def test_sharded_steps_on_the_grid_kernels_equal_the_single_handle(nav_mod, monk
     one.close()
     for nv in navs:
         nv.close()
+
+
+# ---- the emit body's runs: long ones (cut at four measurements), a queue longer than one chunk ---------------------------------------
+@pytest.mark.parametrize("C,M,targets,chain_max", [(60, 64, 3, None), (60, 64, 3, 0), (600, 64, 4, 0), (300, 128, 12, 0)])
+def test_emit_runs_longer_than_four_and_queues_longer_than_a_chunk(nav_mod, monkeypatch, C, M, targets, chain_max):
+    """Every measurement is a noisy sighting of one of a FEW components, so a component is queued with a dozen or more measurements
+    (a lane's run is cut at four: the component's part is computed again for the next four) and, with 600 components x 64
+    measurements on a small clutter density, a wave queues more than the 512 pairs of one chunk. Corrected (as a set) and pruned
+    mixtures, set log-likelihood and alpha against the oracle, through the chain and through the separate kernels."""
+    from monorfs_amd.synth import measure_perfect_identity
+    from test_gpu_parity import assert_mix_close, match_unordered
+    if chain_max is not None:
+        monkeypatch.setenv("PHD_CHAIN_MAX", str(chain_max))
+        monkeypatch.setenv("PHD_SPLIT", "2")
+    P = 3
+    f = Frame(P, C, M, 540 + C + M, weight_profile="steady")
+    rng = np.random.default_rng(541)
+    pick = rng.choice(C, targets, replace=False)
+    base = np.array(f.mean[0])                           # (particle 0's means: the others differ by the frame's small jitter)
+    z = measure_perfect_identity(base[pick[rng.integers(targets, size=M)]]) + rng.normal(size=(M, 3)) * np.sqrt([2.0, 2.0, 1e-3])
+    f.z = z
+    w = np.array(f.w)
+    w[:, pick] = rng.uniform(0.6, 1.2, targets)          # the sighted components are heavy: their updates reach MinWeight
+    f.w = w
+    nav, p = _handle(nav_mod, f, maxq=max(600, C))
+    nav.run_stages(f.z, with_alpha=True)
+    alpha, setll = nav.WeightAlpha(), nav.SetLogLikelihood()
+    longest = 0
+    for i in range(P):
+        pred = orc.predict(p, f.poses[i], f.z, f.map(i))
+        cor = orc.correct(p, f.poses[i], f.z, pred)
+        keep = ~(cor[0] < p.min_weight)
+        npred = len(pred[0])
+        det = np.flatnonzero(keep[npred:])
+        if len(det):
+            longest = max(longest, int(np.bincount(det % npred).max()))   # (the corrected list is measurement-major: index = np + k np + c)
+        match_unordered(nav.CorrectConditional(i), tuple(x[keep] for x in cor), 1e-9)
+        pr = orc.prune(p, cor)
+        assert_mix_close(nav.PruneModel(i), pr, 1e-7, "prune[%d]" % i)
+        a, sll = orc.weight_alpha(p, f.poses[i], f.z, pred, pr)
+        assert np.isclose(setll[i], sll, rtol=1e-9, atol=1e-9)
+        assert np.isclose(alpha[i], a, rtol=1e-6, atol=0)
+    assert longest > 4, "no component met more than four measurements (%d): the frame does not exercise the cut" % longest
+    nav.close()
