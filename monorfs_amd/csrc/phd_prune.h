@@ -906,7 +906,7 @@ __device__ __forceinline__ void prune_merge_body(const DevParams& prm, const Ste
 #endif
 		}
 
-#ifdef PHD_STAMPS
+#if defined(PHD_STAMPS) && !defined(PHD_STAMP_COUNTERS)   // (the counters' build uses the same slots for its counts)
 		if (tid == 0 && a.stamps && a.stamp_kernel == 2) { a.stamps[(size_t) p * 16 + 12] = (double) acc_setup; a.stamps[(size_t) p * 16 + 13] = (double) acc_trips; a.stamps[(size_t) p * 16 + 14] = (double) acc_drain; }
 #endif
 		PHD_STAMP(9);
@@ -1169,7 +1169,7 @@ PHD_REF_ARITH
 	PHD_STAMP(5);
 	if (tid == 0) vout.count[p] = nsurv_before;
 	PHD_STAMP_FLUSH(2, 12);
-#ifdef PHD_STAMPS   // (the fused launch: cycles of the emit body in front of this one, slot 15)
+#if defined(PHD_STAMPS) && !defined(PHD_STAMP_COUNTERS)   // (the fused launch: cycles of the emit body in front of this one, slot 15)
 	if (tid == 0 && a.stamps && a.stamp_kernel == 2 && tk0) a.stamps[(size_t) p * 16 + 15] = (double) (stamp_[0] - tk0);
 #endif
 }
