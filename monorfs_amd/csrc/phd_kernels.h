@@ -137,7 +137,9 @@ struct StepBufs {
 	unsigned int* ticket;       // [0] workgroups of the step's last per-particle launch(es) that are through (set back to 0 by whoever waited for them)
 	                            // [1] the number of the last step whose k_normalise_resample is through
 	int           tickets;      // 1: every workgroup of k_alpha_density publishes its weight and takes a ticket (device-side ordering of the two sub-range streams)
-	int           wait_tickets; // k_normalise_resample: wait for this many tickets first (0: the stream has ordered it)
+	int           wait_tickets; // k_normalise_resample: 1 = wait until the ticket counter has reached ticket_target (0: the stream has ordered it)
+	unsigned int  ticket_target;// ... P times the number of device-ordered steps so far: the counter only ever grows, so tickets that arrive behind a
+	                            // timed-out wait still count for their own step and the next one's wait is not satisfied early
 	unsigned int  done_value;   // k_normalise_resample: the step number it publishes in ticket[1] when through (0: none)
 	double        nr_u;         // the arguments k_normalise_resample would have got
 	int           nr_force, nr_skip, nr_frozen;
@@ -248,8 +250,8 @@ __global__ __launch_bounds__(256, 1) void k_particle_chain(const DevParams prm, 
 		__syncthreads();
 		if (threadIdx.x == 0) {
 			__threadfence();
-			const int last = (atomicAdd(a.ticket, 1u) == gridDim.x - 1) ? 1 : 0;
-			if (last) *a.ticket = 0;   // for the next launch (stream order)
+			const int last = (atomicAdd(a.ticket + 2, 1u) == gridDim.x - 1) ? 1 : 0;   // (a word of its own: the device order's counter beside it never goes back)
+			if (last) a.ticket[2] = 0;   // for the next launch (stream order)
 			__threadfence();
 			s_last = last;
 		}

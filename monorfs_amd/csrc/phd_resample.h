@@ -526,15 +526,16 @@ __global__ __launch_bounds__(1024) void k_normalise_resample(const StepBufs a, d
 		// Two sub-range streams, steps posted back to back (phd_step_async): this launch sits directly behind the k_alpha_density of
 		// ITS stream; the other stream's is ordered by count — every workgroup of both took a ticket behind a device-scope release of
 		// its weight. Everything waited for was submitted before this launch, on whatever queue; the wait is bounded (0.2 s of the
-		// 100 MHz counter: the step is then dropped with PHD_FLAG_ORDER_TIMEOUT).
+		// 100 MHz counter: the step is then dropped with PHD_FLAG_ORDER_TIMEOUT, and so is every step behind it until phd_sync).
 		if (threadIdx.x == 0) {
 			const long long t0 = wall_clock64();
 			// (relaxed loads: an acquire per poll would invalidate the L2 under the kernels still running)
-			while (__hip_atomic_load(a.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned) a.wait_tickets) {
+			// (a step-stamped target on a counter that is never reset: late tickets of a step whose wait timed out cannot count towards
+			// the next step; the flag a timed-out wait raises stays up — every later step is dropped — until phd_sync has reported it)
+			while ((int) (__hip_atomic_load(a.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ticket_target) < 0) {
 				if (wall_clock64() - t0 > 20000000LL) { atomicOr(a.flags, PHD_FLAG_ORDER_TIMEOUT); break; }
 				__builtin_amdgcn_s_sleep(32);
 			}
-			__hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the next step's tickets come behind this launch)
 		}
 		__syncthreads();
 		__threadfence();   // acquire in every wave: what the ticket holders published is what the loads below see

@@ -76,6 +76,7 @@ struct phd_navigator {
 	                                   // streams' k_alpha_density workgroups, the other stream's next k_sweep waits behind k_gate. Measured 0.2 % faster
 	                                   // than the events; two kernels that poll are not worth that by default
 	unsigned    step_seq = 0;          // number of the last step ended that way
+	unsigned    ticket_total = 0;      // tickets all such steps so far have handed out (P per step): what k_normalise_resample waits for — the counter is never reset
 	bool sel_host_valid = false;       // h_sel mirrors the device-side bank roles without a round trip
 	int Pcap = 0, cap = 0, Mcap = 0, ecap = 0, Jcap = 0, cutcap = 0;
 	int P = 0, M = 0;
@@ -262,7 +263,7 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.born_count = nav->d_born_count; b.born_k = nav->d_born_k; b.born_mean = nav->d_born_mean;
 	b.alpha = nav->d_alpha; b.setll = nav->d_setll; b.flags = nav->d_flags; b.murty = nav->d_murty; b.jscratch = nav->d_jscratch;
 	b.bigws = nav->d_bigws; b.bigws_bytes = nav->bigws_bytes; b.bigws_used = nav->d_bigws_used;
-	b.fold_nr = 0; b.ticket = (unsigned int*) (nav->d_bigws_used + 1); b.tickets = 0; b.wait_tickets = 0; b.done_value = 0;
+	b.fold_nr = 0; b.ticket = (unsigned int*) (nav->d_bigws_used + 1); b.tickets = 0; b.wait_tickets = 0; b.ticket_target = 0; b.done_value = 0;
 	b.nr_u = 0; b.nr_force = 0; b.nr_skip = 0; b.nr_frozen = 0; b.nr_src = nullptr; b.nr_info = nullptr; b.nr_sel_next = nullptr; b.nr_inslot = nullptr;
 	b.cand_count = nav->d_cand_count; b.denom = nav->d_denom;
 	b.cand = nav->d_cand; b.candcap = nav->candcap;
@@ -821,8 +822,8 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	ok = ok && dalloc((void**) &nav->d_src, (size_t) nav->Pcap * 4);
 	ok = ok && dalloc((void**) &nav->d_murty, (size_t) nav->Pcap * sizeof(MurtyNodes));
 	nav->bigws_bytes = 128ull << 20;
-	ok = ok && dalloc((void**) &nav->d_bigws, nav->bigws_bytes) && dalloc((void**) &nav->d_bigws_used, 16);   // [0] the slab's bump counter, [1] the chain's ticket
-	if (ok) hipMemset(nav->d_bigws_used, 0, 16);
+	ok = ok && dalloc((void**) &nav->d_bigws, nav->bigws_bytes) && dalloc((void**) &nav->d_bigws_used, 32);   // [0] the slab's bump counter; 32-bit words behind it: the device order's ticket counter (never reset) and step number, the chain's own ticket
+	if (ok) hipMemset(nav->d_bigws_used, 0, 32);
 	nav->cmcap = nav->cap + nav->Mcap;
 	ok = ok && dalloc((void**) &nav->d_cand_count, (size_t) nav->Pcap * 4 * 4) && dalloc((void**) &nav->d_denom, (size_t) nav->Pcap * nav->Mcap * 8);
 	nav->candcap = 16 * nav->cmcap;   // a quarter of all pairs at 64 measurements (four wave segments); beyond it the full second sweep runs
@@ -1423,7 +1424,9 @@ int phd_step_async(phd_navigator* nav, uint8_t onlymapping, double u_resample)
 		if (dev) {
 			nav->step_seq++;
 			if (nav->step_seq == 0) nav->step_seq = 1;
-			b.wait_tickets = nav->P;
+			nav->ticket_total += (unsigned) nav->P;
+			b.wait_tickets = 1;
+			b.ticket_target = nav->ticket_total;
 			b.done_value = nav->step_seq;
 		}
 		else {

@@ -389,8 +389,8 @@ def test_chain_ends_the_step_itself_as_the_separate_launch_does(nav_mod, monkeyp
 @pytest.mark.parametrize("mode", ["device", "events"])
 def test_steps_posted_back_to_back_end_on_the_stream_that_finishes_last(nav_mod, monkeypatch, mode):
     """Two sub-range streams (1024 particles and more), phd_step_async after phd_step_async: no fork between the steps, the end of
-    the step behind the k_alpha_density of the stream that finishes last — ordered on the device (tickets + k_gate, the default) or
-    by events (PHD_DEVICE_ORDER=0). Twelve un-frozen steps, resampled and not, a mapping-only step and an upload in between: weights,
+    the step behind the k_alpha_density of the stream that finishes last — ordered by events (the default, PHD_DEVICE_ORDER=0) or on
+    the device (tickets + k_gate, PHD_DEVICE_ORDER=1: an option). Twelve un-frozen steps, resampled and not, a mapping-only step and an upload in between: weights,
     sources, BestParticle and maps bit for bit those of a handle that forks and joins around every step (PHD_PIPELINE=0)."""
     from monorfs_amd.synth import Frame
     from test_gpu_round2 import make_nav
