@@ -180,6 +180,82 @@ __device__ __forceinline__ size_t in_base(const StepBufs& a, int p) { return (si
 
 #define TILE 256   // components staged per LDS tile
 
+#define PLAN_GRID_MIN 8192               // (= NR_GRID_MIN: the plan's first half runs inside the grid resampling's last launch)
+#define PLAN_GRID_MAXSLOTS 65536          // per-wave count arrays: 1024 global waves
+
+struct PlanGrid {
+	int* cnt;      // [n][n] records rank t takes from rank s            (this launch pair's set; NULL: no plan is counted)
+	int* wcg;      // [Pg / 64] heads whose source is mine, per global wave
+	int* lcg;      // [Pl / 64] heads among my own slots, per local wave
+	unsigned int* used;   // [(Pl + 31) / 32] bit c: OUT slot c stays the source of a local particle
+	int* bad;      // [1]
+	int* cnt_next; unsigned int* used_next; int* bad_next;   // the other set: cleared by k_plan_lists
+};
+
+// the flags of slot g from its source s and the source of the slot before it (see k_plan_migration): owner rank, source rank, head
+// of a run fed from another rank, malformed
+__device__ __forceinline__ void plan_flags(int s, int prev, int g, int Pg, int Pl, float rPl, bool bigidx, int& t, int& sr, bool& head, bool& bad)
+{
+	auto rank_of = [&](int x) { return bigidx ? x / Pl : small_div(x, Pl, rPl); };
+	bad = g < Pg && (s < 0 || s >= Pg || (g > 0 && prev > s));
+	t = rank_of(min(g, Pg - 1));
+	sr = rank_of(min(max(s, 0), Pg - 1));
+	head = g < Pg && sr != t && (g == t * Pl || prev != s);
+}
+
+// ... with the sources read from the vector: this lane's, and the lane before's by a shuffle (lane 0: the word before)
+__device__ __forceinline__ void plan_look(const int* __restrict__ gsrc, int g, int Pg, int Pl, float rPl, bool bigidx, int lane,
+                                          int& s, int& t, int& sr, bool& head, bool& bad)
+{
+	s = (g < Pg) ? gsrc[g] : 0;
+	int prev = __shfl_up(s, 1, 64);
+	if (lane == 0) prev = (g > 0 && g < Pg) ? gsrc[g - 1] : 0;
+	plan_flags(s, prev, g, Pg, Pl, rPl, bigidx, t, sr, head, bad);
+}
+
+// a flag raised on this rank, or — the gathered status words, one per lane — on any other: one trip to memory
+__device__ __forceinline__ bool plan_dropped(const int* lflags, const double* gflags, int n, int lane)
+{
+	const int lf = *lflags;
+	const double gf = (gflags && lane < n) ? gflags[lane] : 0.0;
+	return lf != 0 || ballot64(gf != 0.0) != 0ull;
+}
+
+// What slot g adds to the plan's accumulators (all 64 lanes of a wave call it together; gwave: the wave's number among all slots'
+// waves): the count matrix, the waves' head counts, the bitmap of OUT slots that stay a local source. Pl is a multiple of 64 — the
+// host takes the one-workgroup kernel otherwise —, so a wave's slots belong to one rank.
+__device__ __forceinline__ void plan_count_slot(const PlanGrid& pg, int g, int Pg, int Pl, int n, int rank, int lane, int gwave,
+                                                int s, int t, int sr, bool head, bool bad)
+{
+	const int first = rank * Pl;
+	if (bad) atomicOr(pg.bad, 1);
+	if (head && !bad) atomicAdd(&pg.cnt[t * n + sr], 1);
+	const unsigned long long mine = ballot64(head && !bad && sr == rank);
+	if (lane == 0 && g < Pg) pg.wcg[gwave] = __popcll(mine);
+	const bool myslot = g < Pg && t == rank;
+	if (myslot) {
+		// the heads among my own slots, per wave of them: the records' numbers (k_plan_lists)
+		const unsigned long long lb = ballot64(head && !bad);
+		if (lane == 0) pg.lcg[(g - first) >> 6] = __popcll(lb);
+	}
+	// The OUT slots that stay a local particle's source, as a bitmap. The sources never decrease, so a wave's 64 slots name a run
+	// of neighbouring bits — mostly the same few: the lanes OR theirs together per word first (an atomic per slot was 2048
+	// atomics on 64 words, serialised at the L2: most of the launch) and the first lane of each word's run adds it.
+	const bool loc = myslot && sr == rank && !bad;
+	const int word = loc ? (s - first) >> 5 : -1 - lane;   // (distinct negative numbers: no run)
+	unsigned int bits = loc ? 1u << ((s - first) & 31) : 0u;
+	// segmented OR over runs of equal `word` (the lanes of a run are neighbours): log steps, a lane takes what the lane `o`
+	// further on holds when that lane belongs to the same word
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const int wo = __shfl_down(word, o, 64);
+		const unsigned int bo = __shfl_down(bits, o, 64);
+		if (lane + o < 64 && wo == word) bits |= bo;
+	}
+	const int wp = __shfl_up(word, 1, 64);
+	if (loc && (lane == 0 || wp != word)) atomicOr(&pg.used[word], bits);
+}
+
 #include "phd_correct.h"
 
 // (PHD_ONLY_EP: a translation unit of k_emit_finish / k_prune_merge / k_emit_prune alone — scripts/kres.sh compiles it in seconds
@@ -719,86 +795,25 @@ __global__ __launch_bounds__(1024) void k_plan_migration(const int* __restrict__
 //                  writes the counts (to the host too, when it waits for them)
 // Two sets of the accumulators alternate between launches: k_plan_lists clears the set the NEXT pair of launches adds to, so
 // that no launch — and no memset on the stream — stands between the resampling kernel and k_plan_count.
-#define PLAN_GRID_MIN 4096
-#define PLAN_GRID_MAXSLOTS 65536          // per-wave count arrays: 1024 global waves
-
-struct PlanGrid {
-	int* cnt;      // [n][n] records rank t takes from rank s            (this launch pair's set)
-	int* wcg;      // [Pg / 64] heads whose source is mine, per global wave
-	int* lcg;      // [Pl / 64] heads among my own slots, per local wave
-	unsigned int* used;   // [(Pl + 31) / 32] bit c: OUT slot c stays the source of a local particle
-	int* bad;      // [1]
-	int* cnt_next; unsigned int* used_next; int* bad_next;   // the other set: cleared by k_plan_lists
-};
-
-// the flags of slot g (see k_plan_migration): source, owner rank, source rank, head of a run fed from another rank, malformed
-__device__ __forceinline__ void plan_look(const int* __restrict__ gsrc, int g, int Pg, int Pl, float rPl, bool bigidx, int lane,
-                                          int& s, int& t, int& sr, bool& head, bool& bad)
-{
-	s = (g < Pg) ? gsrc[g] : 0;
-	int prev = __shfl_up(s, 1, 64);
-	if (lane == 0) prev = (g > 0 && g < Pg) ? gsrc[g - 1] : 0;
-	auto rank_of = [&](int x) { return bigidx ? x / Pl : small_div(x, Pl, rPl); };
-	bad = g < Pg && (s < 0 || s >= Pg || (g > 0 && prev > s));
-	t = rank_of(min(g, Pg - 1));
-	sr = rank_of(min(max(s, 0), Pg - 1));
-	head = g < Pg && sr != t && (g == t * Pl || prev != s);
-}
-
-// a flag raised on this rank, or — the gathered status words, one per lane — on any other: one trip to memory
-__device__ __forceinline__ bool plan_dropped(const int* lflags, const double* gflags, int n, int lane)
-{
-	const int lf = *lflags;
-	const double gf = (gflags && lane < n) ? gflags[lane] : 0.0;
-	return lf != 0 || ballot64(gf != 0.0) != 0ull;
-}
-
 __global__ __launch_bounds__(256) void k_plan_count(const int* __restrict__ gsrc, const int* __restrict__ info, const int* lflags,
-                                                    const double* gflags, int Pl, int n, int rank, PlanGrid pg, const StepBufs a, const double* gw)
+                                                    const double* gflags, int Pl, int n, int rank, PlanGrid pg)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-	const int Pg = Pl * n, first = rank * Pl, g = blockIdx.x * 256 + tid;
+	const int Pg = Pl * n, g = blockIdx.x * 256 + tid;
 	int s, t, sr;
 	bool head, bad;
 	const bool bigidx = Pg >= (1 << 24);
 	plan_look(gsrc, g, Pg, Pl, 1.0f / (float) Pl, bigidx, lane, s, t, sr, head, bad);   // (its loads are in flight while the status words arrive)
-	if (gw && g >= first && g < first + Pl) bank_of(a, SEL_OUT).weights[g - first] = gw[g];   // this rank's slice of the (normalised, or 1 / P) weights
 	const int resampled = info[1];
 	const bool drop = plan_dropped(lflags, gflags, n, lane);
 	if (drop || !resampled) return;   // dropped, or not resampled: nothing moves (k_plan_lists writes the status)
-	if (bad) atomicOr(pg.bad, 1);
-	if (head && !bad) atomicAdd(&pg.cnt[t * n + sr], 1);
-	const unsigned long long mine = ballot64(head && !bad && sr == rank);
-	if (lane == 0 && g < Pg) pg.wcg[blockIdx.x * 4 + wv] = __popcll(mine);
-	// (Pl is a multiple of 64 here — the host takes the one-workgroup kernel otherwise —: a wave's slots belong to one rank)
-	const bool myslot = g < Pg && t == rank;
-	if (myslot) {
-		// the heads among my own slots, per wave of them: the records' numbers (k_plan_lists)
-		const unsigned long long lb = ballot64(head && !bad);
-		if (lane == 0) pg.lcg[(g - first) >> 6] = __popcll(lb);
-	}
-	// The OUT slots that stay a local particle's source, as a bitmap. The sources never decrease, so a wave's 64 slots name a run
-	// of neighbouring bits — mostly the same few: the lanes OR theirs together per word first (an atomic per slot was 2048
-	// atomics on 64 words, serialised at the L2: most of this launch) and the first lane of each word's run adds it.
-	{
-		const bool loc = myslot && sr == rank && !bad;
-		const int word = loc ? (s - first) >> 5 : -1 - lane;   // (distinct negative numbers: no run)
-		unsigned int bits = loc ? 1u << ((s - first) & 31) : 0u;
-		// segmented OR over runs of equal `word` (the lanes of a run are neighbours): log steps, a lane takes what the lane `o`
-		// further on holds when that lane belongs to the same word
-#pragma unroll
-		for (int o = 1; o < 64; o <<= 1) {
-			const int wo = __shfl_down(word, o, 64);
-			const unsigned int bo = __shfl_down(bits, o, 64);
-			if (lane + o < 64 && wo == word) bits |= bo;
-		}
-		const int wp = __shfl_up(word, 1, 64);
-		if (loc && (lane == 0 || wp != word)) atomicOr(&pg.used[word], bits);
-	}
+	plan_count_slot(pg, g, Pg, Pl, n, rank, lane, blockIdx.x * 4 + wv, s, t, sr, head, bad);
 }
 
+//   gw (may be NULL): this rank's slice of the gathered (normalised, or 1 / P) weights goes back into its OUT bank here
 __global__ __launch_bounds__(256) void k_plan_lists(const int* __restrict__ gsrc, const int* __restrict__ info, const int* lflags,
-                                                    const double* gflags, int Pl, int n, int rank, MigPlan pl, PlanGrid pg, int* hostcounts, int seq)
+                                                    const double* gflags, int Pl, int n, int rank, MigPlan pl, PlanGrid pg, int* hostcounts, int seq,
+                                                    const StepBufs a, const double* gw)
 {
 	__shared__ int s_cnt[64 * 64], s_base[64], s_roff[64], s_w[20], s_ns, s_nr;   // (at most 64 ranks: PHD_MAX_DEVICES)
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -807,6 +822,32 @@ __global__ __launch_bounds__(256) void k_plan_lists(const int* __restrict__ gsrc
 	bool head, bad;
 	const bool bigidx = Pg >= (1 << 24);
 	plan_look(gsrc, g, Pg, Pl, 1.0f / (float) Pl, bigidx, lane, s, t, sr, head, bad);
+	// Everything this launch reads of the counting's results is requested up front, together — the count matrix into LDS, the
+	// waves' counts into registers — and only then looked at: every dependent trip to memory is a microsecond here.
+	const int resampled = info[1], badword = pg.bad[0];
+	const bool drop = plan_dropped(lflags, gflags, n, lane);
+	if (gw && g >= first && g < first + Pl) bank_of(a, SEL_OUT).weights[g - first] = gw[g];   // this rank's slice of the weights
+	if (!resampled || drop) {
+		// Nothing was counted (the counting returns at the same test) and nothing moves: the step's most common end on a frame
+		// that does not deplete the particle set. One workgroup writes the status; both sets of accumulators are still clear.
+		if (blockIdx.x == 0) {
+			for (int q = tid; q < 2 * n; q += 256) pl.counts[q] = 0;
+			if (tid == 0) { pl.counts[2 * n] = 0; pl.counts[2 * n + 1] = 0; pl.counts[2 * n + 2] = drop ? MIG_DROPPED : MIG_OK; pl.counts[2 * n + 3] = resampled; }
+			if (hostcounts) {
+				for (int q = tid; q < 2 * n + 2; q += 256) __hip_atomic_store(hostcounts + q, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				if (tid == 0) {
+					__hip_atomic_store(hostcounts + 2 * n + 2, drop ? MIG_DROPPED : MIG_OK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					__hip_atomic_store(hostcounts + 2 * n + 3, resampled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					__hip_atomic_store(hostcounts + 2 * n + 4, info[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					__hip_atomic_store(hostcounts + 2 * n + 5, *lflags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				}
+				__threadfence_system();
+				__syncthreads();
+				if (tid == 0) __hip_atomic_store(hostcounts + 2 * n + 6, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
+		}
+		return;
+	}
 	// the accumulators of the next pair of launches
 	{
 		const int gt = blockIdx.x * 256 + tid, gn = gridDim.x * 256;
@@ -814,10 +855,6 @@ __global__ __launch_bounds__(256) void k_plan_lists(const int* __restrict__ gsrc
 		for (int q = gt; q < (Pl + 31) / 32; q += gn) pg.used_next[q] = 0u;
 		if (gt == 0) pg.bad_next[0] = 0;
 	}
-	// Everything this launch reads of k_plan_count's results is requested up front, together — the count matrix into LDS, the
-	// waves' counts into registers — and only then looked at: every dependent trip to memory is a microsecond here.
-	const int resampled = info[1], badword = pg.bad[0];
-	const bool drop = plan_dropped(lflags, gflags, n, lane);
 	int cv[16];
 #pragma unroll
 	for (int q = 0; q < 16; q++) cv[q] = (tid + 256 * q < n * n) ? pg.cnt[tid + 256 * q] : 0;

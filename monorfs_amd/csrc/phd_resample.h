@@ -850,11 +850,16 @@ __global__ __launch_bounds__(256) void k_nr_slots(const StepBufs a, double* gw, 
 	}
 }
 
+//   pg.cnt != NULL (sharded step: the vector holds world x Pl slots): this launch also COUNTS for the migration plan (k_plan_count's
+//   work, phd_kernels.h) — every thread has its slot's source in a register here, and a launch of its own for the counting cost as
+//   much as the counting; k_plan_lists follows. gflags: the gathered status words (a flag on any rank: nothing is counted).
 __global__ __launch_bounds__(256) void k_nr_sources(const StepBufs a, double* gw, int P, double u, int* src, int* info, int* sel_next,
-                                                    int frozen, int* inslot, NrGrid nr)
+                                                    int frozen, int* inslot, NrGrid nr, PlanGrid pg, int Pl, int world, int rank,
+                                                    const double* gflags)
 {
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, g = blockIdx.x, i = g * 256 + tid;
 	const int flags_now = sel_next ? *a.flags : 0, depleted = nr.state[0];
+	const bool plan = pg.cnt != nullptr && !plan_dropped(a.flags, gflags, world, lane);   // (its loads with the two above: one trip)
 	if (flags_now != 0 || depleted == 0) return;   // a dropped step | not depleted: k_nr_slots ended the step
 	double* gwp = gw ? gw : bank_of(a, SEL_OUT).weights;
 	// the workgroups' verdicts and candidates: one per thread, one trip, then the same reduction everywhere
@@ -905,28 +910,40 @@ __global__ __launch_bounds__(256) void k_nr_sources(const StepBufs a, double* gw
 			info[0] = (gm > 0) ? best : 0; info[1] = 1;
 			if (sel_next) roles();
 		}
+		// the source of slot i: the first particle whose upper slot bound lies beyond i (the bounds never decrease; the last is P)
+		// (sixteen ways per trip to memory — fifteen pivots requested together — instead of two: four trips at 16 384 weights,
+		// not fourteen; a workgroup alone on its CU pays every dependent trip in full)
+		// With the plan's counting in this launch a thread also wants the source of the slot BEFORE its own (is its slot the head of
+		// a run?): both are searched in lockstep — the two searches' pivots requested together, the same four trips.
+		int lo = 0, lo2 = 0;
 		if (i < P) {
-			// the source of slot i: the first particle whose upper slot bound lies beyond i (the bounds never decrease; the last is P)
-			// (sixteen ways per trip to memory — fifteen pivots requested together — instead of two: four trips at 16 384 weights,
-			// not fourteen; a workgroup alone on its CU pays every dependent trip in full)
-			int lo = 0, cnt = P;   // the answer lies in [lo, lo + cnt): hi[lo + cnt - 1] > i
-			while (cnt > 1) {
-				const int stride = (cnt + 15) >> 4, end = lo + cnt;
-				int below = 0;
-				int v[15];
+			const int i2 = plan ? max(i - 1, 0) : i;
+			int cnt = P, cnt2 = P;   // the answers lie in [lo, lo + cnt), [lo2, lo2 + cnt2): hi[lo + cnt - 1] > slot
+			while (cnt > 1 || cnt2 > 1) {
+				const int stride = (cnt + 15) >> 4, end = lo + cnt, stride2 = (cnt2 + 15) >> 4, end2 = lo2 + cnt2;
+				int below = 0, below2 = 0;
+				int v[15], v2[15];
 #pragma unroll
 				for (int j = 0; j < 15; j++) {
-					const int idx = lo + (j + 1) * stride - 1;
-					v[j] = (idx < end - 1) ? nr.hi[idx] : 0x7fffffff;
+					const int idx = lo + (j + 1) * stride - 1, idx2 = lo2 + (j + 1) * stride2 - 1;
+					v[j] = (cnt > 1 && idx < end - 1) ? nr.hi[idx] : 0x7fffffff;
+					v2[j] = (plan && cnt2 > 1 && idx2 < end2 - 1) ? nr.hi[idx2] : 0x7fffffff;
 				}
 #pragma unroll
-				for (int j = 0; j < 15; j++) below += (v[j] <= i) ? 1 : 0;
-				lo += below * stride;
-				cnt = min(stride, end - lo);
+				for (int j = 0; j < 15; j++) { below += (v[j] <= i) ? 1 : 0; below2 += (v2[j] <= i2) ? 1 : 0; }
+				if (cnt > 1) { lo += below * stride; cnt = min(stride, end - lo); }
+				if (plan) { if (cnt2 > 1) { lo2 += below2 * stride2; cnt2 = min(stride2, end2 - lo2); } }
+				else { lo2 = lo; cnt2 = cnt; }
 			}
 			src[i] = lo;
 			gwp[i] = 1.0 / P;   // :742
 			finish_slot(lo, i);
+		}
+		if (plan) {   // (uniform over the launch; whole waves: the vector holds a multiple of 64 slots)
+			int t, sr;
+			bool head, bad;
+			plan_flags(lo, lo2, i, P, Pl, 1.0f / (float) Pl, P >= (1 << 24), t, sr, head, bad);
+			plan_count_slot(pg, i, P, Pl, world, rank, lane, g * 4 + wv, lo, t, sr, head, bad);
 		}
 		return;
 	}
@@ -963,4 +980,13 @@ __global__ __launch_bounds__(256) void k_nr_sources(const StepBufs a, double* gw
 		finish_slot(src[s], s);
 	}
 	if (sel_next && tid == 0) roles();
+	if (plan) {   // the counting for the plan, by this one workgroup over all slots (whole waves: the vector holds a multiple of 64 slots)
+		for (int base = 0; base < P; base += 256) {
+			const int gs = base + tid;
+			int sv, t, sr;
+			bool head, bad;
+			plan_look(src, gs, P, Pl, 1.0f / (float) Pl, P >= (1 << 24), lane, sv, t, sr, head, bad);
+			plan_count_slot(pg, gs, P, Pl, world, rank, lane, (base >> 6) + wv, sv, t, sr, head, bad);
+		}
+	}
 }

@@ -486,8 +486,10 @@ int launch_map(phd_navigator* nav, const StepBufs& b, bool with_alpha, int pipe 
 }
 
 // graw / Pl / world (per-rank host): the weights still lie as the all-gather delivered them, [rank][Pl + 1]; the first launch un-gathers them
+// pgp != NULL (sharded step whose plan runs over the grid too): the resampling's last launch also counts for the plan (*counted <- true)
 int launch_normalise(phd_navigator* nav, const StepBufs& b, double* gw, int P, double u, int force, int skipnorm, int* src, int* info,
-                     int* sel_next = nullptr, hipStream_t st = nullptr, const double* graw = nullptr, int Pl = 0, int world = 0)
+                     int* sel_next = nullptr, hipStream_t st = nullptr, const double* graw = nullptr, int Pl = 0, int world = 0,
+                     const PlanGrid* pgp = nullptr, int rank = 0, const double* gflags = nullptr, bool* counted = nullptr)
 {
 	if (!st) st = nav->stream;
 	if (nav->nr_grid_min > 0 && P >= nav->nr_grid_min && P <= 65536 && b.wait_tickets == 0 && b.done_value == 0) {
@@ -512,7 +514,11 @@ int launch_normalise(phd_navigator* nav, const StepBufs& b, double* gw, int P, d
 		hipLaunchKernelGGL(k_nr_sum, dim3(nr.G), dim3(256), 0, st, b, gw, P, skipnorm, sel_next, nr, graw, Pl, world);
 		hipLaunchKernelGGL(k_nr_stats, dim3(nr.G), dim3(256), 0, st, b, gw, P, skipnorm, sel_next, nr);
 		hipLaunchKernelGGL(k_nr_slots, dim3(nr.G), dim3(256), 0, st, b, gw, P, nav->dp.min_eff, u, force, src, info, sel_next, fr, nav->d_inslot, nr);
-		hipLaunchKernelGGL(k_nr_sources, dim3(nr.G), dim3(256), 0, st, b, gw, P, u, src, info, sel_next, fr, nav->d_inslot, nr);
+		PlanGrid pgn;
+		std::memset(&pgn, 0, sizeof pgn);
+		if (pgp) { pgn = *pgp; if (counted) *counted = true; }
+		hipLaunchKernelGGL(k_nr_sources, dim3(nr.G), dim3(256), 0, st, b, gw, P, u, src, info, sel_next, fr, nav->d_inslot, nr, pgn, Pl > 0 ? Pl : P, world > 0 ? world : 1,
+		                   rank, gflags);
 		HC(hipGetLastError());
 		return PHD_OK;
 	}
@@ -1944,25 +1950,38 @@ void* phd_device_global_weights(phd_navigator* nav, int world_particles)
 	return nav->d_gw;
 }
 
-// The migration plan from the global source vector: over a grid of workgroups (two launches) where the vector is long enough to
-// pay for them, by one workgroup otherwise (k_plan_migration).
-static int launch_plan(phd_navigator* nav, const StepBufs& b, const int* gsrc, const int* info, const int* lflags, const double* gflags,
-                       int Pl, int n, int rank, int* hostcounts, int seq, const double* gw)
+// The migration plan from the global source vector: over a grid of workgroups where the vector is long enough to pay for them — its
+// counting inside the grid resampling's last launch (`counted`), or as k_plan_count (phd_test_migration_plan: a vector from the
+// host), then k_plan_lists —, by one workgroup otherwise (k_plan_migration).
+static bool plan_on_grid(const phd_navigator* nav, int Pl, int n)
 {
 	const long long Pg = (long long) Pl * n;
-	if (nav->plan_grid_min > 0 && Pg >= nav->plan_grid_min && Pg <= PLAN_GRID_MAXSLOTS && (Pl & 63) == 0 && nav->d_plang) {
-		const size_t set = (size_t) PHD_MAX_DEVICES * PHD_MAX_DEVICES + (size_t) (nav->Pcap + 31) / 32 + 2;
-		int* cur = nav->d_plang + (size_t) nav->plan_par * set;
-		int* nxt = nav->d_plang + (size_t) (nav->plan_par ^ 1) * set;
-		nav->plan_par ^= 1;
-		PlanGrid pg;
-		pg.cnt = cur; pg.used = (unsigned int*) (cur + PHD_MAX_DEVICES * PHD_MAX_DEVICES); pg.bad = cur + set - 1;
-		pg.cnt_next = nxt; pg.used_next = (unsigned int*) (nxt + PHD_MAX_DEVICES * PHD_MAX_DEVICES); pg.bad_next = nxt + set - 1;
-		pg.wcg = nav->d_plang + 2 * set;
-		pg.lcg = pg.wcg + 1024;
-		const int G = (int) ((Pg + 255) / 256);
-		hipLaunchKernelGGL(k_plan_count, dim3(G), dim3(256), 0, nav->stream, gsrc, info, lflags, gflags, Pl, n, rank, pg, b, gw);
-		hipLaunchKernelGGL(k_plan_lists, dim3(G), dim3(256), 0, nav->stream, gsrc, info, lflags, gflags, Pl, n, rank, nav->plan, pg, hostcounts, seq);
+	return nav->plan_grid_min > 0 && Pg >= nav->plan_grid_min && Pg <= PLAN_GRID_MAXSLOTS && (Pl & 63) == 0 && nav->d_plang != nullptr;
+}
+
+// the accumulators of this launch pair (and the set its second launch clears for the next one)
+static PlanGrid plan_grid_next(phd_navigator* nav)
+{
+	const size_t set = (size_t) PHD_MAX_DEVICES * PHD_MAX_DEVICES + (size_t) (nav->Pcap + 31) / 32 + 2;
+	int* cur = nav->d_plang + (size_t) nav->plan_par * set;
+	int* nxt = nav->d_plang + (size_t) (nav->plan_par ^ 1) * set;
+	nav->plan_par ^= 1;
+	PlanGrid pg;
+	pg.cnt = cur; pg.used = (unsigned int*) (cur + PHD_MAX_DEVICES * PHD_MAX_DEVICES); pg.bad = cur + set - 1;
+	pg.cnt_next = nxt; pg.used_next = (unsigned int*) (nxt + PHD_MAX_DEVICES * PHD_MAX_DEVICES); pg.bad_next = nxt + set - 1;
+	pg.wcg = nav->d_plang + 2 * set;
+	pg.lcg = pg.wcg + 1024;
+	return pg;
+}
+
+static int launch_plan(phd_navigator* nav, const StepBufs& b, const int* gsrc, const int* info, const int* lflags, const double* gflags,
+                       int Pl, int n, int rank, int* hostcounts, int seq, const double* gw, const PlanGrid* pgp = nullptr, bool counted = false)
+{
+	if (plan_on_grid(nav, Pl, n)) {
+		const PlanGrid pg = pgp ? *pgp : plan_grid_next(nav);
+		const int G = (int) (((long long) Pl * n + 255) / 256);
+		if (!counted) hipLaunchKernelGGL(k_plan_count, dim3(G), dim3(256), 0, nav->stream, gsrc, info, lflags, gflags, Pl, n, rank, pg);
+		hipLaunchKernelGGL(k_plan_lists, dim3(G), dim3(256), 0, nav->stream, gsrc, info, lflags, gflags, Pl, n, rank, nav->plan, pg, hostcounts, seq, b, gw);
 	}
 	else {
 		hipLaunchKernelGGL(k_plan_migration, dim3(1), dim3(1024), plan_lds_bytes(Pl, n), nav->stream, gsrc, info, lflags, gflags, Pl, n, rank, nav->plan,
@@ -1991,9 +2010,15 @@ static int step_global(phd_navigator* nav, int rank, int world_size, double u, u
 	// resampling's own first launch, or by k_ungather in front of the one-workgroup kernel)
 	if (from_graw) nav->d_gflags = nav->d_gw + Pg;
 	else if (!nav->gw_shared) nav->d_gflags = nullptr;   // (the host-plan path gathers the weights only: every rank answers for its own flags)
+	// (the plan over the grid: its accumulators are chosen here, its counting rides in the grid resampling's last launch when that runs)
+	const bool pgrid = plan_on_grid(nav, nav->P, world_size);
+	PlanGrid pg;
+	std::memset(&pg, 0, sizeof pg);
+	if (pgrid) pg = plan_grid_next(nav);
+	bool counted = false;
 	timer_begin(nav, T_NR);
 	rc = launch_normalise(nav, b, nav->d_gw, Pg, u, onlymapping ? -1 : 0, onlymapping ? 1 : 0, nav->d_plan, nav->d_info, nullptr, nullptr,
-	                      from_graw ? (const double*) nav->d_graw : nullptr, nav->P, world_size);
+	                      from_graw ? (const double*) nav->d_graw : nullptr, nav->P, world_size, pgrid ? &pg : nullptr, rank, nav->d_gflags, &counted);
 	timer_end(nav, T_NR);
 	if (rc) return rc;
 	int* hc = nullptr;
@@ -2004,7 +2029,7 @@ static int step_global(phd_navigator* nav, int rank, int world_size, double u, u
 	}
 	timer_begin(nav, T_PL);
 	rc = launch_plan(nav, b, (const int*) nav->d_plan, (const int*) nav->d_info, (const int*) nav->d_flags, nav->d_gflags, nav->P, world_size, rank, hc,
-	                 nav->plan_seq, (const double*) nav->d_gw);
+	                 nav->plan_seq, (const double*) nav->d_gw, pgrid ? &pg : nullptr, counted);
 	timer_end(nav, T_PL);
 	return rc;
 }
