@@ -827,9 +827,17 @@ __global__ __launch_bounds__(256) void k_plan_lists(const int* __restrict__ gsrc
 	const int resampled = info[1], badword = pg.bad[0];
 	const bool drop = plan_dropped(lflags, gflags, n, lane);
 	if (gw && g >= first && g < first + Pl) bank_of(a, SEL_OUT).weights[g - first] = gw[g];   // this rank's slice of the weights
+	// the accumulators of the NEXT pair of launches (the set the pair before this one added to): cleared whatever this step does —
+	// the host alternates the sets with every pair, and a set left as a resampling step filled it would be met again two pairs on
+	{
+		const int gt = blockIdx.x * 256 + tid, gn = gridDim.x * 256;
+		for (int q = gt; q < n * n; q += gn) pg.cnt_next[q] = 0;
+		for (int q = gt; q < (Pl + 31) / 32; q += gn) pg.used_next[q] = 0u;
+		if (gt == 0) pg.bad_next[0] = 0;
+	}
 	if (!resampled || drop) {
 		// Nothing was counted (the counting returns at the same test) and nothing moves: the step's most common end on a frame
-		// that does not deplete the particle set. One workgroup writes the status; both sets of accumulators are still clear.
+		// that does not deplete the particle set. One workgroup writes the status; this pair's set of accumulators is still clear.
 		if (blockIdx.x == 0) {
 			for (int q = tid; q < 2 * n; q += 256) pl.counts[q] = 0;
 			if (tid == 0) { pl.counts[2 * n] = 0; pl.counts[2 * n + 1] = 0; pl.counts[2 * n + 2] = drop ? MIG_DROPPED : MIG_OK; pl.counts[2 * n + 3] = resampled; }
@@ -847,13 +855,6 @@ __global__ __launch_bounds__(256) void k_plan_lists(const int* __restrict__ gsrc
 			}
 		}
 		return;
-	}
-	// the accumulators of the next pair of launches
-	{
-		const int gt = blockIdx.x * 256 + tid, gn = gridDim.x * 256;
-		for (int q = gt; q < n * n; q += gn) pg.cnt_next[q] = 0;
-		for (int q = gt; q < (Pl + 31) / 32; q += gn) pg.used_next[q] = 0u;
-		if (gt == 0) pg.bad_next[0] = 0;
 	}
 	int cv[16];
 #pragma unroll

@@ -277,6 +277,19 @@ def test_grid_migration_plan_equals_the_host_plan(nav_mod, monkeypatch, Pl, worl
     check_plans(nav, np.arange(Pg, dtype=np.int32), Pl, world)           # the identity: nothing moves
     d = nav.test_migration_plan(np.arange(Pg, dtype=np.int32), Pl, world, 0, resampled=False)
     assert d["status"] == 0 and d["nsend"] == 0 and d["nrecv"] == 0 and not d["send_counts"].any()
+    # steps that do not resample BETWEEN steps that do (one, then two in a row: both parities of the alternating accumulator sets):
+    # the launch that returns early must still clear the set the plan before it filled (found by tests/soak_multi.py with the
+    # grid kernels forced: the counts of a resampling step met again two plans later)
+    for quiet in (1, 2, 1):
+        w = rng.random(Pg) ** power + 1e-300
+        gsrc, _ = nav.ResampleParticles(w / w.sum(), float(rng.uniform(0.01, 0.99)))
+        check_plans(nav, gsrc, Pl, world)
+        for _ in range(quiet):
+            d = nav.test_migration_plan(gsrc, Pl, world, world - 1, resampled=False)
+            assert d["status"] == 0 and d["nsend"] == 0 and d["nrecv"] == 0
+    w = rng.random(Pg) ** power + 1e-300
+    gsrc, _ = nav.ResampleParticles(w / w.sum(), 0.37)
+    check_plans(nav, gsrc, Pl, world)
     bad = np.arange(Pg, dtype=np.int32)[::-1].copy()
     assert nav.test_migration_plan(bad, Pl, world, world - 1)["status"] == 2
     w = rng.random(Pg) ** power + 1e-300                                   # ... and a good plan again behind the refused one
