@@ -373,3 +373,35 @@ def test_emit_runs_longer_than_four_and_queues_longer_than_a_chunk(nav_mod, monk
         assert np.isclose(alpha[i], a, rtol=1e-6, atol=0)
     assert longest > 4, "no component met more than four measurements (%d): the frame does not exercise the cut" % longest
     nav.close()
+
+
+def test_sharded_steps_at_the_sizes_the_grid_kernels_take_by_default(nav_mod):
+    """8 ranks x 1024 particles = 8192 slots: the default thresholds (no environment switch) put the resampling on its grid kernels
+    with the plan's counting in their last launch, then k_plan_lists — against ONE handle of 8192 particles (whose steps end on the
+    same grid resampling): weights, poses, sampled maps bit for bit over steps that resample and one that does not, landing flags on."""
+    from test_gpu_round4 import _device_path_handles, _device_path_step
+    world, Pl, Cc, M = 8, 1024, 24, 10
+    f = _depleted_frame(world, Pl, Cc, M, 5400)
+    p1 = prm3d_defaults(max_particles=Pl * world, max_components=96, max_measurements=M)
+    p1.max_quantity = 96
+    one = nav_mod.PHDNavigator(p1, particlecount=Pl * world)
+    one.upload_state(f.planes(), f.counts, f.poses, f.weights)
+    navs = _device_path_handles(nav_mod, f, world, Pl, M, maxc=96, maxq=96)
+    for nv in navs:
+        if nv._lib.phd_migration_recv_is_finegrained(nv._h) == 1:
+            nv._check(nv._lib.phd_migration_set_landing(nv._h, 1))
+    rng = np.random.default_rng(5401)
+    nres = 0
+    for step, u in enumerate((0.31, 0.77, 0.12, 0.6, 0.45)):
+        one.SlamUpdate(None, f.z, u_resample=u)
+        _device_path_step(navs, Pl, u)
+        nres += int(one.resample_sources()[1])
+        assert np.array_equal(one.VehicleWeights, np.concatenate([nv.VehicleWeights for nv in navs])), "step %d" % step
+        assert np.array_equal(one.poses(), np.concatenate([nv.poses() for nv in navs])), "step %d" % step
+        for g in rng.choice(Pl * world, 24, replace=False):
+            a_, b_ = one.MapModel(int(g)), navs[int(g) // Pl].MapModel(int(g) % Pl)
+            assert all(np.array_equal(x, y) for x, y in zip(a_, b_)), "step %d particle %d" % (step, g)
+    assert 1 <= nres, "no step resampled"
+    one.close()
+    for nv in navs:
+        nv.close()
