@@ -328,13 +328,17 @@ def test_device_path_a_flag_on_one_rank_drops_the_step_on_all(nav_mod):
         nv.close()
 
 
-def test_deferred_replay_of_big_clusters_is_the_same_step(nav_mod, monkeypatch):
+@pytest.mark.parametrize("grid_nr", [False, True])
+def test_deferred_replay_of_big_clusters_is_the_same_step(nav_mod, monkeypatch, grid_nr):
     """PHD_DEFER_BIG=1 (read when a handle is created): the particles whose association has a cluster of more than ten rows
     are listed, their ordered replay runs inside the launch of the densities, alpha is finished by the resampling kernel —
-    weights, sources and maps bit for bit those of the default path, on a frame with clusters of more than ten rows."""
+    weights, sources and maps bit for bit those of the default path, on a frame with clusters of more than ten rows.
+    grid_nr: the step ends on the grid resampling kernels (round 5; forced on this small set), whose first launch finishes alpha."""
     from test_gpu_parity import clustered_frame
     from test_gpu_round2 import make_nav
     f = clustered_frame(91, 3, 8, 7, spread_px=4.0)        # three groups of 8 landmarks and 7 measurements a few pixels apart: clusters of up to 15 rows
+    if grid_nr:
+        monkeypatch.setenv("PHD_NR_GRID_MIN", "1")
     results = []
     for defer in ("0", "1"):
         monkeypatch.setenv("PHD_DEFER_BIG", defer)
