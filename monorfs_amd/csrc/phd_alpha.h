@@ -677,7 +677,9 @@ __global__ __launch_bounds__(64) void k_test_pairing(MurtyNodes* nodes, char* bi
 // Arrays indexed by landmark live in LDS while the map estimate has at most ALPHA_JL landmarks; a larger
 // estimate (up to Jcap) moves them to a per-particle slab in HBM, reached through the same (flat) pointers.
 #define ALPHA_JL 256
+#ifndef ALPHA_DEFER_ROWS
 #define ALPHA_DEFER_ROWS 10   // a particle with an association cluster of more rows than this is left to the big-cluster workers (DEFER, below)
+#endif
 
 struct AlphaLds {
 	int zs, red, lm, pick, scr;                 // persistent, offsets in doubles
@@ -1545,7 +1547,7 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 			deferred = true;
 			if (tid == 0) a.biglist[1 + atomicAdd(a.biglist, 1)] = p;   // ([0]: entries; emptied by k_normalise_resample)
 		}
-		else if (s_big) {
+		else if ((DEFER != 1 || ALPHA_DEFER_ROWS > 5) && s_big) {   // (ALPHA_DEFER_ROWS 5: the main kernel defers every such particle and carries no solver at all)
 			// Some cluster has more than 5 rows: it is enumerated best-first (MurtyPairing) under the
 			// early-exit test of PHDNavigator.cs:503, which reads logcomp[m] as left behind by the clusters
 			// before it. So wave 0 replays the clusters in order up to the last such cluster, keeping the
