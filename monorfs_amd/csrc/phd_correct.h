@@ -205,7 +205,10 @@ __device__ __forceinline__ void emit_finish_body(const DevParams& prm, const Ste
 		const int2* seg = cands + (size_t) wv * segcap;
 		// (measured and dropped: a quarter of the lists per wave with scalar counters — no LDS atomic, no shuffle of the bases in
 		// the scan —: the scan 22.6 k -> 21.3 k cycles of the body's 80 k, 48 bytes of scratch instead of 12; eight groups of the
-		// queue requested ahead instead of one: the body 86 k -> 112 k cycles)
+		// queue requested ahead instead of one: the body 86 k -> 112 k cycles in the stamped build — where every guarded load was
+		// followed by its own s_waitcnt: the compiler had sunk the float -> double conversion into the guard —; with unconditional
+		// loads, all eight in one trip, the product build: config B 0.608 -> 0.610 ms per step, S 3.45 -> 3.40. The scan is not
+		// waiting for the queue: its ~200 instructions per group issue at the pace the three other workgroups' Kalman paths leave.)
 #ifdef PHD_STAMPS
 		em_setup = clock64() - em_t0;
 #endif
