@@ -70,6 +70,7 @@ def one(seq, nsteps):
 if __name__ == "__main__":
     nseq = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-    for s in range(nseq):
+    first = int(sys.argv[3]) if len(sys.argv) > 3 else 0   # (sequence numbers are the seeds)
+    for s in range(first, first + nseq):
         one(s, nsteps)
     print("multi soak ok")
