@@ -774,9 +774,8 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 
 	const int p = (pin >= 0) ? pin : a.p0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 	const int M = a.M, cap = a.cap;
-	const MixView vin = bank_view(a, SEL_IN), vout = bank_view(a, SEL_OUT);
+	const MixView vout = bank_view(a, SEL_OUT);
 	const Bank bin = bank_of(a, SEL_IN);
-	const Bank bout = bank_of(a, SEL_OUT);
 	const int no = QUASI ? 0 : vout.count[p];
 	bool deferred = false;   // (workgroup-uniform) DEFER == 1: this particle is left to k_alpha_big
 	const size_t sbo = (size_t) p * cap;

@@ -169,7 +169,7 @@ __device__ __forceinline__ void normalise_resample_body(const StepBufs& a, doubl
 	__shared__ double s_pchi[1024], s_pclo[1024];  // double-double prefix sum at the start of every thread's chunk
 	__shared__ double s16[16], s16b[16];
 	__shared__ int    s_i16[16];
-	__shared__ int    s_res, s_ok, s_best;
+	__shared__ int    s_ok, s_best;
 	// (launched with 1024 threads, or 256 for short weight vectors: the shape of the sums depends on the vector length only)
 	const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = (int) blockDim.x, nw = nt >> 6;
 	PHD_STAMP_DECL;

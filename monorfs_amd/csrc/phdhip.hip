@@ -351,10 +351,11 @@ const char* T_SW = "k_sweep";
 const char* T_EF = "k_emit_finish";
 const char* T_PM = "k_prune_merge";
 const char* T_EP = "k_emit_prune";
+#ifdef PHD_WITH_FUSE_SEP
 const char* T_SEP = "k_sweep_emit_prune";
+#endif
 const char* T_WA = "k_alpha_assoc";
 const char* T_WD = "k_alpha_density";
-const char* T_WC = "k_alpha_combine";
 const char* T_NR = "k_normalise_resample";
 const char* T_GR = "k_finish_sharded";
 const char* T_PL = "k_plan_migration";
