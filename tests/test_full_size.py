@@ -286,3 +286,48 @@ def test_timed_mode_equals_the_gated_mode(cfg, profile):
         assert np.isclose(alpha[i], al, rtol=1e-6, atol=0)
     gated.close()
     timed.close()
+
+
+def test_config_c8_at_full_size_on_one_gpu():
+    """BASELINE config C8 at its full size — 8 ranks x 2048 particles x 512 components x 64 measurements — rehearsed on ONE GPU: eight
+    handles in one process play the per-rank sequence of `bench.py --gpus 8` (local step, the weights gathered by device copies,
+    the 16 384-slot resampling and the migration plan on their grid kernels, records stored straight into the peers' receive
+    buffers, landing flags, unpack) against ONE handle holding all 16 384 particles: particle weights, poses and sampled maps bit
+    for bit over steps that resample (long runs of one source cross the rank boundaries) — what no 8-GPU node was ever available
+    to show, minus the wires."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from monorfs_amd import navigator
+    from test_gpu_round4 import _device_path_handles, _device_path_step
+    world, (Pg, Cc, M, seed) = 8, CONFIGS["C8"]
+    Pl = Pg // world
+    f = Frame(Pg, Cc, M, seed, weight_profile="steady")
+    f.weights = np.random.default_rng(8).random(f.P) ** 12     # depleted from the start: the first step resamples
+    f.weights /= f.weights.sum()
+    p1 = prm3d_defaults(max_particles=Pg, max_components=600, max_measurements=M)
+    one = navigator.PHDNavigator(p1, particlecount=Pg)
+    one.upload_state(f.planes(), f.counts, f.poses, f.weights)
+    navs = _device_path_handles(navigator, f, world, Pl, M)
+    flags = all(nv._lib.phd_migration_recv_is_finegrained(nv._h) == 1 for nv in navs)
+    for nv in navs:
+        if flags:
+            nv._check(nv._lib.phd_migration_set_landing(nv._h, 1))
+    rng = np.random.default_rng(seed)
+    nres = 0
+    for step, u in enumerate((0.37, 0.81, 0.09)):
+        one.SlamUpdate(None, f.z, u_resample=u)
+        _device_path_step(navs, Pl, u)
+        src, res = one.resample_sources()
+        nres += int(res)
+        assert np.array_equal(one.VehicleWeights, np.concatenate([nv.VehicleWeights for nv in navs])), "step %d" % step
+        assert np.array_equal(one.poses(), np.concatenate([nv.poses() for nv in navs])), "step %d" % step
+        for g in list(rng.choice(Pg, 12, replace=False)) + [0, Pl - 1, Pl, Pg - 1]:
+            a_, b_ = one.MapModel(int(g)), navs[int(g) // Pl].MapModel(int(g) % Pl)
+            assert all(np.array_equal(x, y) for x, y in zip(a_, b_)), "step %d particle %d" % (step, g)
+        if res:   # records did cross the rank boundaries
+            own = np.arange(Pg) // Pl
+            assert np.any(np.asarray(src) // Pl != own), "step %d: nothing migrated" % step
+    assert nres >= 1, "no step resampled"
+    one.close()
+    for nv in navs:
+        nv.close()
