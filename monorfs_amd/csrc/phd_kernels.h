@@ -1025,7 +1025,10 @@ __global__ __launch_bounds__(256) void k_finish_sharded(const StepBufs a, const 
 	const int i = blockIdx.x, tid = threadIdx.x;
 	const int nrecv = pl.counts[2 * n + 1], status = pl.counts[2 * n + 2], resampled = pl.counts[2 * n + 3];
 	const int I = a.sel[SEL_IN], O = a.sel[SEL_OUT], T = a.sel[SEL_TMP], X = a.sel[SEL_INMIX];
-	if (landing && status == MIG_OK && resampled && nrecv > 0) {   // (uniform over the launch: every workgroup that may read a record waits)
+	// (the workgroups that read the receive buffer wait: the one that unpacks record i, and every particle fed by an arrival — the
+	// others, whose source is a local particle, go ahead: fewer waves polling this rank's memory while the peers' stores come in,
+	// fewer slots held by waiting workgroups)
+	if (landing && status == MIG_OK && resampled && nrecv > 0 && (i < nrecv || pl.code[i] < 0)) {   // (uniform over the workgroup)
 		if (tid < n && pl.counts[n + tid] > 0) {
 			const long long t0 = wall_clock64();
 			while ((long long) (__hip_atomic_load(landing + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {

@@ -7,7 +7,9 @@ and compares.
       PROCESSES' receive buffers (opened through hipIpcMemHandle), a barrier stands in for the one-word all-reduce;
   mode "flags": the same with phd_migration_set_landing(1) — nothing at all between push and unpack: the senders leave a
       step-stamped flag behind their records, the receiver's k_finish_sharded waits for it on the device (round 5);
-  mode "host": round 3's sequence — the host waits for the plan's split sizes and moves the records with all_to_all_single."""
+  mode "host": round 3's sequence — the host waits for the plan's split sizes and moves the records with all_to_all_single.
+  argv[2] "big": every rank holds a shard of config C8's size (2048 x 512 x 64); with four ranks the 8192-slot global vector
+      puts the resampling and the plan on their grid kernels."""
 import ctypes as C
 import os
 import sys
@@ -37,6 +39,8 @@ def main():
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     Pl, Cc, M, steps = 40, 60, 16, 3
+    if len(sys.argv) > 2 and sys.argv[2] == "big":   # a rank's shard at config C8's size: 2048 particles x 512 components x 64 measurements
+        Pl, Cc, M, steps = 2048, 512, 64, 3
     Pg = Pl * world
     f = Frame(Pg, Cc, M, 77, weight_profile="steady")
     planes = f.planes()
@@ -136,7 +140,7 @@ def main():
             print("step %d ok: %d particles migrated between ranks" % (step, moved), flush=True)
     if rank == 0:
         assert nresampled > 0, "no step resampled: the migration path was not exercised"
-        print("multiproc ok")
+        print("multiproc ok: %d ranks x %d particles x %d components x %d measurements" % (world, Pl, Cc, M))
         one.close()
     nav.close()
     dist.destroy_process_group()
