@@ -1006,6 +1006,27 @@ __global__ __launch_bounds__(64) void k_post_landing(double* const* recvbase, in
 	}
 }
 
+// The receiver's wait as ONE wave in front of k_finish_sharded (the default): lane t polls the word of rank t when this step
+// takes records from it; the launch boundary behind it is the acquire for everything k_finish_sharded reads. A grid that waits —
+// the same loop inside k_finish_sharded, PHD_LANDING_INLINE=1: one launch boundary (~3 us) less — holds every slot of the
+// device for as long as it waits: harmless when the senders run on OTHER devices, a standstill when ranks share one (seen:
+// four processes with 2048-particle shards on one GPU), and thousands of waves polling the memory the peers are storing into.
+__global__ __launch_bounds__(64) void k_wait_landing(const MigPlan pl, int n, const unsigned long long* landing, unsigned long long seq,
+                                                     long long landing_ticks, int* flags)
+{
+	const int tid = threadIdx.x;
+	const int nrecv = pl.counts[2 * n + 1], status = pl.counts[2 * n + 2], resampled = pl.counts[2 * n + 3];
+	if (status != MIG_OK || !resampled || nrecv <= 0) return;
+	if (tid < n && pl.counts[n + tid] > 0) {
+		const long long t0 = wall_clock64();
+		while ((long long) (__hip_atomic_load(landing + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+			if (wall_clock64() - t0 > landing_ticks) { atomicOr(flags, PHD_FLAG_ORDER_TIMEOUT); break; }
+			__builtin_amdgcn_s_sleep(8);
+		}
+	}
+	__threadfence_system();
+}
+
 // End of a sharded step, one workgroup per local particle; what it does is read from the device plan, not decided by the
 // host (rotate_roles in phd_resample.h has the rules of the single-handle step, which are these):
 //   dropped step (a flag was raised): the roles stay as they were, nothing is touched

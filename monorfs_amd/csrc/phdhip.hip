@@ -144,6 +144,7 @@ struct phd_navigator {
 	bool recv_finegrained = false;                   // d_recv is fine-grained device memory (coherent for the peers that store into it)
 	int  landing_flags = 0;                          // phd_migration_set_landing: 1 = push posts step-stamped flags into the peers' receive buffers, unpack waits for them
 	unsigned long long landing_seq = 0;              // number of the last device-path global step (the flags' stamp)
+	int       landing_inline = 0;                    // 1 (PHD_LANDING_INLINE): the wait inside k_finish_sharded instead of k_wait_landing in front of it
 	long long landing_ticks = 1000000000LL;          // bound of the wait for a flag, in ticks of the 100 MHz counter: 10 s (environment PHD_LANDING_TIMEOUT_MS)
 	double* d_graw = nullptr; int grawcap = 0;       // per-rank host: the all-gather's landing buffer, [world][P + 1] (weights | status word)
 	std::vector<void*> ipc_opened;                   // peers' receive buffers opened with hipIpcOpenMemHandle (closed in phd_destroy)
@@ -2100,6 +2101,7 @@ int phd_migration_set_landing(phd_navigator* nav, int flags)
 	HC(hipStreamSynchronize(nav->stream));
 	nav->landing_flags = flags ? 1 : 0;
 	if (const char* e = getenv("PHD_LANDING_TIMEOUT_MS")) nav->landing_ticks = std::max(1LL, atoll(e)) * 100000LL;
+	if (const char* e = getenv("PHD_LANDING_INLINE")) nav->landing_inline = atoi(e) != 0;
 	return PHD_OK;
 }
 
@@ -2403,6 +2405,10 @@ static int step_finish(phd_navigator* nav)
 	if (nav->landing_flags && nav->plan_on_device && nav->world > 1) {
 		const size_t rec = (size_t) 8 + (size_t) MIX_REC * nav->cap;
 		landing = (const unsigned long long*) (nav->d_recv + (size_t) nav->recvrecs * rec);
+		if (!nav->landing_inline) {   // one wave waits, in front of the launch that reads (k_wait_landing)
+			hipLaunchKernelGGL(k_wait_landing, dim3(1), dim3(64), 0, nav->stream, nav->plan, nav->world, landing, nav->landing_seq, nav->landing_ticks, nav->d_flags);
+			landing = nullptr;
+		}
 	}
 	hipLaunchKernelGGL(k_finish_sharded, dim3(nav->P), dim3(256), 0, nav->stream, b, nav->plan, nav->world, (const double*) nav->d_recv,
 	                   1.0 / (double) nav->last_world_particles, sel_next, nav->frozen ? 1 : 0, nav->d_inslot, nav->d_mslot, landing, nav->landing_seq, nav->landing_ticks);

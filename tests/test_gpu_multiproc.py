@@ -29,10 +29,12 @@ def test_sharded_sequence_in_real_processes(world, mode):
     _run(world, mode)
 
 
-def test_four_processes_with_shards_of_config_c8():
+@pytest.mark.parametrize("mode", ["device", "flags"])
+def test_four_processes_with_shards_of_config_c8(mode):
     """Four processes, each a rank's shard of config C8 (2048 particles x 512 components x 64 measurements): the 8192-slot global
     vector is resampled and planned by the grid kernels at their default thresholds, the records go into the other PROCESSES'
-    buffers — against one handle of 8192 particles in rank 0, bit for bit. With a barrier behind the push, not the landing flags:
-    the ranks share ONE GPU here, and a rank whose 2048 workgroups of k_finish_sharded wait for a flag hold every slot the
-    sender's kernels would need (the wait then runs into its bound — seen; between GPUs a waiting rank holds only its own)."""
-    assert "4 ranks x 2048 particles x 512 components x 64 measurements" in _run(4, "device", "big")
+    buffers — against one handle of 8192 particles in rank 0, bit for bit. "flags": nothing between push and unpack but the landing
+    flags, waited for by ONE wave in front of k_finish_sharded (k_wait_landing). (With the wait inside k_finish_sharded's 2048
+    workgroups — PHD_LANDING_INLINE=1 — this case ran into the wait's bound on every try: the ranks share ONE GPU here, and a
+    waiting grid holds the slots the senders' kernels need.)"""
+    assert "4 ranks x 2048 particles x 512 components x 64 measurements" in _run(4, mode, "big")
