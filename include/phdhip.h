@@ -309,7 +309,9 @@ int   phd_migration_recv_is_finegrained(phd_navigator* nav);         /* 1 / 0; -
 int   phd_migration_push_async(phd_navigator* nav);
 /* 1: landing flags (needs fine-grained receive buffers: refused with PHD_ERR_BAD_ARGUMENT otherwise); 0: the caller's collective.
  * A flag that does not arrive within 10 s (environment PHD_LANDING_TIMEOUT_MS, read by this call) ends the wait; the next phd_sync
- * reports PHD_ERR_GENERIC (a peer has died; the handle's state is then undefined: phd_reset / upload).                             */
+ * reports PHD_ERR_GENERIC (a peer has died; the handle's state is then undefined: phd_reset / upload). The wait is one wave in a
+ * launch of its own in front of the unpack kernel (environment PHD_LANDING_INLINE=1 at phd_create: inside that kernel's
+ * workgroups instead — one launch less, but a waiting grid holds every slot of its device: never with ranks sharing a GPU).        */
 int   phd_migration_set_landing(phd_navigator* nav, int flags);
 void* phd_stream(phd_navigator* nav);                               /* hipStream_t of the handle   */
 /* Lend the handle a host stream (hipStream_t, NULL = the default stream): kernels and the host's
