@@ -331,3 +331,45 @@ def test_config_c8_at_full_size_on_one_gpu():
     one.close()
     for nv in navs:
         nv.close()
+
+
+def test_multi_device_handle_at_config_c8():
+    """The library's own multi-device handle (phd_create over a device list: what a single-process host — the C# one — uses for
+    N GPUs) at config C8's full size: 8 shards x 2048 particles x 512 components x 64 measurements, device 0 listed eight times on a
+    one-GPU box, against a single handle of 16 384 particles: weights, poses, BestParticle, resampling sources and sampled maps bit
+    for bit over steps that resample, a batch of steps posted back to back included."""
+    from monorfs_amd import navigator
+    Pg, Cc, M, seed = CONFIGS["C8"]
+    f = Frame(Pg, Cc, M, seed, weight_profile="steady")
+    f.weights = np.random.default_rng(9).random(f.P) ** 12
+    f.weights /= f.weights.sum()
+    p = prm3d_defaults(max_particles=Pg, max_components=600, max_measurements=M)
+    single = navigator.PHDNavigator(p, particlecount=Pg)
+    multi = navigator.PHDNavigator(p, particlecount=Pg, devices=[0] * 8)
+    for nav in (single, multi):
+        nav.upload_state(f.planes(), f.counts, f.poses, f.weights)
+    rng = np.random.default_rng(seed + 1)
+    nres = 0
+    for step in range(3):
+        z = f.z + rng.normal(size=f.z.shape) * np.sqrt([2.0, 2.0, 1e-3]) * 0.3
+        if step == 2:
+            us = [0.21, 0.66, 0.93]
+            for nav in (single, multi):
+                nav.set_measurements(z)
+                for ub in us:
+                    nav.step_async(ub)
+                nav.sync()
+        else:
+            u = float(rng.uniform(0.05, 0.95))
+            single.SlamUpdate(None, z, u_resample=u)
+            multi.SlamUpdate(None, z, u_resample=u)
+        assert np.array_equal(single.VehicleWeights, multi.VehicleWeights), "step %d: weights" % step
+        assert np.array_equal(single.poses(), multi.poses()), "step %d: poses" % step
+        assert single.BestParticle == multi.BestParticle, "step %d: BestParticle" % step
+        sa, sb = single.resample_sources(), multi.resample_sources()
+        assert sa[1] == sb[1] and np.array_equal(sa[0], sb[0]), "step %d: sources" % step
+        nres += int(sa[1])
+        for g in list(rng.choice(Pg, 10, replace=False)) + [0, 2047, 2048, Pg - 1]:
+            assert all(np.array_equal(x, y) for x, y in zip(single.MapModel(int(g)), multi.MapModel(int(g)))), "step %d particle %d" % (step, g)
+    assert nres >= 1, "no step resampled"
+    single.close(); multi.close()
