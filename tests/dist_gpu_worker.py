@@ -41,6 +41,8 @@ def main():
     Pl, Cc, M, steps = 40, 60, 16, 3
     if len(sys.argv) > 2 and sys.argv[2] == "big":   # a rank's shard at config C8's size: 2048 particles x 512 components x 64 measurements
         Pl, Cc, M, steps = 2048, 512, 64, 3
+    if len(sys.argv) > 3:
+        steps = int(sys.argv[3])          # (a longer sequence, by hand: tests run three steps)
     Pg = Pl * world
     f = Frame(Pg, Cc, M, 77, weight_profile="steady")
     planes = f.planes()
@@ -74,7 +76,7 @@ def main():
             assert lib.phd_migration_recv_is_finegrained(h) == 1, "no fine-grained receive buffer on this box: the flags need one"
             nav._check(lib.phd_migration_set_landing(h, 1))
     for step in range(steps):
-        u = 0.3 + 0.2 * step
+        u = (0.3 + 0.2 * step) % 1.0
         nav._check(lib.phd_step_local_async(h, 0))
         if mode == "device":
             lw = dev(lib.phd_device_local_weights(h), Pl + 1).cpu()
