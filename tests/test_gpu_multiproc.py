@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(world, *args):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29530 + world))
+def _run(world, *args, **more_env):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29530 + world), **more_env)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
                         "--master-addr", "127.0.0.1", "--master-port", str(29530 + world),
@@ -38,3 +38,10 @@ def test_four_processes_with_shards_of_config_c8(mode):
     workgroups — PHD_LANDING_INLINE=1 — this case ran into the wait's bound on every try: the ranks share ONE GPU here, and a
     waiting grid holds the slots the senders' kernels need.)"""
     assert "4 ranks x 2048 particles x 512 components x 64 measurements" in _run(4, mode, "big")
+
+
+def test_sharded_sequence_with_ordinary_receive_buffers():
+    """bench.py's first fallback (a runtime that refuses IPC on fine-grained memory): PHD_COARSE_RECV=1 makes the receive buffers
+    ordinary device allocations — exported, opened and stored into by the other processes all the same, with the barrier behind
+    the push (the landing flags need fine-grained memory: phd_migration_set_landing refuses)."""
+    _run(3, "device", PHD_COARSE_RECV="1")

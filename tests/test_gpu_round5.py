@@ -405,3 +405,49 @@ def test_sharded_steps_at_the_sizes_the_grid_kernels_take_by_default(nav_mod):
     one.close()
     for nv in navs:
         nv.close()
+
+
+def test_landing_flags_are_refused_on_ordinary_receive_buffers(nav_mod, monkeypatch):
+    """phd_migration_set_landing(1) needs fine-grained receive buffers (a peer's store must become visible while the receiver's
+    kernel runs): with PHD_COARSE_RECV=1 — bench.py's fallback when IPC on fine-grained memory is refused — the call fails loudly
+    and the handle keeps the caller's collective as landing barrier (0 is always accepted)."""
+    monkeypatch.setenv("PHD_COARSE_RECV", "1")
+    f = Frame(32, 40, 12, 503, weight_profile="steady")
+    nav, _ = _handle(nav_mod, f)
+    lib = nav._lib
+    assert lib.phd_migration_recv_is_finegrained(nav._h) == 0
+    with pytest.raises(Exception):
+        nav._check(lib.phd_migration_set_landing(nav._h, 1))
+    nav._check(lib.phd_migration_set_landing(nav._h, 0))
+    nav.close()
+
+
+@pytest.mark.parametrize("inline", ["0", "1"])
+def test_landing_wait_in_its_own_wave_and_inside_the_unpack_kernel(nav_mod, monkeypatch, inline):
+    """the two places of the receiver's wait (k_wait_landing in front of k_finish_sharded, the default; PHD_LANDING_INLINE=1: inside
+    its workgroups) give the same sharded steps, bit for bit the single handle"""
+    from test_gpu_round4 import _device_path_handles, _device_path_step
+    monkeypatch.setenv("PHD_LANDING_INLINE", inline)
+    world, Pl, Cc, M = 3, 64, 70, 18
+    f = _depleted_frame(world, Pl, Cc, M, 5500)
+    p1 = prm3d_defaults(max_particles=Pl * world, max_components=600, max_measurements=M)
+    one = nav_mod.PHDNavigator(p1, particlecount=Pl * world)
+    one.upload_state(f.planes(), f.counts, f.poses, f.weights)
+    navs = _device_path_handles(nav_mod, f, world, Pl, M)
+    for nv in navs:
+        if nv._lib.phd_migration_recv_is_finegrained(nv._h) != 1:
+            pytest.skip("no fine-grained receive buffers on this box")
+        nv._check(nv._lib.phd_migration_set_landing(nv._h, 1))
+    nres = 0
+    for u in (0.31, 0.77, 0.12):
+        one.SlamUpdate(None, f.z, u_resample=u)
+        _device_path_step(navs, Pl, u)
+        nres += int(one.resample_sources()[1])
+        assert np.array_equal(one.VehicleWeights, np.concatenate([nv.VehicleWeights for nv in navs]))
+        assert np.array_equal(one.poses(), np.concatenate([nv.poses() for nv in navs]))
+        for g in range(0, Pl * world, 7):
+            assert all(np.array_equal(x, y) for x, y in zip(one.MapModel(g), navs[g // Pl].MapModel(g % Pl))), "particle %d" % g
+    assert nres >= 1
+    one.close()
+    for nv in navs:
+        nv.close()
