@@ -756,8 +756,17 @@ __host__ __device__ inline size_t alpha_jscratch_doubles(int Jcap)
 //                them). 1: a particle that needs it is put on the launch's list (StepBufs::biglist) and gets no set
 //                log-likelihood here; 2: k_alpha_big, one workgroup per listed particle (pin >= 0), runs the body again WITH the
 //                replay — on a stream of its own, beside k_alpha_density, which does not need the value (k_alpha_combine does).
+#ifndef DENS_JL
+#define DENS_JL 128   // landmarks whose partial sums stay in LDS
+#endif
+// `helper_go` (k_particle_chain with a helper workgroup per particle, a.dsplit): where the map estimate is final the body
+// publishes it and — if the particle's helper has reported, from the same XCD — hands the density sums (alpha_density_body) to it,
+// which then run BESIDE the association below instead of behind it; *helper_go says whether it did.
+__device__ __forceinline__ unsigned int my_xcd() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u; }   // HW_REG_XCC_ID
+
 template <int ZB, bool QUASI, bool GRAD = false, int TAG = 0, int DEFER = 0>
-__device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const StepBufs& a, int ncap, double* smem, double* gws = nullptr, int pin = -1)
+__device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const StepBufs& a, int ncap, double* smem, double* gws = nullptr, int pin = -1,
+                                                 int* helper_go = nullptr)
 {
 	constexpr int MP = ZB * 64;
 	constexpr int MW = ZB;   // 64-bit adjacency words per landmark
@@ -782,6 +791,9 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 	const PoseD pose = load_pose(QUASI ? a.qposes + (size_t) p * 7 : bin.poses + (size_t) p * 7);
 
 	for (int k = tid; k < MP * 3; k += 256) zs[k] = (k < M * 3) ? a.z[k] : 0.0;
+	// (the helper's word, asked for here and looked at where the map estimate is final: the trip to memory is off the path)
+	unsigned int helper_word = 0;
+	if (!QUASI && helper_go && tid == 0) helper_word = __hip_atomic_load(a.dsync + 3 * (size_t) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
 	PHD_STAMP_DECL;
 	PHD_STAMP(0);
@@ -1015,8 +1027,22 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 			glm[j] = l0; glm[a.Jcap + j] = l1; glm[2 * a.Jcap + j] = l2;
 		}
 	}
+	if (!QUASI && helper_go) {
+		// Everything the density sums read is final now: the pruned map, the births, and — just above — the map estimate. The
+		// helper gets them through the L2 both workgroups sit behind (so only a helper on this XCD is taken: no write-back of the
+		// L2, which cost more than the helper gives): every wave's stores have left the CU (vmcnt) before the barrier below, then
+		// thread 0 leaves the word the helper waits for. A map estimate beyond the densities' LDS arrays stays here (its sums would
+		// go through the slab this body is still using).
+		if (tid == 0) { a.aJ[p] = J; a.account[p] = s_ccount; }
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	}
 	__threadfence_block();
 	__syncthreads();
+	if (!QUASI && helper_go && tid == 0) {
+		const int go = (J > 0 && J <= DENS_JL && helper_word == ((a.dstamp << 4) | my_xcd())) ? 1 : 0;
+		__hip_atomic_store(a.dsync + 3 * (size_t) p + 1, 2u * a.dstamp + (unsigned int) go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		*helper_go = go;
+	}
 
 	PHD_STAMP(3);
 	// ---- phase 3: SetLogLikelihood (PHDNavigator.cs:462-515) on the matrix of SetLogLikeMatrix (:415-453)
@@ -2020,9 +2046,6 @@ __global__ __launch_bounds__(256, 4) void k_quasi_setll(const DevParams prm, con
 // with v(.) the full, ungated mixture density (Map.Evaluate(point), Map.cs:192-202) and m_j the landmarks of
 // the map estimate left in HBM by k_alpha_assoc. Landmark per lane, component tiles broadcast from LDS.
 // =================================================================================================
-#ifndef DENS_JL
-#define DENS_JL 128   // landmarks whose partial sums stay in LDS
-#endif
 #define DENS_REC 12   // gauss_record + the weight ratio of the component's surviving misdetection copy (+ 1: records stay 16-byte aligned)
 
 #ifndef DENS_TILE
@@ -2032,7 +2055,26 @@ __global__ __launch_bounds__(256, 4) void k_quasi_setll(const DevParams prm, con
 #define PHD_DENS_WAVES 4
 #endif
 #define DENS_LDS_DOUBLES (DENS_TILE * DENS_REC + 2 * (DENS_JL / 64) * 256 + EXPTAB_N + 2)
-__device__ __forceinline__ void alpha_density_body(const DevParams& prm, const StepBufs& a, double* pool, int pin = -1)
+// WeightAlpha's last line for a particle whose density sums and set log-likelihood come from two workgroups (k_particle_chain's helper
+// and main): each leaves its number (a.ratio / a.setll), waits until that store is in the L2 both sit behind and swaps the launch's
+// number into the particle's ticket word; the one that finds it there already is second, reads the other's number and writes alpha
+// and the weight — exp(setll + ratio), as the one-workgroup path does. One thread; returns whether it was second.
+__device__ __forceinline__ bool alpha_meet(const StepBufs& a, int p, bool have_ratio, double mine)
+{
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	if (atomicExch(a.dsync + 3 * (size_t) p + 2, a.dstamp) != a.dstamp) return false;
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	const double other = __hip_atomic_load(have_ratio ? a.setll + p : a.ratio + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const double setll = have_ratio ? other : mine, ratio = have_ratio ? mine : other;
+	const double alpha = exp(setll + ratio);         // PHDNavigator.cs:392
+	a.alpha[p] = alpha;
+	bank_of(a, SEL_OUT).weights[p] = bank_of(a, SEL_IN).weights[p] * alpha;   // :335
+	return true;
+}
+
+// `meet` (the helper workgroup of k_particle_chain): the body ends with alpha_meet instead of WeightAlpha's last line; returns
+// whether this workgroup wrote the particle's alpha.
+__device__ __forceinline__ bool alpha_density_body(const DevParams& prm, const StepBufs& a, double* pool, int pin = -1, bool meet = false)
 {
 	constexpr int JL = DENS_JL;
 	double* const tile = pool;                                        // [DENS_TILE][12]
@@ -2197,7 +2239,11 @@ __device__ __forceinline__ void alpha_density_body(const DevParams& prm, const S
 	if (tid == 0) {
 		const double ccount = a.account[p];
 		double ratio = (plog - pcount) - (clog - ccount);   // :390
-		if (a.defer) a.ratio[p] = ratio;                    // (k_alpha_combine: the set log-likelihood may still be in the making)
+		if (meet) {
+			__hip_atomic_store(a.ratio + p, ratio, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			s_wc[0] = alpha_meet(a, p, true, ratio) ? 1 : 0;
+		}
+		else if (a.defer) a.ratio[p] = ratio;               // (k_alpha_combine: the set log-likelihood may still be in the making)
 		else {
 			double alpha = exp(a.setll[p] + ratio);         // :392
 			a.alpha[p] = alpha;
@@ -2207,6 +2253,9 @@ __device__ __forceinline__ void alpha_density_body(const DevParams& prm, const S
 			else bout.weights[p] = wnew;
 		}
 	}
+	if (!meet) return true;
+	__syncthreads();
+	return s_wc[0] != 0;
 }
 
 __global__ __launch_bounds__(256, PHD_DENS_WAVES) void k_alpha_density(const DevParams prm, const StepBufs a)

@@ -148,6 +148,10 @@ struct StepBufs {
 	int*          nr_sel_next;
 	int*          nr_inslot;
 	int     stamp_kernel; // which kernel writes them (env PHD_STAMP_KERNEL): 2 prune, 3 assoc, 4 density, 1 correct, 5 the one-launch chain
+	// k_particle_chain with a HELPER workgroup per particle for the densities of WeightAlpha (two workgroups per particle for that body)
+	int           dsplit;   // 1: the launch has 2 P workgroups, the second P are the helpers (2 - 4: test and measuring switches, PHD_DSPLIT_LATE)
+	unsigned int  dstamp;   // this launch's number (never 0, grows by one per launch of the chain): what the words below are compared with
+	unsigned int* dsync;    // [P][3]: helper ready (16 dstamp + its XCD) | the main's word (2 dstamp + {0 it keeps the density sums, 1 the helper runs them}) | ticket (alpha_meet)
 };
 
 // The bank playing `role`. The roles rotate on the device (a.sel lives in device memory), so the index is not known
@@ -296,6 +300,50 @@ template <int ZB, bool HALF = false>
 __global__ __launch_bounds__(256, 1) void k_particle_chain(const DevParams prm, const StepBufs a, int cutcap, int with_alpha)
 {
 	extern __shared__ __align__(16) double smem[];
+	// Two workgroups per particle where the chain allows it (a.dsplit: the launch has 2 nmain workgroups): WeightAlpha's density sums
+	// (alpha_density_body) need the pruned map and the map estimate, not the association — so the HELPER of particle p, workgroup
+	// nmain + p, runs them BESIDE the main workgroup's association instead of behind it. The helper says it is there (the launch's
+	// number and its XCD) and waits for the main's word; the MAIN never waits: where its map estimate is final (alpha_assoc_body)
+	// it looks whether its helper has reported from the same XCD and hands the sums over, or keeps them — the same body, the same
+	// bits either way. The two meet in alpha_meet. A helper only ever waits for a workgroup that was handed out before it, and
+	// gives up (step dropped: a.flags) after 2 s of the 100 MHz counter.
+	const int nmain = a.dsplit ? (int) (gridDim.x >> 1) : (int) gridDim.x;
+	if (a.dsplit && (int) blockIdx.x >= nmain) {
+		// (whose helper: workgroups go to the XCDs in turn, workgroup b to XCD b mod 8, so helper h = b - nmain takes, within its group of
+		// eight particles, the one whose main workgroup has b's residue — with a particle count that is no multiple of 8 the helpers
+		// would otherwise all sit on another XCD than their mains and never be picked; the last, incomplete group stays as it is)
+		const int h = (int) blockIdx.x - nmain;
+		const int p = a.p0 + (((h | 7) < nmain) ? (h & ~7) + ((h + nmain) & 7) : h);
+		int* const s_go = (int*) smem;
+		if (!with_alpha || a.dsplit == 3) return;   // (3: a measuring switch — helpers that leave at once)
+		if (threadIdx.x == 0) {
+			unsigned int* w = a.dsync + 3 * (size_t) p;
+			if (a.dsplit == 2) {   // (test switch PHD_DSPLIT_LATE=1: a helper that reports 0.5 ms late — every main keeps its sums)
+				const long long t1 = wall_clock64();
+				while (wall_clock64() - t1 < 50000LL) __builtin_amdgcn_s_sleep(64);
+			}
+			__hip_atomic_store(w, (a.dstamp << 4) | (a.dsplit == 4 ? 15u : my_xcd()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (4: a measuring switch — helpers nobody picks)
+			const long long t0 = wall_clock64();
+			int go = -1;
+			for (;;) {
+				const unsigned int v = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if ((v >> 1) == a.dstamp) { go = (int) (v & 1u); break; }
+				if (wall_clock64() - t0 > 200000000LL) break;
+				__builtin_amdgcn_s_sleep(8);
+			}
+			if (go < 0) { atomicOr(a.flags, PHD_FLAG_ORDER_TIMEOUT); go = 0; }   // (cannot happen with workgroups handed out in order; the step is dropped)
+			s_go[0] = go;
+		}
+		__syncthreads();
+		const int go = s_go[0];
+		__syncthreads();
+		if (!go) return;
+		// every wave: what the main wrote in front of its word is in the L2 both share; this CU's L1 and the scalar cache may hold older lines
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+		if (!alpha_density_body(prm, a, smem, p, true)) return;
+	}
+	else {
 	PHD_STAMP_DECL;
 	PHD_STAMP(0);
 	sweep_body<ZB, HALF>(prm, a, smem);
@@ -306,15 +354,29 @@ __global__ __launch_bounds__(256, 1) void k_particle_chain(const DevParams prm, 
 	PHD_STAMP(2);
 	prune_merge_body(prm, a, cutcap, smem);
 	if (with_alpha) {
+		__shared__ int s_hgo;
+		if (threadIdx.x == 0) s_hgo = 0;
 		__syncthreads();
 		PHD_STAMP(3);
-		alpha_assoc_body<ZB, false, false, 1>(prm, a, cutcap, smem);
+		alpha_assoc_body<ZB, false, false, 1>(prm, a, cutcap, smem, nullptr, -1, a.dsplit ? &s_hgo : nullptr);
 		__syncthreads();
 		PHD_STAMP(4);
-		alpha_density_body(prm, a, smem);
+		if (!s_hgo) alpha_density_body(prm, a, smem);
+		else {
+			// (the helper has the sums: this workgroup's number is the set log-likelihood it has just written)
+			if (threadIdx.x == 0) {
+				const int p = a.p0 + (int) blockIdx.x;
+				const double sl = a.setll[p];
+				__hip_atomic_store(a.setll + p, sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				s_hgo = alpha_meet(a, p, false, sl) ? 1 : 0;
+			}
+			__syncthreads();
+			if (!s_hgo) return;
+		}
 		PHD_STAMP(5);
 	}
 	PHD_STAMP_FLUSH(5, 6);   // (diagnostic build, PHD_STAMP_KERNEL=5: the bodies' shares of the chain)
+	}
 	if (a.fold_nr) {
 		// The end of the step without a launch of its own: behind the barrier every wave's stores have left the CU; ONE thread
 		// publishes them (release fence, device scope: the XCD's L2 is written back — by every thread that is 1024 write-backs
@@ -326,7 +388,7 @@ __global__ __launch_bounds__(256, 1) void k_particle_chain(const DevParams prm, 
 		__syncthreads();
 		if (threadIdx.x == 0) {
 			__threadfence();
-			const int last = (atomicAdd(a.ticket + 2, 1u) == gridDim.x - 1) ? 1 : 0;   // (a word of its own: the device order's counter beside it never goes back)
+			const int last = ((int) atomicAdd(a.ticket + 2, 1u) == nmain - 1) ? 1 : 0;   // (a word of its own: the device order's counter beside it never goes back)
 			if (last) a.ticket[2] = 0;   // for the next launch (stream order)
 			__threadfence();
 			s_last = last;

@@ -19,6 +19,7 @@
 #include <string>
 #include <vector>
 
+#define DSPLIT_ROWS 1024     // particles the helpers' words are allocated for (k_particle_chain with helper workgroups)
 #define PHD_MAX_DEVICES 64   // device ordinals a process may hand to phd_create / phd_create_multi
 
 namespace {
@@ -44,6 +45,11 @@ struct phd_navigator {
 	hipStream_t own_stream = nullptr;  // created by phd_create; `stream` unless the host lent its own
 	static const int MAXSPLIT = 4;
 	int         nsplit = 0;            // sub-ranges a step's per-particle kernels are split into (0: chosen from the particle count)
+	int         dsplit_max = 256;      // ... and up to this many, with a helper workgroup per particle for the densities of WeightAlpha (two workgroups per
+	                                   // particle: 2 P workgroups fit the chip's 512 slots of that kernel at once; env PHD_DSPLIT_MAX, 0: never)
+	int         dsplit_late = 0;       // env PHD_DSPLIT_LATE (tests): the helpers report late, the main workgroups run both halves
+	unsigned int dseq = 0;             // launches of the chain with helpers so far (StepBufs::dstamp)
+	unsigned int* d_dsync = nullptr;   // the helpers' words (StepBufs); DSPLIT_ROWS particles
 	int         chain_max = 512;       // up to this many particles a step's per-particle kernels run as one launch (k_particle_chain; env PHD_CHAIN_MAX)
 	int         fold_nr = 0;           // 1 (env PHD_FOLD_NR): the chain ends the step itself — k_normalise_resample's body in its last workgroup; measured slower than the launch
 	bool        chain_ok[3] = {false, false, false};   // ... where the bodies' LDS arrays fit one workgroup (per measurement-block count 1, 2, 4)
@@ -268,6 +274,7 @@ StepBufs make_bufs(phd_navigator* nav)
 	b.nr_u = 0; b.nr_force = 0; b.nr_skip = 0; b.nr_frozen = 0; b.nr_src = nullptr; b.nr_info = nullptr; b.nr_sel_next = nullptr; b.nr_inslot = nullptr;
 	b.cand_count = nav->d_cand_count; b.denom = nav->d_denom;
 	b.cand = nav->d_cand; b.candcap = nav->candcap;
+	b.dsplit = 0; b.dstamp = 0; b.dsync = nav->d_dsync;
 	b.alm = nav->d_alm; b.aJ = nav->d_aJ; b.account = nav->d_account; b.srec = nav->d_srec; b.outw = nav->d_outw; b.wcopy = nav->d_wcopy; b.cover = nav->d_cover; b.stamps = nav->d_stamps; b.biglist = nav->d_biglist; b.bigstride = nav->Pcap + 2; b.ratio = nav->d_ratio; b.defer = 0; b.all_pairs = nav->all_pairs ? 1 : 0; b.stamp_kernel = getenv("PHD_STAMP_KERNEL") ? atoi(getenv("PHD_STAMP_KERNEL")) : 2;
 	return b;
 }
@@ -382,9 +389,18 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha, 
 	if (nav->chain_ok[zi] && P <= nav->chain_max) {
 		// a small particle set (up to two workgroups per CU): the whole per-particle chain as one launch
 		timer_begin(nav, T_CH);
+		// (a helper workgroup per particle for the densities when all 2 P workgroups can be on the chip together; the results are the
+		// same bits whether a helper comes in time or not: k_particle_chain)
+		StepBufs bc = b0;
+		const bool helpers = with_alpha && nav->d_dsync && P <= nav->dsplit_max && P <= DSPLIT_ROWS;
+		if (helpers) {
+			if (++nav->dseq >= 0x07ffffffu) nav->dseq = 1;
+			bc.dsplit = nav->dsplit_late > 0 ? 1 + nav->dsplit_late : 1; bc.dstamp = nav->dseq;
+		}
+		const int G = helpers ? 2 * P : P;
 		// (up to 32 measurements: the sweep with two components per visit, phd_sweep.h HALF)
-		if (ZB == 1 && nav->M <= 32) hipLaunchKernelGGL((k_particle_chain<1, true>), dim3(P), dim3(256), (size_t) chain_lds_bytes<1>(nav->cutcap), nav->stream, nav->dp, b0, nav->cutcap, with_alpha ? 1 : 0);
-		else hipLaunchKernelGGL(k_particle_chain<ZB>, dim3(P), dim3(256), (size_t) chain_lds_bytes<ZB>(nav->cutcap), nav->stream, nav->dp, b0, nav->cutcap, with_alpha ? 1 : 0);
+		if (ZB == 1 && nav->M <= 32) hipLaunchKernelGGL((k_particle_chain<1, true>), dim3(G), dim3(256), (size_t) chain_lds_bytes<1>(nav->cutcap), nav->stream, nav->dp, bc, nav->cutcap, with_alpha ? 1 : 0);
+		else hipLaunchKernelGGL(k_particle_chain<ZB>, dim3(G), dim3(256), (size_t) chain_lds_bytes<ZB>(nav->cutcap), nav->stream, nav->dp, bc, nav->cutcap, with_alpha ? 1 : 0);
 		timer_end(nav, T_CH);
 		HC(hipGetLastError());
 		nav->last_defer = 0;
@@ -799,6 +815,8 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	if (const char* e = getenv("PHD_NBIG")) nav->nbig = std::max(1, atoi(e));
 	if (const char* e = getenv("PHD_SPLIT")) nav->nsplit = std::max(0, atoi(e));
 	if (const char* e = getenv("PHD_CHAIN_MAX")) nav->chain_max = std::max(0, atoi(e));
+	if (const char* e = getenv("PHD_DSPLIT_MAX")) nav->dsplit_max = std::max(0, atoi(e));
+	if (const char* e = getenv("PHD_DSPLIT_LATE")) nav->dsplit_late = atoi(e);
 	if (const char* e = getenv("PHD_FOLD_NR")) nav->fold_nr = atoi(e) != 0;
 	if (const char* e = getenv("PHD_NR_GRID_MIN")) nav->nr_grid_min = std::max(0, atoi(e));
 	if (const char* e = getenv("PHD_PLAN_GRID_MIN")) nav->plan_grid_min = std::max(0, atoi(e));
@@ -846,6 +864,11 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	ok = ok && dalloc((void**) &nav->d_wcopy, (size_t) nav->Pcap * (nav->cap + nav->Mcap) * 8) && dalloc((void**) &nav->d_cover, (size_t) nav->Pcap * nav->cap * 4);
 	ok = ok && dalloc((void**) &nav->d_alm, (size_t) nav->Pcap * 3 * nav->Jcap * 8);
 	ok = ok && dalloc((void**) &nav->d_aJ, (size_t) nav->Pcap * 4) && dalloc((void**) &nav->d_account, (size_t) nav->Pcap * 8);
+	if (nav->dsplit_max > 0) {
+		const size_t rows = (size_t) std::min(nav->Pcap, (int) DSPLIT_ROWS);
+		ok = ok && dalloc((void**) &nav->d_dsync, rows * 3 * 4);
+		ok = ok && hipMemset(nav->d_dsync, 0, rows * 3 * 4) == hipSuccess;
+	}
 	ok = ok && dalloc((void**) &nav->d_jscratch, (size_t) nav->Pcap * alpha_jscratch_doubles(nav->Jcap) * 8);
 	nav->stagecap = std::max((size_t) nav->Pcap * 8 + 8, (size_t) 256 * 3);   // poses + weights | odometry + noise | measurements
 	ok = ok && dalloc((void**) &nav->d_stage, nav->stagecap * 8) && dalloc((void**) &nav->d_motion, ((size_t) nav->Pcap * 6 + 6) * 8);
@@ -960,7 +983,7 @@ void phd_destroy(phd_navigator* nav)
 	hipFree(nav->d_sel); hipFree(nav->d_inslot); hipFree(nav->d_mslot); hipFree(nav->d_z); hipFree(nav->d_emit_w); hipFree(nav->d_emit_idx); hipFree(nav->d_emit_rec);
 	hipFree(nav->d_emit_count); hipFree(nav->d_born_count); hipFree(nav->d_born_k); hipFree(nav->d_born_mean);
 	hipFree(nav->d_alpha); hipFree(nav->d_setll); hipFree(nav->d_src);
-	hipFree(nav->d_murty); hipFree(nav->d_bigws); hipFree(nav->d_bigws_used); hipFree(nav->d_jscratch); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_outw); hipFree(nav->d_wcopy); hipFree(nav->d_cover); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan); hipFree(nav->d_nrd); hipFree(nav->d_nri);
+	hipFree(nav->d_murty); hipFree(nav->d_bigws); hipFree(nav->d_bigws_used); hipFree(nav->d_jscratch); hipFree(nav->d_dsync); hipFree(nav->d_stamps); hipFree(nav->d_srec); hipFree(nav->d_outw); hipFree(nav->d_wcopy); hipFree(nav->d_cover); hipFree(nav->d_motion); hipFree(nav->d_quasi); hipFree(nav->d_alm); hipFree(nav->d_aJ); hipFree(nav->d_account); hipFree(nav->d_cand_count); hipFree(nav->d_denom); hipFree(nav->d_cand); hipFree(nav->d_gw); hipFree(nav->d_send); hipFree(nav->d_recv); hipFree(nav->d_plan); hipFree(nav->d_nrd); hipFree(nav->d_nri);
 	hipFree(nav->d_lw); hipFree(nav->d_dst_tab); hipFree(nav->d_recv_tab); hipFree(nav->plan.code); hipFree(nav->plan.fslot); hipFree(nav->plan.sendlist); hipFree(nav->plan.senddst); hipFree(nav->plan.counts);
 	if (nav->h_counts) hipHostFree(nav->h_counts);
 	for (void* q : nav->ipc_opened) hipIpcCloseMemHandle(q);

@@ -451,3 +451,45 @@ def test_landing_wait_in_its_own_wave_and_inside_the_unpack_kernel(nav_mod, monk
     one.close()
     for nv in navs:
         nv.close()
+
+
+# ---- two workgroups per particle in the one-launch chain: the density sums of WeightAlpha on a helper workgroup, beside the association -----
+@pytest.mark.parametrize("shape", [(40, 150, 24, "steady"), (256, 128, 32, "steady"), (256, 128, 32, "survey"), (24, 400, 40, "survey"),
+                                   (7, 60, 5, "steady"), (100, 128, 32, "steady")])
+def test_helper_workgroups_of_the_chain_change_no_bit(nav_mod, monkeypatch, shape):
+    """k_particle_chain with a helper workgroup per particle (PHD_DSPLIT_MAX particles and fewer): the helper runs alpha_density_body beside
+    the main workgroup's association and the two meet in alpha_meet — the same body and the same last line as without helpers, so
+    the SAME bits whether the helper takes the sums (helper in time, on the main's XCD), the main keeps them (PHD_DSPLIT_LATE=1:
+    every helper reports 0.5 ms late; 3: helpers nobody picks) or there are no helpers at all (PHD_DSPLIT_MAX=0). The first mode against
+    the oracle, so that "equal" means "right"; a frame whose map estimate outgrows the densities' LDS arrays (more than 128 landmarks:
+    never handed over) among them."""
+    P, Cc, M, prof = shape
+    f = Frame(P, Cc, M, 511, weight_profile=prof)
+    got = {}
+    for mode in ("helpers", "again", "late", "unpicked", "off", "other-end"):
+        monkeypatch.setenv("PHD_DSPLIT_MAX", "0" if mode == "off" else "256")
+        if mode == "other-end":   # the step's end inside the chain's launch (PHD_FOLD_NR=1; the default is a launch behind it): the finishers' count
+            monkeypatch.setenv("PHD_FOLD_NR", "1")
+        monkeypatch.setenv("PHD_DSPLIT_LATE", {"late": "1", "unpicked": "3"}.get(mode, "0"))
+        nav, p = _handle(nav_mod, f)
+        nav.run_stages(f.z)               # (the stages of one update, for WeightAlpha's values themselves; the state stays)
+        alphas = [nav.WeightAlpha(), nav.SetLogLikelihood()]
+        for step in range(3):
+            nav.SlamUpdate(None, f.z + 0.05 * step, u_resample=0.3 + 0.2 * step)
+        got[mode] = (nav.VehicleWeights, nav.resample_sources()[0], [nav.MapModel(i) for i in (0, P // 2, P - 1)], alphas)
+        if mode == "helpers":
+            st = orc.State(P, 700)
+            st.poses[:] = f.poses
+            st.w[:, :Cc], st.mean[:, :Cc], st.cov[:, :Cc], st.n[:] = f.w, f.mean, f.cov, Cc
+            for step in range(3):
+                _, src, _, _ = orc.slam_update(p, st, f.z + 0.05 * step, u=0.3 + 0.2 * step, threads=4)
+            assert np.array_equal(got[mode][1], src)
+            assert np.allclose(got[mode][0], st.weights, rtol=1e-6, atol=1e-300)
+        nav.close()
+    monkeypatch.delenv("PHD_FOLD_NR", raising=False)
+    for mode in ("again", "late", "unpicked", "off", "other-end"):
+        assert np.array_equal(got[mode][0], got["helpers"][0]) and np.array_equal(got[mode][1], got["helpers"][1]), mode
+        for a, b in zip(got[mode][3], got["helpers"][3]):
+            assert np.array_equal(a, b), mode
+        for a, b in zip(got[mode][2], got["helpers"][2]):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), mode
