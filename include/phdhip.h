@@ -178,7 +178,8 @@ int phd_slam_update(phd_navigator* nav, const double* z3, int nmeasurements,
  * waits inside a frame: upload (asynchronous), enqueue (asynchronous on the handle's stream), wait + collect status.
  * Steps may be queued back to back; a failed one is dropped as a whole together with those queued behind it, and
  * phd_sync reports it. Up to 512 particles (environment PHD_CHAIN_MAX) the per-particle part of a step is one kernel
- * launch. From 1024 particles on a step runs on two streams of the handle's own; phd_step_async directly behind
+ * launch (up to 256 — PHD_DSPLIT_MAX, 0: never — with a second workgroup per particle that runs WeightAlpha's density sums beside
+ * the association: the same results bit for bit). From 1024 particles on a step runs on two streams of the handle's own; phd_step_async directly behind
  * phd_step_async (no other call on the handle between them) is the fast path: the streams are not forked and joined around
  * each step, the end of a step runs on the stream that finishes last (results are bit-identical either way; any other call
  * on the handle, and a stream lent with phd_set_stream, take the fork / join order — INTEGRATION.md, "Posting steps back to

@@ -1042,6 +1042,9 @@ __device__ __forceinline__ void alpha_assoc_body(const DevParams& prm, const Ste
 		const int go = (J > 0 && J <= DENS_JL && helper_word == ((a.dstamp << 4) | my_xcd())) ? 1 : 0;
 		__hip_atomic_store(a.dsync + 3 * (size_t) p + 1, 2u * a.dstamp + (unsigned int) go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		*helper_go = go;
+#ifdef PHD_STAMPS   // (diagnostic build, PHD_STAMP_KERNEL=5: was the helper taken, and when — 100 MHz ticks; see k_particle_chain)
+		if (a.stamps && a.stamp_kernel == 5) { a.stamps[(size_t) p * 16 + 12] = go; a.stamps[(size_t) p * 16 + 13] = (double) wall_clock64(); }
+#endif
 	}
 
 	PHD_STAMP(3);

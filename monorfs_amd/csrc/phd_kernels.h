@@ -341,7 +341,18 @@ __global__ __launch_bounds__(256, 1) void k_particle_chain(const DevParams prm, 
 		// every wave: what the main wrote in front of its word is in the L2 both share; this CU's L1 and the scalar cache may hold older lines
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 		asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef PHD_STAMPS   // (slot 14: ticks from the main's hand-over to this point; slot 15: the helper's density sums, hand-over to end)
+		const long long tw_ = wall_clock64();
+		const bool fin_ = alpha_density_body(prm, a, smem, p, true);
+		if (threadIdx.x == 0 && a.stamps && a.stamp_kernel == 5) {
+			const double t0_ = a.stamps[(size_t) p * 16 + 13];
+			a.stamps[(size_t) p * 16 + 14] = (double) tw_ - t0_;
+			a.stamps[(size_t) p * 16 + 15] = (double) wall_clock64() - t0_;
+		}
+		if (!fin_) return;
+#else
 		if (!alpha_density_body(prm, a, smem, p, true)) return;
+#endif
 	}
 	else {
 	PHD_STAMP_DECL;
@@ -366,6 +377,9 @@ __global__ __launch_bounds__(256, 1) void k_particle_chain(const DevParams prm, 
 			// (the helper has the sums: this workgroup's number is the set log-likelihood it has just written)
 			if (threadIdx.x == 0) {
 				const int p = a.p0 + (int) blockIdx.x;
+#ifdef PHD_STAMPS   // (slot 11: the association behind the hand-over, ticks)
+				if (a.stamps && a.stamp_kernel == 5) a.stamps[(size_t) p * 16 + 11] = (double) wall_clock64() - a.stamps[(size_t) p * 16 + 13];
+#endif
 				const double sl = a.setll[p];
 				__hip_atomic_store(a.setll + p, sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				s_hgo = alpha_meet(a, p, false, sl) ? 1 : 0;
