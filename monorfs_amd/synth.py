@@ -13,6 +13,7 @@ CONFIGS = {   # BASELINE.json configs: particles, components, measurements, seed
     "C8": (16384, 512, 64, 1003),
     "S": (4096, 1024, 128, 1004),
     # tuning shapes (where the one-launch chain stops paying: phdhip.hip chain_max), not BASELINE configs
+    "A24": (24, 128, 32, 1001), "A64": (64, 128, 32, 1001), "A128": (128, 128, 32, 1001),   # (the reference's real-time regime: 20 - 200 particles)
     "A512": (512, 128, 32, 1001), "A1024": (1024, 128, 32, 1001), "B512": (512, 512, 64, 1002), "B1024": (1024, 512, 64, 1002),
     # rehearsal shapes of the multi-shard hosts: what 8 shards of A / B512 hold, as ONE handle
     "A2048": (2048, 128, 32, 1001), "B4096": (4096, 512, 64, 1002),
