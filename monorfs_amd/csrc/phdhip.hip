@@ -47,7 +47,8 @@ struct phd_navigator {
 	int         nsplit = 0;            // sub-ranges a step's per-particle kernels are split into (0: chosen from the particle count)
 	int         dsplit_max = 256;      // ... and up to this many, with a helper workgroup per particle for the densities of WeightAlpha (two workgroups per
 	                                   // particle: 2 P workgroups fit the chip's 512 slots of that kernel at once; env PHD_DSPLIT_MAX, 0: never)
-	int         dsplit_late = 0;       // env PHD_DSPLIT_LATE (tests): the helpers report late, the main workgroups run both halves
+	int         dsplit_late = 0;       // env PHD_DSPLIT_LATE (tests and measurements; StepBufs::dsplit = 1 + this): 1 the helpers report 0.5 ms late, 2 they leave at once,
+	                                   // 3 they report and wait but are never picked — in all three every main workgroup keeps its density sums
 	unsigned int dseq = 0;             // launches of the chain with helpers so far (StepBufs::dstamp)
 	unsigned int* d_dsync = nullptr;   // the helpers' words (StepBufs); DSPLIT_ROWS particles
 	int         chain_max = 512;       // up to this many particles a step's per-particle kernels run as one launch (k_particle_chain; env PHD_CHAIN_MAX)
