@@ -395,7 +395,10 @@ int launch_map_kernels(phd_navigator* nav, const StepBufs& b0, bool with_alpha, 
 		StepBufs bc = b0;
 		const bool helpers = with_alpha && nav->d_dsync && P <= nav->dsplit_max && P <= DSPLIT_ROWS;
 		if (helpers) {
-			if (++nav->dseq >= 0x07ffffffu) nav->dseq = 1;
+			if (++nav->dseq >= 0x07ffffffu) {   // (the numbers start again: no word of an earlier round may be taken for one of this round)
+				nav->dseq = 1;
+				HC(hipMemsetAsync(nav->d_dsync, 0, (size_t) std::min(nav->Pcap, (int) DSPLIT_ROWS) * 3 * 4, nav->stream));
+			}
 			bc.dsplit = nav->dsplit_late > 0 ? 1 + nav->dsplit_late : 1; bc.dstamp = nav->dseq;
 		}
 		const int G = helpers ? 2 * P : P;
@@ -818,6 +821,7 @@ phd_navigator* phd_create(const phd_params* params, int device)
 	if (const char* e = getenv("PHD_CHAIN_MAX")) nav->chain_max = std::max(0, atoi(e));
 	if (const char* e = getenv("PHD_DSPLIT_MAX")) nav->dsplit_max = std::max(0, atoi(e));
 	if (const char* e = getenv("PHD_DSPLIT_LATE")) nav->dsplit_late = atoi(e);
+	if (const char* e = getenv("PHD_DSPLIT_SEQ0")) nav->dseq = (unsigned int) std::max(0LL, atoll(e));   // (tests: launch numbers that start again soon)
 	if (const char* e = getenv("PHD_FOLD_NR")) nav->fold_nr = atoi(e) != 0;
 	if (const char* e = getenv("PHD_NR_GRID_MIN")) nav->nr_grid_min = std::max(0, atoi(e));
 	if (const char* e = getenv("PHD_PLAN_GRID_MIN")) nav->plan_grid_min = std::max(0, atoi(e));

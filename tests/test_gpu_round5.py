@@ -466,8 +466,10 @@ def test_helper_workgroups_of_the_chain_change_no_bit(nav_mod, monkeypatch, shap
     P, Cc, M, prof = shape
     f = Frame(P, Cc, M, 511, weight_profile=prof)
     got = {}
-    for mode in ("helpers", "again", "late", "unpicked", "off", "other-end"):
+    for mode in ("helpers", "again", "late", "unpicked", "off", "other-end", "numbers-start-again"):
         monkeypatch.setenv("PHD_DSPLIT_MAX", "0" if mode == "off" else "256")
+        # (the launches' numbers are 27 bits long: the handle of the last mode starts two launches short of their end)
+        monkeypatch.setenv("PHD_DSPLIT_SEQ0", str(0x07ffffff - 3) if mode == "numbers-start-again" else "0")
         if mode == "other-end":   # the step's end inside the chain's launch (PHD_FOLD_NR=1; the default is a launch behind it): the finishers' count
             monkeypatch.setenv("PHD_FOLD_NR", "1")
         monkeypatch.setenv("PHD_DSPLIT_LATE", {"late": "1", "unpicked": "3"}.get(mode, "0"))
@@ -487,7 +489,8 @@ def test_helper_workgroups_of_the_chain_change_no_bit(nav_mod, monkeypatch, shap
             assert np.allclose(got[mode][0], st.weights, rtol=1e-6, atol=1e-300)
         nav.close()
     monkeypatch.delenv("PHD_FOLD_NR", raising=False)
-    for mode in ("again", "late", "unpicked", "off", "other-end"):
+    monkeypatch.delenv("PHD_DSPLIT_SEQ0", raising=False)
+    for mode in ("again", "late", "unpicked", "off", "other-end", "numbers-start-again"):
         assert np.array_equal(got[mode][0], got["helpers"][0]) and np.array_equal(got[mode][1], got["helpers"][1]), mode
         for a, b in zip(got[mode][3], got["helpers"][3]):
             assert np.array_equal(a, b), mode
