@@ -2075,9 +2075,35 @@ __device__ __forceinline__ bool alpha_meet(const StepBufs& a, int p, bool have_r
 	return true;
 }
 
+// What alpha_density_body can do before the step has produced anything (the helper workgroup of k_particle_chain, while it waits):
+// the exponent table and the records of the PRIOR components of its first tile — they only need the prior mixture —, the
+// component's weight kept in the record's spare slot. Returns the thread's share of sum w_pred so far; the body is then called
+// with `pre` = true and that number and leaves those records as they are (the same arithmetic, done earlier).
+__device__ __forceinline__ double alpha_density_prestage(const StepBufs& a, double* pool, int p)
+{
+	double* const tile = pool;
+	double* const etab = tile + DENS_TILE * DENS_REC + 2 * (DENS_JL / 64) * 256;
+	const int tid = threadIdx.x;
+	const MixView vin = bank_view(a, SEL_IN);
+	const int n = vin.count[p];
+	const size_t sbi = in_base(a, p);
+	exp_tab_init(etab, tid);
+	double pc = 0;
+	if (tid < DENS_TILE && tid < n) {
+		double w, m[3], P[6], Pi[6], det;
+		load_comp(vin.rec + (sbi + tid) * MIX_REC, w, m, P);
+		pc = w;
+		inv_sym3(P, Pi, det);
+		gauss_record(w, m, Pi, PHD_INV_2PI / sqrt(fabs(det)), tile + tid * DENS_REC);
+		tile[tid * DENS_REC + 11] = w;
+	}
+	return pc;
+}
+
 // `meet` (the helper workgroup of k_particle_chain): the body ends with alpha_meet instead of WeightAlpha's last line; returns
-// whether this workgroup wrote the particle's alpha.
-__device__ __forceinline__ bool alpha_density_body(const DevParams& prm, const StepBufs& a, double* pool, int pin = -1, bool meet = false)
+// whether this workgroup wrote the particle's alpha. `pre`: alpha_density_prestage has run on this pool (pre_pcount: what it returned).
+__device__ __forceinline__ bool alpha_density_body(const DevParams& prm, const StepBufs& a, double* pool, int pin = -1, bool meet = false,
+                                                   bool pre = false, double pre_pcount = 0.0)
 {
 	constexpr int JL = DENS_JL;
 	double* const tile = pool;                                        // [DENS_TILE][12]
@@ -2103,7 +2129,7 @@ __device__ __forceinline__ bool alpha_density_body(const DevParams& prm, const S
 	double* partc = (J <= JL) ? partcl : gj;
 	const double* wcopy = a.wcopy + (size_t) p * (cap + a.Mcap);
 	const int* cover = a.cover + sbo;
-	exp_tab_init(etab, tid);
+	if (!pre) exp_tab_init(etab, tid);
 	__syncthreads();
 
 	// ---- phase 2: sum_j log v_pred(m_j), sum_j log v_corr(m_j) with v = full ungated mixture density (Map.cs:192-202)
@@ -2116,7 +2142,7 @@ __device__ __forceinline__ bool alpha_density_body(const DevParams& prm, const S
 	// over the predicted mixture adds ratio_c * (w_c N_c(m_j)) to the corrected sum as well, ratio_c = wcopy[c] / w_c
 	// (k_prune_merge, which also checks that the copy's moments are the component's up to Merge's rounding). The second
 	// sweep takes only the other corrected components (updated by a measurement, merged).
-	double plog_part = 0, clog_part = 0, pcount_part = 0;
+	double plog_part = 0, clog_part = 0, pcount_part = pre ? pre_pcount : 0.0;
 	{
 		const int JB = (J + 63) >> 6;
 		// (the sum of the prior weights, sum w_pred: added up where the records are staged below — thread tid takes the
@@ -2128,7 +2154,11 @@ __device__ __forceinline__ bool alpha_density_body(const DevParams& prm, const S
 				int c = (DENS_TILE < 256 && tid >= DENS_TILE) ? total : c0 + tid;
 				int cend;
 				if (src == 0) {
-					if (c < total) {
+					if (pre && c0 == 0 && c < n) {   // (staged ahead: only the copy's weight ratio is new)
+						const double w = tile[tid * DENS_REC + 11];
+						tile[tid * DENS_REC + 10] = (w > 0) ? wcopy[c] / w : 0.0;
+					}
+					else if (c < total) {
 						double w, m[3], P[6], Pi[6], det;
 						if (c < n) {
 							load_comp(vin.rec + (sbi + c) * MIX_REC, w, m, P);

@@ -314,8 +314,10 @@ __global__ __launch_bounds__(256, 1) void k_particle_chain(const DevParams prm, 
 		// would otherwise all sit on another XCD than their mains and never be picked; the last, incomplete group stays as it is)
 		const int h = (int) blockIdx.x - nmain;
 		const int p = a.p0 + (((h | 7) < nmain) ? (h & ~7) + ((h + nmain) & 7) : h);
-		int* const s_go = (int*) smem;
+		__shared__ int s_go[1];
 		if (!with_alpha || a.dsplit == 3) return;   // (3: a measuring switch — helpers that leave at once)
+		// (while it waits: what the density sums can have ready from the prior mixture alone)
+		const double pre_pcount = alpha_density_prestage(a, smem, p);
 		if (threadIdx.x == 0) {
 			unsigned int* w = a.dsync + 3 * (size_t) p;
 			if (a.dsplit == 2) {   // (test switch PHD_DSPLIT_LATE=1: a helper that reports 0.5 ms late — every main keeps its sums)
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void k_particle_chain(const DevParams prm, 
 		asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 #ifdef PHD_STAMPS   // (slot 14: ticks from the main's hand-over to this point; slot 15: the helper's density sums, hand-over to end)
 		const long long tw_ = wall_clock64();
-		const bool fin_ = alpha_density_body(prm, a, smem, p, true);
+		const bool fin_ = alpha_density_body(prm, a, smem, p, true, true, pre_pcount);
 		if (threadIdx.x == 0 && a.stamps && a.stamp_kernel == 5) {
 			const double t0_ = a.stamps[(size_t) p * 16 + 13];
 			a.stamps[(size_t) p * 16 + 14] = (double) tw_ - t0_;
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(256, 1) void k_particle_chain(const DevParams prm, 
 		}
 		if (!fin_) return;
 #else
-		if (!alpha_density_body(prm, a, smem, p, true)) return;
+		if (!alpha_density_body(prm, a, smem, p, true, true, pre_pcount)) return;
 #endif
 	}
 	else {
