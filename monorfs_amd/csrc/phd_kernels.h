@@ -275,6 +275,10 @@ __device__ __forceinline__ void plan_count_slot(const PlanGrid& pg, int g, int P
 
 #include "phd_resample.h"
 
+#ifndef PHD_HELPER_PRIO
+#define PHD_HELPER_PRIO 3   // s_setprio of the chain's helper workgroups while they run the density sums
+#endif
+
 // The per-particle chain of a step as ONE launch, for small particle sets (the real-time regime of the reference: 20 - 800
 // particles at 30 Hz, plots/scripts/chap3/S4-particles.sh:14-15; BASELINE config A): a particle's predict / correct / prune /
 // reweight touch nothing of another particle, so its workgroup runs the five kernels' bodies back to back, with a
@@ -340,6 +344,9 @@ __global__ __launch_bounds__(256, 1) void k_particle_chain(const DevParams prm, 
 		const int go = s_go[0];
 		__syncthreads();
 		if (!go) return;
+		// (the helper's sums are the longer of the two paths behind the hand-over: its waves go ahead of the main's where both sit on one
+		// SIMD — 256 particles 0.0862 -> 0.0855 ms, profiles/r05_chain_helpers_prio.txt)
+		__builtin_amdgcn_s_setprio(PHD_HELPER_PRIO);
 		// every wave: what the main wrote in front of its word is in the L2 both share; this CU's L1 and the scalar cache may hold older lines
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 		asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
